@@ -1,0 +1,312 @@
+#!/usr/bin/env python3
+"""Benchmark of the scan-matching / map-update hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config2|ref2level] [--particles P]
+
+A "step" is one lidar scan processed for every particle of the rank: search-field build
+from each particle's own map, pose-cube sweep with soft-max pose draw and confidence,
+occupancy-grid update at the matched pose, weight update + normalisation (sharded runs:
+the RCCL all-reduce of the normaliser).  All inputs of all steps (ranges, pose estimates,
+uniforms) are resident in HBM before the timed region; nothing is copied or synchronised
+inside it.
+
+Default workload = BASELINE.json configs[1] ("config2": 800x800 @ 0.1 m search field,
+36x41x41 pose cube, 180 beams) with the north-star's 64 particles per GPU.  Prints ONE JSON
+line (rank 0).  N > 1: launched by torch.distributed.run, one rank per GPU, particles
+sharded P per rank (weak scaling), value = whole-job particle-scans/s.
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import math
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
+
+WORKLOADS = {
+    # BASELINE.json configs[1]; SURVEY.md 8(d) "config 2": single-level match at 0.1 m
+    "config2": dict(unit=0.1, max_range=34.5, fov=math.pi, beams=180, map_m=100.0, search_radius=2.05,
+                    half_rad=0.30, sigma_cells=2, miss=0.15, coarse_factor=1, levels=1, wall=0.5,
+                    move_sigma=0.1, max_dev=0.25, turn_sigma=0.3,
+                    note="800x800@0.1m search field, 36x41x41 pose cube, 180 beams, single-level match + map update"),
+    # reference defaults (Algorithm/FastSlam.py:197-199): two-level match at 0.02 m
+    "ref2level": dict(unit=0.02, max_range=10.0, fov=math.pi, beams=180, map_m=50.0, search_radius=1.4,
+                      half_rad=0.25, sigma_cells=2, miss=0.15, coarse_factor=5, levels=2, wall=0.1,
+                      move_sigma=0.1, max_dev=0.25, turn_sigma=0.3,
+                      note="reference defaults: coarse 249^2/30x27x27 + fine 1241^2/30x11x11, 180 beams, map update"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
+    ap.add_argument("--particles", type=int, default=64, help="particles per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample")
+    return ap.parse_args()
+
+
+class Scenario:
+    """Synthetic world, trajectory, scans and per-particle pose estimates of one workload."""
+
+    def __init__(self, cfg, P, n_scans, seed=0, rank=0):
+        synth = importlib.import_module("slam-2d-lidar-scan_amd.synth")
+        self.cfg, self.P = cfg, P
+        u = cfg["unit"]
+        self.world = synth.make_world(cfg["map_m"], u, seed=seed, n_boxes=60)
+        self.origin = (-cfg["map_m"] / 2, -cfg["map_m"] / 2)
+        self.visited, self.total = synth.counts_from_world(self.world)
+        poses = synth.random_walk(self.world, u, self.origin, n_scans + 1, seed=seed + 1, step=0.4, max_radius=7.0)
+        self.poses = np.array(poses)
+        self.ranges = np.stack([synth.raycast(self.world, u, self.origin, p, cfg["fov"], cfg["beams"],
+                                              cfg["max_range"]) for p in poses[1:]])
+        rs = np.random.RandomState(1000 + rank)
+        # per-particle estimates: previous true pose + a small lattice offset (a spread-out particle cloud)
+        k = rs.randint(-2, 3, size=(n_scans, P, 2))
+        self.est = np.empty((n_scans, P, 3))
+        self.est[:, :, 0] = self.poses[:-1, None, 0] + k[:, :, 0] * u
+        self.est[:, :, 1] = self.poses[:-1, None, 1] + k[:, :, 1] * u
+        self.est[:, :, 2] = self.poses[1:, None, 2] + rs.normal(0, 0.02, size=(n_scans, P))
+        d = self.poses[1:, :2] - self.poses[:-1, :2]
+        self.dist = np.hypot(d[:, 0], d[:, 1])
+        self.psi = np.arctan2(d[:, 1], d[:, 0])
+        self.uniform = rs.random_sample((n_scans, P))
+
+
+class HotPath:
+    """Device state + the per-step launch sequence (no host round trips)."""
+
+    def __init__(self, cfg, P, scen, device):
+        pkg = importlib.import_module("slam-2d-lidar-scan_amd")
+        E = importlib.import_module("slam-2d-lidar-scan_amd.engine")
+        self.E, self.cfg, self.P = E, cfg, P
+        u = cfg["unit"]
+        self.lidar = E.LidarModel.get(u, cfg["max_range"], cfg["fov"], cfg["beams"], cfg["wall"])
+        first = E.MapState.create(cfg["map_m"], cfg["map_m"], {"x": 0.0, "y": 0.0}, u, device)
+        first.upload(scen.visited, scen.total)
+        maps = [first] + [first.clone() for _ in range(P - 1)]
+        self.eng = E.ParticleEngine(self.lidar, maps, device)
+        common = dict(search_radius_ctor=cfg["search_radius"], half_rad=cfg["half_rad"], move_sigma=cfg["move_sigma"],
+                      max_move_dev=cfg["max_dev"], turn_sigma=cfg["turn_sigma"])
+        cf = cfg["coarse_factor"]
+        self.coarse = E.SearchLevel(self.lidar, P, device, step=cf * u, sigma=cfg["sigma_cells"] / cf,
+                                    miss_prob=cfg["miss"], radius=cfg["search_radius"], fine=False, **common)
+        self.fine = None
+        if cfg["levels"] == 2:
+            self.fine = E.SearchLevel(self.lidar, P, device, step=u, sigma=cfg["sigma_cells"],
+                                      miss_prob=cfg["miss"] ** (2 / cf), radius=cf * u, fine=True, **common)
+        e = self.eng
+        self.d_ranges = e.to_device(scen.ranges)
+        self.d_est = e.to_device(scen.est)
+        self.d_uniform = e.to_device(scen.uniform)
+        psi_cs = np.stack([np.cos(scen.psi), np.sin(scen.psi)], axis=1)            # shared heading prior
+        self.d_psi = e.to_device(np.repeat(psi_cs[:, None, :], P, axis=1))
+        self.dist = scen.dist
+        self.m_coarse, self.m_fine = e.match_buffer("coarse"), e.match_buffer("fine")
+        self.d_logw = torch.zeros(P, dtype=torch.float64, device=device)
+        self.d_w = torch.zeros(P, dtype=torch.float64, device=device)
+        self.d_stats = torch.zeros(2, dtype=torch.float64, device=device)
+        self.L = E._lib.lib()
+        self.sharded = dist.is_initialized() and dist.get_world_size() > 1
+        self.par = importlib.import_module("slam-2d-lidar-scan_amd.parallel")
+        self.total_particles = P * (dist.get_world_size() if dist.is_initialized() else 1)
+
+    def step(self, s):
+        e, E = self.eng, self.E
+        est, rng = self.d_est[s], self.d_ranges[s]
+        e.field_build(self.coarse, est, 3)
+        e.sweep(self.coarse, est, 3, rng, float(self.dist[s]), self.d_psi[s], self.d_uniform[s], self.m_coarse)
+        final = self.m_coarse
+        if self.fine is not None:
+            e.field_build(self.fine, self.m_coarse, E.MATCH_DOUBLES)
+            e.sweep(self.fine, self.m_coarse, E.MATCH_DOUBLES, rng, float(self.dist[s]), None, None, self.m_fine)
+            final = self.m_fine
+        e.grid_update(final, E.MATCH_DOUBLES, rng)
+        logconf = self.m_coarse[:, 4].contiguous()         # Slam2dMatch.log_confidence
+        if self.sharded:
+            self.d_logw += logconf
+            w, logw, var = self.par.normalize_sharded(self.d_logw, self.total_particles)
+            self.d_logw.copy_(logw)
+            self.d_w.copy_(w)
+        else:
+            E._lib.check(self.L.slam2d_weights_normalize(E._ptr(self.d_logw), C.c_void_p(logconf.data_ptr()), self.P,
+                                                         E._ptr(self.d_w), E._ptr(self.d_stats), E._stream()), "weights")
+
+    def algorithmic_bytes(self, scen):
+        """SURVEY.md 8(d) per particle-scan, with the build's real storage: packed uint32 cell
+        (both counts) => 4 B per map cell read, 8 B per updated cell; float32 field; float64 cube."""
+        lid, out = self.lidar, {}
+        for name, lv in (("coarse", self.coarse), ("fine", self.fine)):
+            if lv is None:
+                continue
+            f = int(2 * lv.reach / lv.step) + 1
+            wm = int(2 * lv.reach / lid.unit)
+            out[name] = dict(scatter=4 * wm * wm + f * f, blur=f * f + 4 * f * f,
+                             sweep=4 * f * f + 8 * lid.beams + 8 * lv.ntheta * lv.nx * lv.nx)
+        # update: touched cells of one representative scan (cell-major classification on the host LUT)
+        rng = scen.ranges[0]
+        S, B = lid.num_spokes, lid.beams
+        beam = (lid.bin.astype(np.int64) - lid.spoke_start) % S
+        own = beam < B
+        rb = rng[np.where(own, beam, 0)]
+        hw = lid.wall_thickness / 2
+        empty = own & (rb < lid.max_range) & (lid.r < rb - hw)
+        occ = own & (lid.r > rb - hw) & (lid.r < rb + hw)
+        out["update"] = dict(touched_cells=int(empty.sum() + occ.sum()),
+                             per_particle=8 * int(empty.sum() + occ.sum()), shared_lut=10 * lid.width ** 2)
+        return out
+
+
+def cpu_baseline(cfg, scen, target_seconds):
+    """The CPU oracle (a NumPy port of the reference; oracle/slam_oracle.py) on the same
+    workload, one process, one core, on a bounded sample of particle-scans."""
+    from oracle import slam_oracle as so
+    u = cfg["unit"]
+    t0 = time.perf_counter()
+    lut = so.SpokeLUT(u, cfg["max_range"], cfg["fov"], cfg["beams"])
+    og = so.GridOracle(cfg["map_m"], cfg["map_m"], {"x": 0.0, "y": 0.0}, u, cfg["fov"], cfg["beams"],
+                       cfg["max_range"], cfg["wall"], lut=lut)
+    og.visited[:], og.total[:] = scen.visited, scen.total
+    sm = so.MatcherOracle(og, cfg["search_radius"], cfg["half_rad"], cfg["sigma_cells"], cfg["move_sigma"],
+                          cfg["max_dev"], cfg["turn_sigma"], cfg["miss"], cfg["coarse_factor"],
+                          rng=np.random.RandomState(0))
+    setup = time.perf_counter() - t0
+    units, t_start = 0, time.perf_counter()
+    n_scans, P = scen.est.shape[:2]
+    while True:
+        s, p = units // P % n_scans, units % P
+        x, y, th = scen.est[s, p]
+        ranges = scen.ranges[s]
+        reading = {"x": x, "y": y, "theta": th, "range": ranges}
+        if cfg["levels"] == 2:
+            matched, _ = sm.matchScan(reading, scen.dist[s], scen.psi[s], 2, matchMax=False)
+        else:
+            xr, yr, prob = sm.frameSearchSpace(x, y, u, cfg["sigma_cells"], cfg["miss"])
+            matched, _, _ = sm.searchToMatch(prob, x, y, th, ranges, xr, yr, cfg["search_radius"], cfg["half_rad"], u,
+                                             scen.dist[s], scen.psi[s], fineSearch=False, matchMax=False)
+        og.update_cell_major(matched)
+        units += 1
+        el = time.perf_counter() - t_start
+        if el >= target_seconds or units >= 4 * P:
+            break
+    return dict(value=units / el, unit="particle-scans/s", cores=1, kind="port",
+                sample=f"{units} particle-scans of the same workload (scan(s) 0..{(units - 1) // P}, "
+                       f"{el:.1f} s; NumPy port of the reference, single process; LUT/setup {setup:.1f} s excluded)",
+                host_cores_available=os.cpu_count())
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert world == max(1, args.gpus) or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    E = importlib.import_module("slam-2d-lidar-scan_amd.engine")
+    lib = E._lib.lib()
+
+    cfg = WORKLOADS[args.workload]
+    P, K, W = args.particles, args.steps, args.warmup
+    scen = Scenario(cfg, P, K + W, seed=0, rank=rank)
+    hot = HotPath(cfg, P, scen, device)
+
+    for s in range(W):
+        hot.step(s)
+    flags = hot.eng.take_flags()        # synchronises; raises on any fault
+    stages = [E._lib.STAGE_SWEEP, E._lib.STAGE_BLUR, E._lib.STAGE_SCATTER, E._lib.STAGE_UPDATE,
+              E._lib.STAGE_SELECT, E._lib.STAGE_ENDPOINTS]
+    E._lib.check(lib.slam2d_prof_enable(sum(1 << s for s in stages), 4 * K + 8), "prof_enable")
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(W, W + K):
+        hot.step(s)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    flags = hot.eng.take_flags()
+    lib.slam2d_prof_disable()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    stage_ms = {}
+    for s in stages:
+        tot, n = C.c_double(0), C.c_int32(0)
+        E._lib.check(lib.slam2d_prof_collect(s, C.byref(tot), C.byref(n)), "prof_collect")
+        if n.value:
+            stage_ms[E._lib.STAGE_NAMES[s]] = dict(total_ms=tot.value, launches=n.value, avg_us=1e3 * tot.value / n.value)
+
+    if rank == 0:
+        total_units = P * world * K
+        ab = hot.algorithmic_bytes(scen)
+        # dominant kernel = largest measured total time over the timed region
+        dom = max(stage_ms, key=lambda k: stage_ms[k]["total_ms"])
+        per_unit = {"k_sweep": sum(v["sweep"] for k, v in ab.items() if k != "update"),
+                    "k_blur_clamp": sum(v["blur"] for k, v in ab.items() if k != "update"),
+                    "k_occ_scatter": sum(v["scatter"] for k, v in ab.items() if k != "update"),
+                    "k_grid_update": ab["update"]["per_particle"]}
+        launches_per_step = stage_ms[dom]["launches"] / K
+        bytes_per_launch = per_unit.get(dom, 0) * P / launches_per_step
+        if dom == "k_grid_update":
+            bytes_per_launch += ab["update"]["shared_lut"]
+        achieved = bytes_per_launch / (stage_ms[dom]["avg_us"] * 1e-6) / 1e9
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(f"{args.workload}:{dom}")
+        out = {
+            "metric": "scans/sec (180-beam) x particles at fixed search volume",
+            "value": total_units / elapsed, "unit": "particle-scans/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 field / f64 accumulate / u32 packed counts", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {cfg['note']}", "particles_per_gpu": P,
+                       "total_particles": P * world, "pose_hypotheses_per_particle_scan":
+                       hot.coarse.ntheta * hot.coarse.nx ** 2 + (hot.fine.ntheta * hot.fine.nx ** 2 if hot.fine else 0),
+                       "parallelism": f"particles sharded x{world}, all-reduce of the weight normaliser"
+                       if world > 1 else "single GPU"},
+            "scans_per_sec": K / elapsed,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "avg_launch_us": stage_ms[dom]["avg_us"]},
+            "stages": {k: {"avg_us": round(v["avg_us"], 2), "launches": v["launches"]} for k, v in stage_ms.items()},
+            "algorithmic_bytes_per_particle_scan": ab,
+            "fault_flags": int(np.bitwise_or.reduce(flags)) if len(flags) else 0,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, scen, args.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

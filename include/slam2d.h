@@ -1,0 +1,240 @@
+/*
+ * slam2d.h -- C ABI of libslam2d_hip.so: MI355X (gfx950) kernels for the 2-D lidar
+ * FastSLAM hot path of xiaofeng419/SLAM-2D-LIDAR-SCAN.
+ *
+ * The reference is pure Python and has no FFI layer; its boundary for this path is
+ * the class surface of Utils/OccupancyGrid.py:OccupancyGrid and
+ * Utils/ScanMatcher_OGBased.py:ScanMatcher as driven by Algorithm/FastSlam.py
+ * (SURVEY.md section 8b).  Each entry point below replaces the body of one of
+ * those methods for a batch of P particles; the Python classes in
+ * slam-2d-lidar-scan_amd/ keep the reference's constructor/method/attribute
+ * surface and call these through ctypes (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - plain C: PODs, raw pointers, sizes; no C++ or torch types.
+ *   - every pointer named d_* (and every pointer inside the structs) is DEVICE memory
+ *     owned by the caller (the Python side allocates it as torch tensors);
+ *     the library allocates nothing and keeps no state between calls.
+ *   - every call enqueues work on `stream` (a hipStream_t passed as void*) and returns
+ *     without synchronising; results are ordered after the call on that stream.
+ *   - return value: 0 on success, otherwise a hipError_t code (> 0) or a
+ *     SLAM2D_E_* code (< 0).  No exceptions cross the boundary.
+ *   - data-dependent faults (window outside the map, count overflow, cell list
+ *     overflow) are reported by OR-ing SLAM2D_F_* bits into d_flags[p]; the offending
+ *     access is skipped, never performed out of bounds.
+ *   - row-major everywhere; images are [rows = y][cols = x].
+ *
+ * Cell format of a particle's map (one uint32 per cell):
+ *     bits 31..16 = occupancyGridVisited count, bits 15..0 = occupancyGridTotal count
+ *   (reference: two float64 arrays initialised to 1 and 2, Utils/OccupancyGrid.py:13-14;
+ *    hit: visited += 2, total += 2; miss: total += 1, :148-152).  A cell is occupied
+ *   iff 2*visited > total (== visited/total > 0.5, Utils/ScanMatcher_OGBased.py:29-31).
+ *   Counts saturate the format after 32766 observations of one cell; the update
+ *   kernel raises SLAM2D_F_COUNT_OVERFLOW instead of wrapping.
+ */
+#ifndef SLAM2D_H
+#define SLAM2D_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLAM2D_ABI_VERSION 1
+
+/* library error codes (negative; positive values are hipError_t) */
+#define SLAM2D_E_BADARG   (-1)
+#define SLAM2D_E_TOOLARGE (-2)   /* a size exceeds a compiled-in limit */
+
+/* per-particle fault bits OR-ed into d_flags[p] */
+#define SLAM2D_F_WINDOW_OUTSIDE_MAP 0x01u  /* search window not inside the map: grow first (checkAndExapndOG) */
+#define SLAM2D_F_FIELD_INDEX        0x02u  /* an occupied cell mapped outside the field (reference: IndexError) */
+#define SLAM2D_F_ENDPOINT_OUTSIDE   0x04u  /* a beam endpoint +/- search radius left the field */
+#define SLAM2D_F_UPDATE_OUTSIDE_MAP 0x08u  /* map update touched a cell outside the map */
+#define SLAM2D_F_COUNT_OVERFLOW     0x10u  /* a 16-bit count would overflow */
+#define SLAM2D_F_FLOOR_REDO         0x20u  /* informational: field minimum != analytic floor, clamp pass redone */
+
+#define SLAM2D_INIT_CELL 0x00010002u       /* visited = 1, total = 2 */
+#define SLAM2D_MAX_BLUR_RADIUS 16
+#define SLAM2D_MAX_BEAMS 2048
+
+/* One particle's map (device-resident).  X[cols] / Y[rows] are the stored cell-centre
+ * coordinates (reference OccupancyGridX[0, :] / OccupancyGridY[:, 0]; rank-1 by
+ * construction, growth included -- Utils/OccupancyGrid.py:12,83-85).  lim_* mirror
+ * mapXLim / mapYLim (:19-20,86-89). */
+typedef struct {
+    uint32_t*     cells;     /* [rows][pitch] */
+    const double* X;         /* [cols] */
+    const double* Y;         /* [rows] */
+    int32_t rows, cols, pitch, _pad;
+    double  lim_x0, lim_x1, lim_y0, lim_y1;
+} Slam2dMap;
+
+/* Lidar + polar spoke lookup table shared by all particles
+ * (Utils/OccupancyGrid.py:22-57).  lut_bin / lut_r are the cell-major form of
+ * radByX/radByY/radByR: spoke bin and radius of every cell of the W x W window. */
+typedef struct {
+    double unit;             /* unitGridSize */
+    double max_range;        /* lidarMaxRange */
+    double fov;              /* lidarFOV */
+    double wall_half;        /* wallThickness / 2 */
+    int32_t beams;           /* numSamplesPerRev */
+    int32_t num_spokes;      /* numSpokes */
+    int32_t spoke_start;     /* spokesStartIdx */
+    int32_t lut_w;           /* W = 2*int(max_range/unit)+1 */
+    const uint16_t* lut_bin; /* [W][W] */
+    const double*   lut_r;   /* [W][W] */
+    const double*   lut_xs;  /* [W]  linspace(-R, R, W) */
+} Slam2dLidar;
+
+/* Geometry of one particle's search field at one level, written by
+ * slam2d_field_build and read by slam2d_sweep. */
+typedef struct {
+    double xlo, ylo;         /* xRangeList[0], yRangeList[0] */
+    double xhi, yhi;
+    double cx, cy;           /* window centre (the pose estimate) */
+    double field_min;        /* min of the blurred field (probMin) */
+    int32_t fh, fw;          /* field rows / cols actually used (<= fmax) */
+    int32_t mx0, mx1;        /* map column window [mx0, mx1) */
+    int32_t my0, my1;        /* map row window    [my0, my1) */
+    int32_t redo, _pad;
+    unsigned long long min_bits; /* scratch: order-preserving bits of the running minimum */
+} Slam2dFrame;
+
+/* One search level (coarse or fine) for P particles: parameters + workspaces.
+ * Reference: the two halves of ScanMatcher.matchScan,
+ * Utils/ScanMatcher_OGBased.py:53-60 (coarse) and :65-73 (fine). */
+typedef struct {
+    /* ---- field build (frameSearchSpace + generateProbSearchSpace, :20-45) ---- */
+    double step;             /* unitLength: coarseFactor*unit or unit */
+    double reach;            /* 1.1*lidarMaxRange + searchRadius (ctor value, both levels) */
+    double log_miss;         /* log(missMatchProb) of this level */
+    double floor_value;      /* analytic field minimum: blur of an all-free neighbourhood */
+    int32_t blur_radius;     /* int(4*sigma + 0.5) */
+    int32_t fmax;            /* max field rows/cols over particles: int(2*reach/step) + 2 */
+    int32_t fpitch;          /* row pitch (elements) of field / occ images, >= fmax */
+    int32_t wmax;            /* max map-window edge: int(2*reach/unit) + 3 */
+    const double* blur_w;    /* [2*blur_radius+1] normalised Gaussian taps */
+    /* ---- cube scoring (searchToMatch, :91-151) ---- */
+    int32_t ncell;           /* int(searchRadius/step): cube is [ntheta][2*ncell+1][2*ncell+1] */
+    int32_t ntheta;
+    int32_t fine;            /* 1: priors are zero (fineSearch=True) */
+    int32_t kmax;            /* capacity of a per-theta cell list (>= beams) */
+    const double* thetas;    /* [ntheta] thetaRange (:114) */
+    const double* theta_cos; /* [ntheta] np.cos(thetaRange) */
+    const double* theta_sin; /* [ntheta] */
+    double rv_coef;          /* -(1 / (2 * moveRSigma**2))  (:101) */
+    double tw_coef;          /* -1 / (2 * turnSigma**2)     (:108) */
+    double max_move_dev;     /* maxMoveDeviation            (:103) */
+    /* ---- workspaces, all device, sized for P particles ---- */
+    Slam2dFrame* frames;     /* [P] */
+    int32_t* axis_x;         /* [P][wmax] field column of every window map column */
+    int32_t* axis_y;         /* [P][wmax] */
+    uint8_t* occ;            /* [P][fmax][fpitch] */
+    float*   field;          /* [P][fmax][fpitch]  probSP, float32 */
+    int32_t* cells;          /* [P][ntheta][kmax] unique endpoint cells (patch-corner offsets) */
+    int32_t* kcount;         /* [P][ntheta] */
+    double*  prior;          /* [P][2][ny][nx]  rv plane, thetaWeight plane */
+    double*  cube;           /* [P][ntheta][ny][nx] convTotal */
+} Slam2dLevel;
+
+/* Result of one level for one particle. */
+typedef struct {
+    double x, y, theta;      /* matchedReading pose (:142-143) */
+    double confidence;       /* sum(exp(convTotal)) (:141); 0 when it underflows */
+    double log_confidence;   /* log of the same, finite when confidence underflows */
+    double best_score;       /* max(convTotal) */
+    int32_t pick;            /* flat cube index chosen (argmax or soft-max draw) */
+    int32_t argmax;          /* flat cube index of the maximum (lowest index on ties) */
+} Slam2dMatch;
+
+/* ------------------------------------------------------------------------- */
+
+int slam2d_abi_version(void);
+/* sizeof() of the PODs above as compiled, so the binding can verify its mirror. */
+int slam2d_sizeof(const char* type_name);
+/* number of visible HIP devices (<= 0: none); never raises. */
+int slam2d_device_count(void);
+
+/* frameSearchSpace + generateProbSearchSpace for P particles
+ * (Utils/ScanMatcher_OGBased.py:20-45).
+ *   d_centre[p*centre_stride + 0..1] = (estimatedX, estimatedY) of particle p.
+ * Writes level->frames[p] and level->field[p].  The window must already lie inside
+ * each map (the caller performs checkAndExapndOG growth, :27); otherwise
+ * SLAM2D_F_WINDOW_OUTSIDE_MAP is raised and the window is clipped. */
+int slam2d_field_build(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2dMap* d_maps,
+                       int32_t P, const double* d_centre, int32_t centre_stride,
+                       uint32_t* d_flags, void* stream);
+
+/* searchToMatch for P particles (Utils/ScanMatcher_OGBased.py:91-151).
+ *   d_est[p*est_stride + 0..2] = (estimatedX, estimatedY, estimatedTheta)
+ *   d_ranges[beams]            = rMeasure (shared by all particles)
+ *   est_moving_dist            = estMovingDist
+ *   d_psi_cs[P][2]             = (math.cos, math.sin) of estMovingTheta, NaN pair for None
+ *                                (NULL: None for every particle; ignored when level->fine)
+ *   d_uniform[P]               = one uniform in [0,1) per particle for the soft-max draw
+ *                                (matchMax=False, :136-139); NULL selects argmax (matchMax=True)
+ * Writes level->cube[p] (convTotal) and d_out[p]. */
+int slam2d_sweep(const Slam2dLidar* lidar, const Slam2dLevel* level, int32_t P,
+                 const double* d_est, int32_t est_stride, const double* d_ranges,
+                 double est_moving_dist, const double* d_psi_cs, const double* d_uniform,
+                 Slam2dMatch* d_out, uint32_t* d_flags, void* stream);
+
+/* updateOccupancyGrid for P particles (Utils/OccupancyGrid.py:127-159), as a dense
+ * sweep of the W x W lidar window (each window cell is owned by exactly one beam).
+ *   d_pose[p*pose_stride + 0..2] = matched (x, y, theta)
+ *   d_beam_shift: NULL, or [P][beams][2] int32 (dx, dy) index shifts reproducing the
+ *                 reference's stale-index writes when the map grew during that beam
+ *                 (Utils/OccupancyGrid.py:144-147). */
+int slam2d_grid_update(const Slam2dLidar* lidar, const Slam2dMap* d_maps, int32_t P,
+                       const double* d_pose, int32_t pose_stride, const double* d_ranges,
+                       int32_t* d_axis_scratch /* [P][2][lut_w] */, const int32_t* d_beam_shift,
+                       uint32_t* d_flags, void* stream);
+
+/* Particle.update's `weight *= confidence` in the log domain followed by
+ * ParticleFilter.normalizeWeights / weightUnbalanced (Algorithm/FastSlam.py:30-48,135).
+ *   d_logw[N]    in/out: log-weights of ALL N particles (after an all-gather when sharded)
+ *   d_logconf[N] log-confidences to add first (NULL: none)
+ *   d_w[N]       out: normalised weights
+ *   d_stats[2]   out: [variance = sum (w - 1/N)^2, log of the pre-normalisation weight sum] */
+int slam2d_weights_normalize(double* d_logw, const double* d_logconf, int32_t N,
+                             double* d_w, double* d_stats, void* stream);
+
+/* ParticleFilter.resample's state movement (Algorithm/FastSlam.py:56-61) for maps of
+ * identical shape: dst[p] = src[d_index[p]].  Ragged maps are copied by the host with
+ * plain device-to-device copies instead. */
+int slam2d_gather_maps(const Slam2dMap* d_src, const Slam2dMap* d_dst, const int32_t* d_index,
+                       int32_t P, int64_t cells_per_map, void* stream);
+
+/* Fill a map with SLAM2D_INIT_CELL (np.ones / 2*np.ones, Utils/OccupancyGrid.py:13-14). */
+int slam2d_map_fill(uint32_t* d_cells, int64_t n, uint32_t value, void* stream);
+
+/* Per-stage timing for bench.py's roofline figure: when a stage's bit is enabled, every
+ * launch of that stage's kernel is bracketed by a HIP event pair on the launch stream
+ * (up to `capacity` launches).  slam2d_prof_collect synchronises on the recorded
+ * events, returns their summed duration and launch count, and resets the stage. */
+#define SLAM2D_STAGE_SWEEP     0   /* k_sweep: pose-cube scoring */
+#define SLAM2D_STAGE_BLUR      1   /* k_blur_clamp: separable blur + clamp */
+#define SLAM2D_STAGE_SCATTER   2   /* k_occ_scatter: map window -> occupied field cells */
+#define SLAM2D_STAGE_UPDATE    3   /* k_grid_update: occupancy-grid update */
+#define SLAM2D_STAGE_SELECT    4   /* k_select: argmax / soft-max draw / confidence */
+#define SLAM2D_STAGE_ENDPOINTS 5   /* k_endpoints: unique endpoint cells */
+#define SLAM2D_STAGE_COUNT     6
+int  slam2d_prof_enable(uint32_t stage_mask, int32_t capacity);
+int  slam2d_prof_collect(int32_t stage, double* total_ms, int32_t* launches);
+void slam2d_prof_disable(void);
+
+/* Timing helper for bench.py: HIP events on the caller's stream.
+ * slam2d_timer_create -> opaque handle; _start/_stop record events on `stream`;
+ * _elapsed_ms synchronises on the stop event and returns milliseconds. */
+void* slam2d_timer_create(void);
+void  slam2d_timer_destroy(void* timer);
+int   slam2d_timer_start(void* timer, void* stream);
+int   slam2d_timer_stop(void* timer, void* stream);
+int   slam2d_timer_elapsed_ms(void* timer, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLAM2D_H */

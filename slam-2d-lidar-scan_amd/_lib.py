@@ -1,0 +1,165 @@
+"""ctypes binding of libslam2d_hip.so (the C ABI in include/slam2d.h).
+
+There is no CPU fallback: if the shared library is missing or was not built,
+``lib()`` raises.  ``build_library()`` compiles it in-tree with hipcc for
+gfx950 (cross-compiles without a GPU).
+"""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO_DIR = os.path.dirname(PKG_DIR)
+LIB_PATH = os.path.join(PKG_DIR, "libslam2d_hip.so")
+SRC_PATH = os.path.join(PKG_DIR, "csrc", "slam2d.hip")
+INCLUDE_DIR = os.path.join(REPO_DIR, "include")
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+# fault bits (include/slam2d.h SLAM2D_F_*)
+F_WINDOW_OUTSIDE_MAP = 0x01
+F_FIELD_INDEX = 0x02
+F_ENDPOINT_OUTSIDE = 0x04
+F_UPDATE_OUTSIDE_MAP = 0x08
+F_COUNT_OVERFLOW = 0x10
+F_FLOOR_REDO = 0x20
+FATAL_FLAGS = F_WINDOW_OUTSIDE_MAP | F_FIELD_INDEX | F_ENDPOINT_OUTSIDE | F_UPDATE_OUTSIDE_MAP | F_COUNT_OVERFLOW
+FLAG_NAMES = {
+    F_WINDOW_OUTSIDE_MAP: "search window outside the map (grow the map first)",
+    F_FIELD_INDEX: "occupied cell mapped outside the search field",
+    F_ENDPOINT_OUTSIDE: "beam endpoint +/- search radius left the search field",
+    F_UPDATE_OUTSIDE_MAP: "map update touched a cell outside the map",
+    F_COUNT_OVERFLOW: "16-bit cell count overflow",
+    F_FLOOR_REDO: "field minimum differed from the analytic floor (clamp redone)",
+}
+INIT_CELL = 0x00010002
+MAX_BLUR_RADIUS = 16
+MAX_BEAMS = 2048
+
+STAGE_SWEEP, STAGE_BLUR, STAGE_SCATTER, STAGE_UPDATE, STAGE_SELECT, STAGE_ENDPOINTS = range(6)
+STAGE_NAMES = {STAGE_SWEEP: "k_sweep", STAGE_BLUR: "k_blur_clamp", STAGE_SCATTER: "k_occ_scatter",
+               STAGE_UPDATE: "k_grid_update", STAGE_SELECT: "k_select", STAGE_ENDPOINTS: "k_endpoints"}
+
+_vp = C.c_void_p
+
+
+class Slam2dMap(C.Structure):
+    _fields_ = [("cells", _vp), ("X", _vp), ("Y", _vp),
+                ("rows", C.c_int32), ("cols", C.c_int32), ("pitch", C.c_int32), ("_pad", C.c_int32),
+                ("lim_x0", C.c_double), ("lim_x1", C.c_double), ("lim_y0", C.c_double), ("lim_y1", C.c_double)]
+
+
+class Slam2dLidar(C.Structure):
+    _fields_ = [("unit", C.c_double), ("max_range", C.c_double), ("fov", C.c_double), ("wall_half", C.c_double),
+                ("beams", C.c_int32), ("num_spokes", C.c_int32), ("spoke_start", C.c_int32), ("lut_w", C.c_int32),
+                ("lut_bin", _vp), ("lut_r", _vp), ("lut_xs", _vp)]
+
+
+class Slam2dFrame(C.Structure):
+    _fields_ = [("xlo", C.c_double), ("ylo", C.c_double), ("xhi", C.c_double), ("yhi", C.c_double),
+                ("cx", C.c_double), ("cy", C.c_double), ("field_min", C.c_double),
+                ("fh", C.c_int32), ("fw", C.c_int32), ("mx0", C.c_int32), ("mx1", C.c_int32),
+                ("my0", C.c_int32), ("my1", C.c_int32), ("redo", C.c_int32), ("_pad", C.c_int32),
+                ("min_bits", C.c_uint64)]
+
+
+class Slam2dLevel(C.Structure):
+    _fields_ = [("step", C.c_double), ("reach", C.c_double), ("log_miss", C.c_double), ("floor_value", C.c_double),
+                ("blur_radius", C.c_int32), ("fmax", C.c_int32), ("fpitch", C.c_int32), ("wmax", C.c_int32),
+                ("blur_w", _vp),
+                ("ncell", C.c_int32), ("ntheta", C.c_int32), ("fine", C.c_int32), ("kmax", C.c_int32),
+                ("thetas", _vp), ("theta_cos", _vp), ("theta_sin", _vp),
+                ("rv_coef", C.c_double), ("tw_coef", C.c_double), ("max_move_dev", C.c_double),
+                ("frames", _vp), ("axis_x", _vp), ("axis_y", _vp), ("occ", _vp), ("field", _vp),
+                ("cells", _vp), ("kcount", _vp), ("prior", _vp), ("cube", _vp)]
+
+
+class Slam2dMatch(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("theta", C.c_double),
+                ("confidence", C.c_double), ("log_confidence", C.c_double), ("best_score", C.c_double),
+                ("pick", C.c_int32), ("argmax", C.c_int32)]
+
+
+STRUCTS = {"Slam2dMap": Slam2dMap, "Slam2dLidar": Slam2dLidar, "Slam2dFrame": Slam2dFrame,
+           "Slam2dLevel": Slam2dLevel, "Slam2dMatch": Slam2dMatch}
+
+# name -> (restype, argtypes); every symbol include/slam2d.h declares
+SIGNATURES = {
+    "slam2d_abi_version": (C.c_int, []),
+    "slam2d_sizeof": (C.c_int, [C.c_char_p]),
+    "slam2d_device_count": (C.c_int, []),
+    "slam2d_field_build": (C.c_int, [C.POINTER(Slam2dLidar), C.POINTER(Slam2dLevel), _vp, C.c_int32, _vp, C.c_int32,
+                                     _vp, _vp]),
+    "slam2d_sweep": (C.c_int, [C.POINTER(Slam2dLidar), C.POINTER(Slam2dLevel), C.c_int32, _vp, C.c_int32, _vp,
+                               C.c_double, _vp, _vp, _vp, _vp, _vp]),
+    "slam2d_grid_update": (C.c_int, [C.POINTER(Slam2dLidar), _vp, C.c_int32, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
+    "slam2d_weights_normalize": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, _vp]),
+    "slam2d_gather_maps": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int64, _vp]),
+    "slam2d_map_fill": (C.c_int, [_vp, C.c_int64, C.c_uint32, _vp]),
+    "slam2d_prof_enable": (C.c_int, [C.c_uint32, C.c_int32]),
+    "slam2d_prof_collect": (C.c_int, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "slam2d_prof_disable": (None, []),
+    "slam2d_timer_create": (_vp, []),
+    "slam2d_timer_destroy": (None, [_vp]),
+    "slam2d_timer_start": (C.c_int, [_vp, _vp]),
+    "slam2d_timer_stop": (C.c_int, [_vp, _vp]),
+    "slam2d_timer_elapsed_ms": (C.c_int, [_vp, C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+class Slam2dError(RuntimeError):
+    pass
+
+
+def build_library(force=False, verbose=False):
+    """Compile csrc/slam2d.hip for gfx950 into libslam2d_hip.so (in-tree)."""
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(
+            os.path.getmtime(SRC_PATH), os.path.getmtime(os.path.join(INCLUDE_DIR, "slam2d.h"))):
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise Slam2dError("hipcc not found: cannot build libslam2d_hip.so")
+    cmd = [hipcc] + HIPCC_FLAGS + ["-I", INCLUDE_DIR, SRC_PATH, "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise Slam2dError("hipcc failed:\n" + res.stdout + res.stderr)
+    global _lib
+    _lib = None
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library with argtypes set.  Raises if it is not built: the
+    product path has no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Slam2dError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback for the HIP path)")
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    for name, st in STRUCTS.items():
+        n = L.slam2d_sizeof(name.encode())
+        if n != C.sizeof(st):
+            raise Slam2dError(f"ABI mismatch: sizeof({name}) is {n} in the library, {C.sizeof(st)} in the binding")
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = "HIP error" if rc > 0 else "argument error"
+        raise Slam2dError(f"{what}: {kind} {rc}")
+
+
+def describe_flags(bits):
+    return "; ".join(msg for bit, msg in FLAG_NAMES.items() if bits & bit) or "none"

@@ -1,0 +1,835 @@
+// slam2d.hip -- gfx950 (MI355X / CDNA4) kernels + C ABI for the 2-D lidar FastSLAM hot
+// path: search-field build, pose-cube sweep, arg-max / soft-max pose selection,
+// occupancy-grid update, weight normalisation.  See include/slam2d.h for the
+// contract and DESIGN.md for the layout and roofline of each kernel.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared
+//   -ffp-contract=off is REQUIRED: every cell index is a trunc/rint of an fp64
+//   expression that sits on a lattice point, and the blur reproduces SciPy's
+//   operation order; a fused multiply-add anywhere changes results.
+//
+// All `file:line` citations are relative to the reference repository root.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <math.h>
+#include <limits.h>
+
+#include "slam2d.h"
+
+#define WAVE 64
+
+// ------------------------------------------------------------------------------------
+// stage profiling (bench.py): optional HIP-event pairs around selected kernels
+// ------------------------------------------------------------------------------------
+namespace {
+
+struct StageProf {
+    hipEvent_t* start = nullptr;
+    hipEvent_t* stop = nullptr;
+    int capacity = 0;
+    int used = 0;
+};
+StageProf g_prof[SLAM2D_STAGE_COUNT];
+unsigned g_prof_mask = 0;
+
+struct StageScope {
+    int stage; hipStream_t s; int slot = -1;
+    StageScope(int st, hipStream_t stream) : stage(st), s(stream) {
+        if ((g_prof_mask >> st) & 1u) {
+            StageProf& p = g_prof[st];
+            if (p.used < p.capacity) { slot = p.used++; (void)hipEventRecord(p.start[slot], s); }
+        }
+    }
+    ~StageScope() { if (slot >= 0) (void)hipEventRecord(g_prof[stage].stop[slot], s); }
+};
+
+inline int launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long order_bits(double v) {
+    // monotone map double -> uint64 (so that atomicMin on the bits is a min on the values)
+    unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double unorder_bits(unsigned long long k) {
+    unsigned long long b = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+__device__ __forceinline__ int reflect_index(int i, int n) {
+    // SciPy 'reflect' extension: d c b a | a b c d | d c b a
+    int period = 2 * n;
+    int m = i % period;
+    if (m < 0) m += period;
+    return m < n ? m : period - 1 - m;
+}
+
+// ------------------------------------------------------------------------------------
+// K2a  frame geometry                      (Utils/ScanMatcher_OGBased.py:21-28)
+// ------------------------------------------------------------------------------------
+__global__ void k_frame_setup(Slam2dLidar lid, Slam2dLevel lv, const Slam2dMap* __restrict__ maps, int P,
+                              const double* __restrict__ centre, int cstride, uint32_t* flags) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const Slam2dMap m = maps[p];
+    const double ex = centre[(size_t)p * cstride], ey = centre[(size_t)p * cstride + 1];
+    Slam2dFrame fr;
+    fr.cx = ex; fr.cy = ey;
+    fr.xlo = ex - lv.reach; fr.xhi = ex + lv.reach;            // :22-23
+    fr.ylo = ey - lv.reach; fr.yhi = ey + lv.reach;
+    int fw = (int)((fr.xhi - fr.xlo) / lv.step) + 1;            // :24-25
+    int fh = (int)((fr.yhi - fr.ylo) / lv.step) + 1;
+    uint32_t f = 0;
+    if (fw > lv.fmax) { fw = lv.fmax; f |= SLAM2D_F_FIELD_INDEX; }
+    if (fh > lv.fmax) { fh = lv.fmax; f |= SLAM2D_F_FIELD_INDEX; }
+    // checkMapToExpand (Utils/OccupancyGrid.py:108-118): the caller grows the map first
+    if (fr.xlo < m.lim_x0 || fr.xhi > m.lim_x1 || fr.ylo < m.lim_y0 || fr.yhi > m.lim_y1)
+        f |= SLAM2D_F_WINDOW_OUTSIDE_MAP;
+    // convertRealXYToMapIdx (Utils/OccupancyGrid.py:102-106) + Python slice clipping (:29-33)
+    int mx0 = (int)rint((fr.xlo - m.lim_x0) / lid.unit), mx1 = (int)rint((fr.xhi - m.lim_x0) / lid.unit);
+    int my0 = (int)rint((fr.ylo - m.lim_y0) / lid.unit), my1 = (int)rint((fr.yhi - m.lim_y0) / lid.unit);
+    mx0 = max(0, min(mx0, m.cols)); mx1 = max(mx0, min(mx1, m.cols));
+    my0 = max(0, min(my0, m.rows)); my1 = max(my0, min(my1, m.rows));
+    if (mx1 - mx0 > lv.wmax) { mx1 = mx0 + lv.wmax; f |= SLAM2D_F_WINDOW_OUTSIDE_MAP; }
+    if (my1 - my0 > lv.wmax) { my1 = my0 + lv.wmax; f |= SLAM2D_F_WINDOW_OUTSIDE_MAP; }
+    fr.fh = fh; fr.fw = fw; fr.mx0 = mx0; fr.mx1 = mx1; fr.my0 = my0; fr.my1 = my1;
+    fr.field_min = lv.floor_value; fr.redo = 0; fr._pad = 0;
+    fr.min_bits = ~0ull;
+    lv.frames[p] = fr;
+    if (f) atomicOr(&flags[p], f);
+}
+
+// ------------------------------------------------------------------------------------
+// K2b  field index of every window column / row   (Utils/ScanMatcher_OGBased.py:32-36,173-176)
+// ------------------------------------------------------------------------------------
+__global__ void k_axis_index(Slam2dLevel lv, const Slam2dMap* __restrict__ maps, uint32_t* flags) {
+    const int p = blockIdx.y, axis = blockIdx.z;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const Slam2dFrame fr = lv.frames[p];
+    const Slam2dMap m = maps[p];
+    const int n = axis == 0 ? fr.mx1 - fr.mx0 : fr.my1 - fr.my0;
+    if (j >= n) return;
+    const double coord = axis == 0 ? m.X[fr.mx0 + j] : m.Y[fr.my0 + j];
+    const double lo = axis == 0 ? fr.xlo : fr.ylo;
+    const int dim = axis == 0 ? fr.fw : fr.fh;
+    int idx = (int)((coord - lo) / lv.step);       // astype(int): truncation toward zero
+    if (idx < 0) idx += dim;                       // Python negative-index wrap (:37)
+    if (idx < 0 || idx >= dim) { idx = -1; atomicOr(&flags[p], SLAM2D_F_FIELD_INDEX); }
+    (axis == 0 ? lv.axis_x : lv.axis_y)[(size_t)p * lv.wmax + j] = idx;
+}
+
+// ------------------------------------------------------------------------------------
+// K2c  occupied map cells -> occupied field cells  (Utils/ScanMatcher_OGBased.py:29-37)
+//      HBM-bound: streams the map window once (4 B / map cell), byte scatter into occ.
+// ------------------------------------------------------------------------------------
+#define SCATTER_ROWS 16
+__global__ __launch_bounds__(256) void k_occ_scatter(Slam2dLevel lv, const Slam2dMap* __restrict__ maps) {
+    const int p = blockIdx.z;
+    const Slam2dFrame fr = lv.frames[p];
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    if (j >= fr.mx1 - fr.mx0) return;
+    const Slam2dMap m = maps[p];
+    const int fx = lv.axis_x[(size_t)p * lv.wmax + j];
+    uint8_t* occ = lv.occ + (size_t)p * lv.fmax * lv.fpitch;
+    const int i0 = blockIdx.y * SCATTER_ROWS + threadIdx.y;
+    const int nrow = fr.my1 - fr.my0;
+#pragma unroll
+    for (int rr = 0; rr < SCATTER_ROWS / 4; ++rr) {
+        const int i = i0 + rr * 4;
+        if (i >= nrow) break;
+        const uint32_t c = m.cells[(size_t)(fr.my0 + i) * m.pitch + fr.mx0 + j];
+        if (2u * (c >> 16) > (c & 0xffffu)) {
+            const int fy = lv.axis_y[(size_t)p * lv.wmax + i];
+            if (fx >= 0 && fy >= 0) occ[(size_t)fy * lv.fpitch + fx] = 1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K2d  separable Gaussian blur + clamp           (Utils/ScanMatcher_OGBased.py:41-45)
+//      fp64, SciPy's symmetric correlate1d operation order, axis 0 then axis 1,
+//      'reflect' borders.  The clamp threshold is 0.5 * (field minimum); the minimum
+//      is known analytically (floor_value) whenever some cell has an all-free
+//      neighbourhood, which k_floor_check verifies from the measured minimum --
+//      mode 1 redoes the clamp with the measured minimum otherwise.
+// ------------------------------------------------------------------------------------
+#define BLUR_TILE 32
+#define BLUR_EXT (BLUR_TILE + 2 * SLAM2D_MAX_BLUR_RADIUS)
+__global__ __launch_bounds__(256) void k_blur_clamp(Slam2dLevel lv, int mode) {
+    const int p = blockIdx.z;
+    const Slam2dFrame fr = lv.frames[p];
+    if (mode == 1 && !fr.redo) return;
+    const int fh = fr.fh, fw = fr.fw;
+    const int ty0 = blockIdx.y * BLUR_TILE, tx0 = blockIdx.x * BLUR_TILE;
+    if (ty0 >= fh || tx0 >= fw) return;
+    const int r = lv.blur_radius;
+    const int ext = BLUR_TILE + 2 * r;
+    const int tid = threadIdx.x;
+
+    __shared__ double w_s[2 * SLAM2D_MAX_BLUR_RADIUS + 1];
+    __shared__ uint8_t occ_s[BLUR_EXT][BLUR_EXT + 4];
+    __shared__ double mid_s[BLUR_TILE][BLUR_EXT + 1];
+    __shared__ double red_s[4];
+
+    if (tid < 2 * r + 1) w_s[tid] = lv.blur_w[tid];
+    const uint8_t* occ = lv.occ + (size_t)p * lv.fmax * lv.fpitch;
+    for (int idx = tid; idx < ext * ext; idx += 256) {
+        const int ly = idx / ext, lx = idx - ly * ext;
+        const int gy = reflect_index(ty0 - r + ly, fh), gx = reflect_index(tx0 - r + lx, fw);
+        occ_s[ly][lx] = occ[(size_t)gy * lv.fpitch + gx];
+    }
+    __syncthreads();
+    const double L = lv.log_miss;
+    // axis-0 pass: out = a[c]*w[c]; for j=-r..-1: out += (a[c+j] + a[c-j]) * w[j]
+    for (int idx = tid; idx < BLUR_TILE * ext; idx += 256) {
+        const int y = idx / ext, lx = idx - y * ext;
+        double acc = (occ_s[y + r][lx] ? 0.0 : L) * w_s[r];
+        for (int j = -r; j < 0; ++j) {
+            const double a = occ_s[y + r + j][lx] ? 0.0 : L;
+            const double b = occ_s[y + r - j][lx] ? 0.0 : L;
+            acc = acc + (a + b) * w_s[r + j];
+        }
+        mid_s[y][lx] = acc;
+    }
+    __syncthreads();
+    const double thr = 0.5 * (mode == 1 ? fr.field_min : lv.floor_value);
+    float* field = lv.field + (size_t)p * lv.fmax * lv.fpitch;
+    double lmin = INFINITY;
+    for (int idx = tid; idx < BLUR_TILE * BLUR_TILE; idx += 256) {
+        const int y = idx / BLUR_TILE, x = idx - y * BLUR_TILE;
+        double acc = mid_s[y][x + r] * w_s[r];
+        for (int j = -r; j < 0; ++j) acc = acc + (mid_s[y][x + r + j] + mid_s[y][x + r - j]) * w_s[r + j];
+        const int gy = ty0 + y, gx = tx0 + x;
+        if (gy < fh && gx < fw) {
+            lmin = fmin(lmin, acc);
+            field[(size_t)gy * lv.fpitch + gx] = acc > thr ? 0.0f : (float)acc;   // :44
+        }
+    }
+    if (mode == 0) {
+        for (int o = 32; o > 0; o >>= 1) lmin = fmin(lmin, __shfl_down(lmin, o));
+        if ((tid & 63) == 0) red_s[tid >> 6] = lmin;
+        __syncthreads();
+        if (tid == 0) {
+            lmin = fmin(fmin(red_s[0], red_s[1]), fmin(red_s[2], red_s[3]));
+            atomicMin(&lv.frames[p].min_bits, order_bits(lmin));
+        }
+    }
+}
+
+__global__ void k_floor_check(Slam2dLevel lv, int P, uint32_t* flags) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const double measured = unorder_bits(lv.frames[p].min_bits);
+    lv.frames[p].field_min = measured;                            // probMin (:43)
+    if (measured != lv.floor_value) { lv.frames[p].redo = 1; atomicOr(&flags[p], SLAM2D_F_FLOOR_REDO); }
+}
+
+// ------------------------------------------------------------------------------------
+// K1a  beam endpoints -> unique field cells per theta   (Utils/ScanMatcher_OGBased.py:81-89,
+//      117-121,162-176).  One block per (theta, particle); bitonic sort + compaction in LDS.
+//      A cell is stored as the offset of the corner of its (2*ncell+1)^2 patch:
+//      (cy - ncell) * fpitch + (cx - ncell).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel lv, const double* __restrict__ est,
+                                                   int estride, const double* __restrict__ ranges, uint32_t* flags) {
+    __shared__ int keys[SLAM2D_MAX_BEAMS];
+    __shared__ int cnt_s[257];
+    const int it = blockIdx.x, p = blockIdx.y, tid = threadIdx.x;
+    const Slam2dFrame fr = lv.frames[p];
+    const double ex = est[(size_t)p * estride], ey = est[(size_t)p * estride + 1], eth = est[(size_t)p * estride + 2];
+    const int B = lid.beams;
+    int n = 256;
+    while (n < B) n <<= 1;
+    // np.linspace(theta - fov/2, theta + fov/2, num=B)  (:82-83)
+    const double a0 = eth - lid.fov / 2, a1 = eth + lid.fov / 2;
+    const double astep = (a1 - a0) / (double)(B - 1);
+    const double c = lv.theta_cos[it], s = lv.theta_sin[it];
+    const int nc = lv.ncell;
+    bool bad = false;
+    for (int b = tid; b < n; b += 256) {
+        int key = INT_MAX;
+        if (b < B) {
+            const double rg = ranges[b];
+            if (rg < lid.max_range) {                                               // :84
+                const double a = (b == B - 1) ? a1 : (double)b * astep + a0;
+                const double px = ex + cos(a) * rg, py = ey + sin(a) * rg;          // :87-88
+                const double dx = px - ex, dy = py - ey;
+                const double qx = ex + c * dx - s * dy;                             // :169
+                const double qy = ey + s * dx + c * dy;                             // :170
+                const int cx = (int)((qx - fr.xlo) / lv.step);                      // :174
+                const int cy = (int)((qy - fr.ylo) / lv.step);                      // :175
+                const int x0 = cx - nc, y0 = cy - nc;
+                if (x0 < 0 || y0 < 0 || cx + nc >= fr.fw || cy + nc >= fr.fh) bad = true;
+                else key = y0 * lv.fpitch + x0;
+            }
+        }
+        keys[b] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < n; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const bool up = (i & k) == 0;
+                    const int a = keys[i], b = keys[ixj];
+                    if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // np.unique(axis=0) (:120): keep the first of every run; contiguous chunk per thread
+    const int chunk = n / 256;
+    int mine = 0;
+    for (int q = 0; q < chunk; ++q) {
+        const int i = tid * chunk + q;
+        const int k = keys[i];
+        if (k != INT_MAX && (i == 0 || k != keys[i - 1])) ++mine;
+    }
+    cnt_s[tid + 1] = mine;
+    if (tid == 0) cnt_s[0] = 0;
+    __syncthreads();
+    if (tid == 0) for (int t = 1; t <= 256; ++t) cnt_s[t] += cnt_s[t - 1];
+    __syncthreads();
+    int pos = cnt_s[tid];
+    int* out = lv.cells + ((size_t)p * lv.ntheta + it) * lv.kmax;
+    for (int q = 0; q < chunk; ++q) {
+        const int i = tid * chunk + q;
+        const int k = keys[i];
+        if (k != INT_MAX && (i == 0 || k != keys[i - 1])) { if (pos < lv.kmax) out[pos] = k; ++pos; }
+    }
+    if (tid == 0) {
+        int K = cnt_s[256];
+        if (K > lv.kmax) { K = lv.kmax; bad = true; }
+        lv.kcount[p * lv.ntheta + it] = K;
+    }
+    if (bad) atomicOr(&flags[p], SLAM2D_F_ENDPOINT_OUTSIDE);
+}
+
+// ------------------------------------------------------------------------------------
+// K1b  motion priors rv / thetaWeight              (Utils/ScanMatcher_OGBased.py:97-110)
+//      prior[p][0] = rv, prior[p][1] = thetaWeight, each [ny][nx]
+// ------------------------------------------------------------------------------------
+__global__ void k_priors(Slam2dLevel lv, double est_dist, const double* __restrict__ psi_cs) {
+    const int p = blockIdx.y;
+    const int nx = 2 * lv.ncell + 1, np_ = nx * nx;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= np_) return;
+    double rv = 0.0, tw = 0.0;
+    if (!lv.fine) {
+        const int iy = q / nx, ix = q - iy * nx;
+        const int xv = ix - lv.ncell, yv = iy - lv.ncell;
+        const double mx = (double)xv * lv.step, my = (double)yv * lv.step;
+        const double dist = sqrt(mx * mx + my * my);
+        const double dev = dist - est_dist;
+        rv = lv.rv_coef * (dev * dev);                                              // :101
+        if (fabs(dev) > lv.max_move_dev) rv = -100.0;                               // :102-103
+        const double cpsi = psi_cs ? psi_cs[2 * p] : NAN;
+        if (!isnan(cpsi)) {                                                         // :104-108
+            double dv = sqrt((double)(xv * xv + yv * yv));
+            if (dv == 0.0) dv = 0.0001;
+            const double arg = ((double)xv * cpsi + (double)yv * psi_cs[2 * p + 1]) / dv;
+            const double th = acos(arg);            // NaN when |arg| > 1, as np.arccos
+            tw = lv.tw_coef * (th * th);
+        }
+    }
+    double* out = lv.prior + (size_t)p * 2 * np_;
+    out[q] = rv;
+    out[np_ + q] = tw;
+}
+
+// ------------------------------------------------------------------------------------
+// K1c  pose-cube sweep                              (Utils/ScanMatcher_OGBased.py:116-132)
+//      score[theta][dy][dx] = sum_k field[cy_k + dy][cx_k + dx] + rv + thetaWeight
+//
+//      One WAVE scores 64*R consecutive poses of one (particle, theta): lanes run along
+//      the flattened (dy, dx) plane, so every gather of a wave is a few contiguous row
+//      segments of the float32 field.  The unique-cell list is wave-uniform: it is
+//      read with scalar loads and the field is read through a buffer resource as
+//      (per-lane constant VGPR offset) + (scalar cell offset).  float32 field
+//      values are accumulated in float64 (sums of <= 2048 float32 values are then
+//      exact to ~1e-13, so argmax ties in the reference stay ties here).
+//      Blocks of one particle are pinned to one XCD (block b runs on XCD b % 8) so that
+//      particle's field stays in that XCD's 4 MiB L2 while its cube is swept.
+// ------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks, int bpp) {
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int p = (slot / bpp) * 8 + xcd;
+    if (p >= P) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int w = (slot % bpp) * 4 + wave;
+    if (w >= lv.ntheta * chunks) return;
+    const int it = w / chunks, ch = w - it * chunks;
+    const int nx = 2 * lv.ncell + 1, npose = nx * nx;
+    const float* __restrict__ F = lv.field + (size_t)p * lv.fmax * lv.fpitch;
+    const int* __restrict__ cl = lv.cells + ((size_t)p * lv.ntheta + it) * lv.kmax;
+    const int K = lv.kcount[p * lv.ntheta + it];
+    const int q0 = ch * (WAVE * R) + lane;
+    // Buffer addressing (SRSRC): address = field base + per-lane VGPR byte offset (constant
+    // over k) + wave-uniform SGPR byte offset (the cell) -- no vector address arithmetic in
+    // the loop, and out-of-range offsets read 0 instead of faulting.
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)F, (short)0, (int)((size_t)lv.fmax * lv.fpitch * sizeof(float)), 0x00020000);
+    int off[R];
+    double acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int q = q0 + r * WAVE;
+        const int qq = q < npose ? q : 0;
+        const int iy = qq / nx;
+        off[r] = (iy * lv.fpitch + (qq - iy * nx)) * 4;
+        acc[r] = 0.0;
+    }
+#pragma unroll 4
+    for (int k = 0; k < K; ++k) {
+        const int cell = cl[k] * 4;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            acc[r] += (double)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off[r], cell, 0));
+    }
+    const double* __restrict__ pr = lv.prior + (size_t)p * 2 * npose;
+    double* __restrict__ out = lv.cube + ((size_t)p * lv.ntheta + it) * npose;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int q = q0 + r * WAVE;
+        if (q < npose) out[q] = (acc[r] + pr[q]) + pr[npose + q];                  // :131
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K1d  arg-max / soft-max draw / confidence / matched pose   (Utils/ScanMatcher_OGBased.py:133-143)
+//      one block per particle
+// ------------------------------------------------------------------------------------
+struct Best { double v; int i; int nan; };
+__device__ __forceinline__ bool better(const Best& a, const Best& b) {
+    // np.argmax semantics: first NaN wins; otherwise the largest value, lowest index on ties
+    if (a.nan != b.nan) return a.nan > b.nan;
+    if (a.nan) return a.i < b.i;
+    return a.v > b.v || (a.v == b.v && a.i < b.i);
+}
+#define RED_T 512
+__global__ __launch_bounds__(RED_T) void k_select(Slam2dLevel lv, const double* __restrict__ est, int estride,
+                                                  const double* __restrict__ uniform, Slam2dMatch* out) {
+    __shared__ double sv[RED_T];
+    __shared__ int si[RED_T];
+    __shared__ int sn[RED_T];
+    __shared__ int pick_s;
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const int nx = 2 * lv.ncell + 1, npose = nx * nx, N = lv.ntheta * npose;
+    const double* __restrict__ c = lv.cube + (size_t)p * N;
+    Best me{-INFINITY, INT_MAX, 0};
+    for (int i = tid; i < N; i += RED_T) {
+        const double v = c[i];
+        Best cand{v, i, isnan(v) ? 1 : 0};
+        if (better(cand, me)) me = cand;
+    }
+    sv[tid] = me.v; si[tid] = me.i; sn[tid] = me.nan;
+    __syncthreads();
+    for (int o = RED_T / 2; o > 0; o >>= 1) {
+        if (tid < o) {
+            Best a{sv[tid], si[tid], sn[tid]}, b{sv[tid + o], si[tid + o], sn[tid + o]};
+            if (better(b, a)) { sv[tid] = b.v; si[tid] = b.i; sn[tid] = b.nan; }
+        }
+        __syncthreads();
+    }
+    const double m = sv[0];
+    const int amax = si[0];
+    __syncthreads();
+    // sum exp(s - m) over contiguous chunks (fixed order => deterministic)
+    const int chunk = (N + RED_T - 1) / RED_T;
+    const int i0 = tid * chunk, i1 = min(N, i0 + chunk);
+    double part = 0.0;
+    for (int i = i0; i < i1; ++i) part += exp(c[i] - m);
+    sv[tid] = part;
+    __syncthreads();
+    if (tid == 0) {
+        double total = 0.0;
+        for (int t = 0; t < RED_T; ++t) total += sv[t];
+        int pick = amax;
+        if (uniform != nullptr && !isnan(total)) {
+            // np.random.choice(n, 1, p): cdf.searchsorted(u, 'right') on the normalised cdf (:137-138)
+            const double target = uniform[p] * total;
+            double run = 0.0;
+            int t = 0;
+            while (t < RED_T - 1 && run + sv[t] <= target) { run += sv[t]; ++t; }
+            pick = -1;
+            for (; t < RED_T && pick < 0; ++t) {
+                const int j0 = t * chunk, j1 = min(N, j0 + chunk);
+                for (int i = j0; i < j1; ++i) {
+                    run += exp(c[i] - m);
+                    if (run > target) { pick = i; break; }
+                }
+            }
+            if (pick < 0) pick = N - 1;
+        }
+        Slam2dMatch r;
+        const int it = pick / npose, rem = pick - it * npose;
+        const int iy = rem / nx, ix = rem - iy * nx;
+        const double ex = est[(size_t)p * estride], ey = est[(size_t)p * estride + 1], eth = est[(size_t)p * estride + 2];
+        r.x = ex + (double)(ix - lv.ncell) * lv.step;                               // :142-143
+        r.y = ey + (double)(iy - lv.ncell) * lv.step;
+        r.theta = eth + lv.thetas[it];
+        r.confidence = exp(m) * total;                                              // :141
+        r.log_confidence = m + log(total);
+        r.best_score = m;
+        r.pick = pick;
+        r.argmax = amax;
+        out[p] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K3  occupancy-grid update                         (Utils/OccupancyGrid.py:127-152)
+// ------------------------------------------------------------------------------------
+__global__ void k_update_axis(Slam2dLidar lid, const Slam2dMap* __restrict__ maps, const double* __restrict__ pose,
+                              int pstride, int32_t* axis) {
+    const int p = blockIdx.y, a = blockIdx.z;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= lid.lut_w) return;
+    const Slam2dMap m = maps[p];
+    const double base = pose[(size_t)p * pstride + a];
+    const double lim0 = a == 0 ? m.lim_x0 : m.lim_y0;
+    // convertRealXYToMapIdx(x + xAtSpokeDir, ...)  (:104-105,144-145)
+    axis[((size_t)p * 2 + a) * lid.lut_w + j] = (int)rint(((base + lid.lut_xs[j]) - lim0) / lid.unit);
+}
+
+#define UPD_ROWS 16
+__global__ __launch_bounds__(256) void k_grid_update(Slam2dLidar lid, const Slam2dMap* __restrict__ maps, int P,
+                                                     const double* __restrict__ pose, int pstride,
+                                                     const double* __restrict__ ranges,
+                                                     const int32_t* __restrict__ axis,
+                                                     const int32_t* __restrict__ beam_shift, uint32_t* flags,
+                                                     int tiles_x) {
+    __shared__ double rng_s[SLAM2D_MAX_BEAMS];
+    const int b = blockIdx.x;
+    const int p = b % P, t = b / P;
+    const int tx = t % tiles_x, ty = t / tiles_x;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    for (int i = tid; i < lid.beams; i += 256) rng_s[i] = ranges[i];
+    __syncthreads();
+    const int W = lid.lut_w, S = lid.num_spokes;
+    const int j = tx * 64 + threadIdx.x;
+    if (j >= W) return;
+    // spokesOffsetIdxByTheta = int(rint(theta / (2*pi) * numSpokes))  (:131)
+    const double th = pose[(size_t)p * pstride + 2];
+    const int offset = (int)rint(th / (2 * 3.141592653589793) * (double)S);
+    const Slam2dMap m = maps[p];
+    const int mx_base = axis[((size_t)p * 2 + 0) * W + j];
+    uint32_t f = 0;
+#pragma unroll
+    for (int rr = 0; rr < UPD_ROWS / 4; ++rr) {
+        const int i = ty * UPD_ROWS + rr * 4 + threadIdx.y;
+        if (i >= W) break;
+        const int bin = lid.lut_bin[(size_t)i * W + j];
+        int beam = (bin - lid.spoke_start - offset) % S;                             // inverse of :134
+        if (beam < 0) beam += S;
+        if (beam >= lid.beams) continue;
+        const double rg = rng_s[beam];
+        const double r = lid.lut_r[(size_t)i * W + j];
+        const double lo = rg - lid.wall_half, hi = rg + lid.wall_half;
+        uint32_t inc = 0;
+        if (rg < lid.max_range && r < lo) inc = 1u;                                  // :138-139,149
+        else if (r > lo && r < hi) inc = 0x00020002u;                                // :142-143,151-152
+        if (!inc) continue;
+        int mx = mx_base, my = axis[((size_t)p * 2 + 1) * W + i];
+        if (beam_shift) {   // stale indices after a low-side growth inside this beam (:144-147)
+            mx -= beam_shift[((size_t)p * lid.beams + beam) * 2 + 0];
+            my -= beam_shift[((size_t)p * lid.beams + beam) * 2 + 1];
+            if (mx < 0) mx += m.cols;
+            if (my < 0) my += m.rows;
+        }
+        if (mx < 0 || mx >= m.cols || my < 0 || my >= m.rows) { f |= SLAM2D_F_UPDATE_OUTSIDE_MAP; continue; }
+        uint32_t* cell = m.cells + (size_t)my * m.pitch + mx;
+        const uint32_t c = *cell;
+        if ((c & 0xffffu) + (inc & 0xffffu) > 0xffffu) { f |= SLAM2D_F_COUNT_OVERFLOW; continue; }
+        *cell = c + inc;
+    }
+    if (f) atomicOr(&flags[p], f);
+}
+
+// ------------------------------------------------------------------------------------
+// K4  weights                                        (Algorithm/FastSlam.py:30-48,135)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_weights(double* logw, const double* __restrict__ logconf, int N, double* w,
+                                                 double* stats) {
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    double mx = -INFINITY;
+    for (int i = tid; i < N; i += 256) {
+        double v = logw[i] + (logconf ? logconf[i] : 0.0);
+        logw[i] = v;
+        mx = fmax(mx, v);
+    }
+    red[tid] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] = fmax(red[tid], red[tid + o]); __syncthreads(); }
+    mx = red[0];
+    __syncthreads();
+    double s = 0.0;
+    for (int i = tid; i < N; i += 256) s += exp(logw[i] - mx);
+    red[tid] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    const double total = red[0];
+    __syncthreads();
+    const double lse = mx + log(total);
+    double var = 0.0;
+    for (int i = tid; i < N; i += 256) {
+        const double wi = exp(logw[i] - mx) / total;                                 // :47-48
+        w[i] = wi;
+        logw[i] = logw[i] - lse;
+        const double d = wi - 1.0 / (double)N;                                       // :34
+        var += d * d;
+    }
+    red[tid] = var;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    if (tid == 0) { stats[0] = red[0]; stats[1] = lse; }
+}
+
+// ------------------------------------------------------------------------------------
+// resample state movement / fill
+// ------------------------------------------------------------------------------------
+__global__ void k_gather_maps(const Slam2dMap* __restrict__ src, const Slam2dMap* __restrict__ dst,
+                              const int32_t* __restrict__ index) {
+    const int p = blockIdx.y;
+    const Slam2dMap s = src[index[p]], d = dst[p];
+    const size_t n = (size_t)s.rows * s.pitch;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        d.cells[i] = s.cells[i];
+}
+
+__global__ void k_fill(uint32_t* cells, long long n, uint32_t value) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        cells[i] = value;
+}
+
+// ------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------
+template <int R>
+static void launch_sweep(const Slam2dLevel& lv, int P, int chunks, hipStream_t s) {
+    const int waves = lv.ntheta * chunks;
+    const int bpp = cdiv(waves, 4);
+    const int groups = cdiv(P, 8);
+    k_sweep<R><<<groups * 8 * bpp, 256, 0, s>>>(lv, P, chunks, bpp);
+}
+
+extern "C" {
+
+int slam2d_abi_version(void) { return SLAM2D_ABI_VERSION; }
+
+int slam2d_sizeof(const char* name) {
+    if (!name) return -1;
+    if (!strcmp(name, "Slam2dMap")) return (int)sizeof(Slam2dMap);
+    if (!strcmp(name, "Slam2dLidar")) return (int)sizeof(Slam2dLidar);
+    if (!strcmp(name, "Slam2dFrame")) return (int)sizeof(Slam2dFrame);
+    if (!strcmp(name, "Slam2dLevel")) return (int)sizeof(Slam2dLevel);
+    if (!strcmp(name, "Slam2dMatch")) return (int)sizeof(Slam2dMatch);
+    return -1;
+}
+
+int slam2d_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+static int check_level(const Slam2dLidar* lidar, const Slam2dLevel* lv, int P) {
+    if (!lidar || !lv || P <= 0) return SLAM2D_E_BADARG;
+    if (lv->blur_radius < 0 || lv->blur_radius > SLAM2D_MAX_BLUR_RADIUS) return SLAM2D_E_TOOLARGE;
+    if (lidar->beams < 2 || lidar->beams > SLAM2D_MAX_BEAMS) return SLAM2D_E_TOOLARGE;
+    if (lv->fmax <= 0 || lv->fpitch < lv->fmax || lv->wmax <= 0 || lv->ncell < 0 || lv->ntheta <= 0) return SLAM2D_E_BADARG;
+    if ((long long)lv->fmax * lv->fpitch >= (1ll << 31)) return SLAM2D_E_TOOLARGE;
+    return 0;
+}
+
+int slam2d_field_build(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2dMap* d_maps, int32_t P,
+                       const double* d_centre, int32_t centre_stride, uint32_t* d_flags, void* stream) {
+    int rc = check_level(lidar, level, P);
+    if (rc) return rc;
+    if (!d_maps || !d_centre || !d_flags || centre_stride < 2) return SLAM2D_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    const Slam2dLevel& lv = *level;
+    k_frame_setup<<<cdiv(P, 64), 64, 0, s>>>(*lidar, lv, d_maps, P, d_centre, centre_stride, d_flags);
+    k_axis_index<<<dim3(cdiv(lv.wmax, 256), P, 2), 256, 0, s>>>(lv, d_maps, d_flags);
+    hipError_t e = hipMemsetAsync(lv.occ, 0, (size_t)P * lv.fmax * lv.fpitch, s);
+    if (e != hipSuccess) return (int)e;
+    {
+        StageScope prof(SLAM2D_STAGE_SCATTER, s);
+        k_occ_scatter<<<dim3(cdiv(lv.wmax, 64), cdiv(lv.wmax, SCATTER_ROWS), P), dim3(64, 4), 0, s>>>(lv, d_maps);
+    }
+    const dim3 bgrid(cdiv(lv.fmax, BLUR_TILE), cdiv(lv.fmax, BLUR_TILE), P);
+    {
+        StageScope prof(SLAM2D_STAGE_BLUR, s);
+        k_blur_clamp<<<bgrid, 256, 0, s>>>(lv, 0);
+    }
+    k_floor_check<<<cdiv(P, 64), 64, 0, s>>>(lv, P, d_flags);
+    k_blur_clamp<<<bgrid, 256, 0, s>>>(lv, 1);
+    return launch_status();
+}
+
+int slam2d_sweep(const Slam2dLidar* lidar, const Slam2dLevel* level, int32_t P, const double* d_est,
+                 int32_t est_stride, const double* d_ranges, double est_moving_dist, const double* d_psi_cs,
+                 const double* d_uniform, Slam2dMatch* d_out, uint32_t* d_flags, void* stream) {
+    int rc = check_level(lidar, level, P);
+    if (rc) return rc;
+    if (!d_est || !d_ranges || !d_out || !d_flags || est_stride < 3) return SLAM2D_E_BADARG;
+    const Slam2dLevel& lv = *level;
+    if (lv.kmax < lidar->beams) return SLAM2D_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int nx = 2 * lv.ncell + 1, npose = nx * nx;
+    {
+        StageScope prof(SLAM2D_STAGE_ENDPOINTS, s);
+        k_endpoints<<<dim3(lv.ntheta, P), 256, 0, s>>>(*lidar, lv, d_est, est_stride, d_ranges, d_flags);
+    }
+    k_priors<<<dim3(cdiv(npose, 256), P), 256, 0, s>>>(lv, est_moving_dist, lv.fine ? nullptr : d_psi_cs);
+    // poses per lane: the largest R <= 8 that wastes the fewest lanes
+    const int need = cdiv(npose, WAVE);
+    int bestR = 1, bestWaste = INT_MAX;
+    for (int R = 1; R <= 8; ++R) {
+        const int waste = cdiv(need, R) * R - need;
+        if (waste <= bestWaste) { bestWaste = waste; bestR = R; }
+    }
+    const int chunks = cdiv(need, bestR);
+    {
+        StageScope prof(SLAM2D_STAGE_SWEEP, s);
+        switch (bestR) {
+            case 1: launch_sweep<1>(lv, P, chunks, s); break;
+            case 2: launch_sweep<2>(lv, P, chunks, s); break;
+            case 3: launch_sweep<3>(lv, P, chunks, s); break;
+            case 4: launch_sweep<4>(lv, P, chunks, s); break;
+            case 5: launch_sweep<5>(lv, P, chunks, s); break;
+            case 6: launch_sweep<6>(lv, P, chunks, s); break;
+            case 7: launch_sweep<7>(lv, P, chunks, s); break;
+            default: launch_sweep<8>(lv, P, chunks, s); break;
+        }
+    }
+    {
+        StageScope prof(SLAM2D_STAGE_SELECT, s);
+        k_select<<<P, RED_T, 0, s>>>(lv, d_est, est_stride, d_uniform, d_out);
+    }
+    return launch_status();
+}
+
+int slam2d_grid_update(const Slam2dLidar* lidar, const Slam2dMap* d_maps, int32_t P, const double* d_pose,
+                       int32_t pose_stride, const double* d_ranges, int32_t* d_axis_scratch,
+                       const int32_t* d_beam_shift, uint32_t* d_flags, void* stream) {
+    if (!lidar || !d_maps || !d_pose || !d_ranges || !d_axis_scratch || !d_flags || P <= 0 || pose_stride < 3)
+        return SLAM2D_E_BADARG;
+    if (lidar->beams < 1 || lidar->beams > SLAM2D_MAX_BEAMS) return SLAM2D_E_TOOLARGE;
+    hipStream_t s = (hipStream_t)stream;
+    const int W = lidar->lut_w;
+    k_update_axis<<<dim3(cdiv(W, 256), P, 2), 256, 0, s>>>(*lidar, d_maps, d_pose, pose_stride, d_axis_scratch);
+    const int tiles_x = cdiv(W, 64), tiles_y = cdiv(W, UPD_ROWS);
+    {
+        StageScope prof(SLAM2D_STAGE_UPDATE, s);
+        k_grid_update<<<(unsigned)((long long)P * tiles_x * tiles_y), dim3(64, 4), 0, s>>>(
+            *lidar, d_maps, P, d_pose, pose_stride, d_ranges, d_axis_scratch, d_beam_shift, d_flags, tiles_x);
+    }
+    return launch_status();
+}
+
+int slam2d_weights_normalize(double* d_logw, const double* d_logconf, int32_t N, double* d_w, double* d_stats,
+                             void* stream) {
+    if (!d_logw || !d_w || !d_stats || N <= 0) return SLAM2D_E_BADARG;
+    k_weights<<<1, 256, 0, (hipStream_t)stream>>>(d_logw, d_logconf, N, d_w, d_stats);
+    return launch_status();
+}
+
+int slam2d_gather_maps(const Slam2dMap* d_src, const Slam2dMap* d_dst, const int32_t* d_index, int32_t P,
+                       int64_t cells_per_map, void* stream) {
+    if (!d_src || !d_dst || !d_index || P <= 0 || cells_per_map <= 0) return SLAM2D_E_BADARG;
+    const int gx = (int)((cells_per_map + 256 * 8 - 1) / (256 * 8));
+    k_gather_maps<<<dim3(gx < 1 ? 1 : gx, P), 256, 0, (hipStream_t)stream>>>(d_src, d_dst, d_index);
+    return launch_status();
+}
+
+int slam2d_map_fill(uint32_t* d_cells, int64_t n, uint32_t value, void* stream) {
+    if (!d_cells || n <= 0) return SLAM2D_E_BADARG;
+    long long blocks = (n + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 65535) blocks = 65535;
+    k_fill<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(d_cells, (long long)n, value);
+    return launch_status();
+}
+
+// ---- stage profiling ----
+int slam2d_prof_enable(uint32_t stage_mask, int32_t capacity) {
+    if (capacity <= 0) return SLAM2D_E_BADARG;
+    for (int st = 0; st < SLAM2D_STAGE_COUNT; ++st) {
+        StageProf& p = g_prof[st];
+        if (!((stage_mask >> st) & 1u)) continue;
+        if (p.capacity < capacity) {
+            for (int i = 0; i < p.capacity; ++i) { (void)hipEventDestroy(p.start[i]); (void)hipEventDestroy(p.stop[i]); }
+            delete[] p.start; delete[] p.stop;
+            p.start = new hipEvent_t[capacity]; p.stop = new hipEvent_t[capacity];
+            for (int i = 0; i < capacity; ++i) {
+                hipError_t e = hipEventCreate(&p.start[i]);
+                if (e == hipSuccess) e = hipEventCreate(&p.stop[i]);
+                if (e != hipSuccess) { p.capacity = 0; return (int)e; }
+            }
+            p.capacity = capacity;
+        }
+        p.used = 0;
+    }
+    g_prof_mask = stage_mask;
+    return 0;
+}
+
+int slam2d_prof_collect(int32_t stage, double* total_ms, int32_t* launches) {
+    if (stage < 0 || stage >= SLAM2D_STAGE_COUNT || !total_ms || !launches) return SLAM2D_E_BADARG;
+    StageProf& p = g_prof[stage];
+    double tot = 0.0;
+    for (int i = 0; i < p.used; ++i) {
+        hipError_t e = hipEventSynchronize(p.stop[i]);
+        if (e != hipSuccess) return (int)e;
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, p.start[i], p.stop[i]);
+        if (e != hipSuccess) return (int)e;
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = p.used;
+    p.used = 0;
+    return 0;
+}
+
+void slam2d_prof_disable(void) { g_prof_mask = 0; }
+
+// ---- plain event timer ----
+struct Timer { hipEvent_t a, b; };
+void* slam2d_timer_create(void) {
+    Timer* t = new Timer;
+    if (hipEventCreate(&t->a) != hipSuccess || hipEventCreate(&t->b) != hipSuccess) { delete t; return nullptr; }
+    return t;
+}
+void slam2d_timer_destroy(void* timer) {
+    if (!timer) return;
+    Timer* t = (Timer*)timer;
+    (void)hipEventDestroy(t->a); (void)hipEventDestroy(t->b);
+    delete t;
+}
+int slam2d_timer_start(void* timer, void* stream) { return timer ? (int)hipEventRecord(((Timer*)timer)->a, (hipStream_t)stream) : SLAM2D_E_BADARG; }
+int slam2d_timer_stop(void* timer, void* stream) { return timer ? (int)hipEventRecord(((Timer*)timer)->b, (hipStream_t)stream) : SLAM2D_E_BADARG; }
+int slam2d_timer_elapsed_ms(void* timer, float* ms) {
+    if (!timer || !ms) return SLAM2D_E_BADARG;
+    Timer* t = (Timer*)timer;
+    hipError_t e = hipEventSynchronize(t->b);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipEventElapsedTime(ms, t->a, t->b);
+}
+
+}  // extern "C"

@@ -1,0 +1,431 @@
+"""Host side of the HIP path: device-resident particle maps, search-level plans and
+the calls into libslam2d_hip.so.
+
+Everything numeric that decides a cell index is either done on the device in fp64
+with the reference's operation order, or prepared here once with NumPy scalars
+(Gaussian taps, theta tables, the spoke LUT) so it is bit-identical to what the
+reference's NumPy computes.  PyTorch is used only as the device allocator, for
+host<->device copies and for the stream handle.
+
+``file:line`` citations are relative to the reference repository root.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Slam2dFrame, Slam2dLevel, Slam2dLidar, Slam2dMap, Slam2dMatch, check
+
+MATCH_DOUBLES = C.sizeof(Slam2dMatch) // 8      # stride of a Slam2dMatch array viewed as double*
+_MATCH_DTYPE = np.dtype([("x", "f8"), ("y", "f8"), ("theta", "f8"), ("confidence", "f8"),
+                         ("log_confidence", "f8"), ("best_score", "f8"), ("pick", "i4"), ("argmax", "i4")])
+_FRAME_DTYPE = np.dtype([("xlo", "f8"), ("ylo", "f8"), ("xhi", "f8"), ("yhi", "f8"), ("cx", "f8"), ("cy", "f8"),
+                         ("field_min", "f8"), ("fh", "i4"), ("fw", "i4"), ("mx0", "i4"), ("mx1", "i4"),
+                         ("my0", "i4"), ("my1", "i4"), ("redo", "i4"), ("_pad", "i4"), ("min_bits", "u8")])
+assert _MATCH_DTYPE.itemsize == C.sizeof(Slam2dMatch) and _FRAME_DTYPE.itemsize == C.sizeof(Slam2dFrame)
+
+
+def require_gpu(device):
+    """The HIP path needs the library and a GPU; there is no CPU fallback."""
+    _lib.lib()
+    if not torch.cuda.is_available():
+        raise _lib.Slam2dError("no HIP device visible: the scan-matching path runs on an MI355X only "
+                               "(there is no CPU fallback)")
+    return torch.device(device)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _dev(a, device, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(device)
+
+
+# ----------------------------------------------------------------------------
+# Gaussian taps / analytic field floor
+# ----------------------------------------------------------------------------
+def gaussian_taps(sigma):
+    """Normalised taps of SciPy's gaussian_filter (truncate 4.0) as the reference
+    calls it (Utils/ScanMatcher_OGBased.py:42)."""
+    sd = float(sigma)
+    radius = int(4.0 * sd + 0.5)
+    x = np.arange(-radius, radius + 1)
+    w = np.exp(-0.5 / (sd * sd) * x ** 2)
+    return w / w.sum(), radius
+
+
+def blurred_free_value(log_miss, taps, radius):
+    """Value the separable blur gives a cell whose whole neighbourhood is free, in the
+    device kernel's (= SciPy's) operation order.  It is the field minimum whenever
+    such a cell exists; k_floor_check verifies that on the device."""
+    L = np.float64(log_miss)
+
+    def one_pass(v):
+        acc = v * taps[radius]
+        for j in range(-radius, 0):
+            acc = acc + (v + v) * taps[radius + j]
+        return acc
+    return float(one_pass(one_pass(L)))
+
+
+# ----------------------------------------------------------------------------
+# Lidar model + polar spoke LUT (Utils/OccupancyGrid.py:22-57)
+# ----------------------------------------------------------------------------
+class LidarModel:
+    """Lidar parameters and the cell-major spoke lookup table shared by all
+    particles of one configuration."""
+
+    _cache = {}
+
+    @classmethod
+    def get(cls, unit, max_range, fov, beams, wall_thickness):
+        key = (float(unit), float(max_range), float(fov), int(beams), float(wall_thickness))
+        if key not in cls._cache:
+            cls._cache[key] = cls(*key)
+        return cls._cache[key]
+
+    def __init__(self, unit, max_range, fov, beams, wall_thickness):
+        if not 2 <= beams <= _lib.MAX_BEAMS:
+            raise ValueError(f"numSamplesPerRev must be in [2, {_lib.MAX_BEAMS}]")
+        self.unit, self.max_range, self.fov, self.beams = unit, max_range, fov, int(beams)
+        self.wall_thickness = wall_thickness
+        self.angular_step = fov / beams                                           # :22
+        self.num_spokes = int(np.rint(2 * np.pi / self.angular_step))             # :23
+        self.spoke_start = int(((self.num_spokes / 2 - beams) / 2) % self.num_spokes)   # :30
+        half = int(max_range / unit)                                              # :34
+        self.half, self.width = half, 2 * half + 1
+        self.xs = np.linspace(-max_range, max_range, self.width)                  # :36
+        self.bin, self.r = self._build()
+        self._dev = {}
+
+    def _build(self):
+        """spokesGrid (:32-45), cell-major: spoke bin and radius of each window cell."""
+        S, h, W = self.num_spokes, self.half, self.width
+        x = self.xs[None, :]
+        y = self.xs[:, None]
+        bins = np.zeros((W, W), dtype=np.int64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ang = np.arctan(y / x[:, h + 1:])
+            bins[:, h + 1:] = np.rint((np.pi / 2 + ang) / np.pi / 2 * S - 0.5).astype(int)
+        bins[:, :h] = bins[::-1, ::-1][:, :h] + int(S / 2)        # point mirror, half a turn on
+        bins[h + 1:, h] = int(S / 2)                              # upper half of the centre column
+        r = np.sqrt(x ** 2 + y ** 2)
+        return bins.astype(np.uint16), np.ascontiguousarray(r)
+
+    def on(self, device):
+        """Device copies + the C struct (kept alive with the tensors)."""
+        key = str(device)
+        if key not in self._dev:
+            t = dict(bin=_dev(self.bin.view(np.int16), device), r=_dev(self.r, device), xs=_dev(self.xs, device))
+            s = Slam2dLidar(unit=self.unit, max_range=self.max_range, fov=self.fov,
+                            wall_half=self.wall_thickness / 2, beams=self.beams, num_spokes=self.num_spokes,
+                            spoke_start=self.spoke_start, lut_w=self.width,
+                            lut_bin=t["bin"].data_ptr(), lut_r=t["r"].data_ptr(), lut_xs=t["xs"].data_ptr())
+            self._dev[key] = (s, t)
+        return self._dev[key][0]
+
+
+# ----------------------------------------------------------------------------
+# One particle's map (Utils/OccupancyGrid.py:7-20, 59-125)
+# ----------------------------------------------------------------------------
+class MapState:
+    """Device-resident count map of one particle + host copies of its coordinate
+    vectors and limits.  Cells are uint32 (visited << 16 | total), stored in an
+    int32 tensor."""
+
+    PITCH_ALIGN = 16
+
+    def __init__(self, X, Y, device, cells=None):
+        self.device = device
+        self.X = np.ascontiguousarray(X, dtype=np.float64)
+        self.Y = np.ascontiguousarray(Y, dtype=np.float64)
+        self.rows, self.cols = len(self.Y), len(self.X)
+        self.pitch = -(-self.cols // self.PITCH_ALIGN) * self.PITCH_ALIGN
+        if cells is None:
+            cells = torch.full((self.rows, self.pitch), _lib.INIT_CELL, dtype=torch.int32, device=device)
+        self.cells = cells
+        self._sync_coords()
+        self.growth_log = []
+
+    @classmethod
+    def create(cls, mapXLength, mapYLength, initXY, unit, device):
+        """Initial extent exactly as the reference's constructor (:8-14), including its
+        use of xNum for both axes; count arrays are (xNum+1, yNum+1) there, which is
+        only consistent for square maps -- rectangular maps are rejected here."""
+        xNum, yNum = int(mapXLength / unit), int(mapYLength / unit)
+        if xNum != yNum:
+            raise ValueError("the reference's OccupancyGrid is only self-consistent for square maps")
+        X = np.linspace(-xNum * unit / 2, xNum * unit / 2, num=xNum + 1) + initXY['x']
+        Y = np.linspace(-xNum * unit / 2, xNum * unit / 2, num=yNum + 1) + initXY['y']
+        return cls(X, Y, device)
+
+    def _sync_coords(self):
+        self.lim_x = [self.X[0], self.X[-1]]           # mapXLim (:19, :86-87)
+        self.lim_y = [self.Y[0], self.Y[-1]]           # mapYLim (:20, :88-89)
+        self.dX = _dev(self.X, self.device)
+        self.dY = _dev(self.Y, self.device)
+
+    def desc(self):
+        return Slam2dMap(cells=self.cells.data_ptr(), X=self.dX.data_ptr(), Y=self.dY.data_ptr(),
+                         rows=self.rows, cols=self.cols, pitch=self.pitch, _pad=0,
+                         lim_x0=self.lim_x[0], lim_x1=self.lim_x[1], lim_y0=self.lim_y[0], lim_y1=self.lim_y[1])
+
+    # -- growth: expandOccupancyGridHelper (:59-89) --
+    def _side_to_grow(self, x, y):                                            # :108-118
+        x, y = np.asarray(x), np.asarray(y)
+        if np.any(x < self.lim_x[0]):
+            return 1
+        if np.any(x > self.lim_x[1]):
+            return 2
+        if np.any(y < self.lim_y[0]):
+            return 3
+        if np.any(y > self.lim_y[1]):
+            return 4
+        return -1
+
+    def _grow(self, side, unit):
+        """One 20 % growth step on one side.  Returns (d_col, d_row): how far existing
+        content moved (non-zero only for low-side growth)."""
+        rows, cols = self.rows, self.cols
+        if side in (1, 2):
+            n = int(cols / 5)                                                 # :72
+            if side == 1:      # low side: exact spacing (:75-76)
+                new = np.linspace(self.lim_x[0] - n * unit, self.lim_x[0], num=n, endpoint=False)
+                X = np.concatenate((new, self.X))
+                shift = (n, 0)
+            else:              # high side: spacing unit*(n-1)/n, as the reference (:79-80)
+                new = np.linspace(self.lim_x[1] + unit, self.lim_x[1] + n * unit, num=n, endpoint=False)
+                X = np.concatenate((self.X, new))
+                shift = (0, 0)
+            Y = self.Y
+        else:
+            n = int(rows / 5)                                                 # :62
+            if side == 3:
+                new = np.linspace(self.lim_y[0] - n * unit, self.lim_y[0], num=n, endpoint=False)
+                Y = np.concatenate((new, self.Y))
+                shift = (0, n)
+            else:
+                new = np.linspace(self.lim_y[1] + unit, self.lim_y[1] + n * unit, num=n, endpoint=False)
+                Y = np.concatenate((self.Y, new))
+                shift = (0, 0)
+            X = self.X
+        nrows, ncols = len(Y), len(X)
+        pitch = -(-ncols // self.PITCH_ALIGN) * self.PITCH_ALIGN
+        cells = torch.full((nrows, pitch), _lib.INIT_CELL, dtype=torch.int32, device=self.device)
+        cells[shift[1]:shift[1] + rows, shift[0]:shift[0] + cols] = self.cells[:, :cols]
+        self.cells, self.X, self.Y = cells, X, Y
+        self.rows, self.cols, self.pitch = nrows, ncols, pitch
+        self._sync_coords()
+        self.growth_log.append((side, n))
+        return shift
+
+    def ensure_contains(self, x, y, unit):
+        """checkAndExapndOG (:120-125).  Returns the total (d_col, d_row) content shift."""
+        dc = dr = 0
+        side = self._side_to_grow(x, y)
+        while side != -1:
+            s = self._grow(side, unit)
+            dc += s[0]; dr += s[1]
+            side = self._side_to_grow(x, y)
+        return dc, dr
+
+    def to_map_idx(self, x, y, unit):                                         # :102-106
+        xi = np.rint((np.asarray(x) - self.lim_x[0]) / unit).astype(int)
+        yi = np.rint((np.asarray(y) - self.lim_y[0]) / unit).astype(int)
+        return xi, yi
+
+    def download(self):
+        """(visited, total) as float64 host arrays, like the reference's attributes."""
+        raw = self.cells[:, :self.cols].cpu().numpy().view(np.uint32)
+        return (raw >> np.uint32(16)).astype(np.float64), (raw & np.uint32(0xFFFF)).astype(np.float64)
+
+    def upload(self, visited, total):
+        v = np.asarray(visited)
+        t = np.asarray(total)
+        if v.shape != (self.rows, self.cols) or t.shape != v.shape:
+            raise ValueError("count arrays do not match the map shape")
+        if (v < 0).any() or (t < 0).any() or v.max() > 65535 or t.max() > 65535 or \
+                not (np.array_equal(v, np.rint(v)) and np.array_equal(t, np.rint(t))):
+            raise ValueError("counts must be integers in [0, 65535]")
+        packed = (v.astype(np.uint32) << np.uint32(16)) | t.astype(np.uint32)
+        self.cells[:, :self.cols] = torch.from_numpy(packed.view(np.int32)).to(self.device)
+
+    def clone(self):
+        m = MapState.__new__(MapState)
+        m.device = self.device
+        m.X, m.Y = self.X.copy(), self.Y.copy()
+        m.rows, m.cols, m.pitch = self.rows, self.cols, self.pitch
+        m.cells = self.cells.clone()
+        m._sync_coords()
+        m.growth_log = list(self.growth_log)
+        return m
+
+
+def upload_map_descs(maps, device):
+    arr = (Slam2dMap * len(maps))(*[m.desc() for m in maps])
+    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+
+
+# ----------------------------------------------------------------------------
+# One search level (Utils/ScanMatcher_OGBased.py:53-60 coarse, :65-73 fine)
+# ----------------------------------------------------------------------------
+class SearchLevel:
+    """Parameters and device workspaces of one level for P particles."""
+
+    def __init__(self, lidar, P, device, step, sigma, miss_prob, search_radius_ctor, radius, half_rad, fine,
+                 move_sigma, max_move_dev, turn_sigma):
+        self.lidar, self.P, self.device = lidar, P, device
+        self.step, self.sigma, self.miss_prob, self.fine = step, sigma, miss_prob, bool(fine)
+        self.radius, self.half_rad = radius, half_rad
+        self.reach = 1.1 * lidar.max_range + search_radius_ctor                   # :21
+        self.taps, self.blur_radius = gaussian_taps(sigma)
+        if self.blur_radius > _lib.MAX_BLUR_RADIUS:
+            raise ValueError(f"blur radius {self.blur_radius} exceeds {_lib.MAX_BLUR_RADIUS}")
+        self.log_miss = math.log(miss_prob)                                       # :25
+        self.floor_value = blurred_free_value(self.log_miss, self.taps, self.blur_radius)
+        self.ncell = int(radius / step)                                           # :94
+        self.nx = 2 * self.ncell + 1
+        self.thetas = np.arange(-half_rad, half_rad + lidar.angular_step, lidar.angular_step)   # :114
+        self.ntheta = len(self.thetas)
+        self.fmax = int(2 * self.reach / step) + 2
+        self.fpitch = -(-self.fmax // 16) * 16
+        self.wmax = int(2 * self.reach / lidar.unit) + 3
+        self.kmax = lidar.beams
+        self.rv_coef = -(1 / (2 * move_sigma ** 2))                               # :101
+        self.tw_coef = -1 / (2 * turn_sigma ** 2)                                 # :108
+        self.max_move_dev = max_move_dev
+        npose = self.nx * self.nx
+        i32, f64 = torch.int32, torch.float64
+        t = self.t = dict(
+            blur_w=_dev(self.taps, device),
+            thetas=_dev(self.thetas, device),
+            # scalar np.cos / np.sin per angle, as the reference's rotate() sees them (:169-170)
+            cos=_dev(np.array([np.cos(a) for a in self.thetas]), device),
+            sin=_dev(np.array([np.sin(a) for a in self.thetas]), device),
+            frames=torch.zeros((P, C.sizeof(Slam2dFrame)), dtype=torch.uint8, device=device),
+            axis_x=torch.zeros((P, self.wmax), dtype=i32, device=device),
+            axis_y=torch.zeros((P, self.wmax), dtype=i32, device=device),
+            occ=torch.zeros((P, self.fmax, self.fpitch), dtype=torch.uint8, device=device),
+            field=torch.zeros((P, self.fmax, self.fpitch), dtype=torch.float32, device=device),
+            cells=torch.zeros((P, self.ntheta, self.kmax), dtype=i32, device=device),
+            kcount=torch.zeros((P, self.ntheta), dtype=i32, device=device),
+            prior=torch.zeros((P, 2, npose), dtype=f64, device=device),
+            cube=torch.zeros((P, self.ntheta, npose), dtype=f64, device=device),
+        )
+        self.c = Slam2dLevel(
+            step=step, reach=self.reach, log_miss=self.log_miss, floor_value=self.floor_value,
+            blur_radius=self.blur_radius, fmax=self.fmax, fpitch=self.fpitch, wmax=self.wmax,
+            blur_w=t["blur_w"].data_ptr(), ncell=self.ncell, ntheta=self.ntheta, fine=int(self.fine),
+            kmax=self.kmax, thetas=t["thetas"].data_ptr(), theta_cos=t["cos"].data_ptr(),
+            theta_sin=t["sin"].data_ptr(), rv_coef=self.rv_coef, tw_coef=self.tw_coef,
+            max_move_dev=max_move_dev, frames=t["frames"].data_ptr(), axis_x=t["axis_x"].data_ptr(),
+            axis_y=t["axis_y"].data_ptr(), occ=t["occ"].data_ptr(), field=t["field"].data_ptr(),
+            cells=t["cells"].data_ptr(), kcount=t["kcount"].data_ptr(), prior=t["prior"].data_ptr(),
+            cube=t["cube"].data_ptr())
+
+    # -- results --
+    def frames(self):
+        return self.t["frames"].cpu().numpy().view(_FRAME_DTYPE).reshape(-1)
+
+    def field(self, p=0):
+        """probSP of particle p as a float64 host array [fh, fw] (float32 values)."""
+        fr = self.frames()[p]
+        return self.t["field"][p, :fr["fh"], :fr["fw"]].cpu().numpy().astype(np.float64)
+
+    def cube(self, p=0):
+        return self.t["cube"][p].cpu().numpy().reshape(self.ntheta, self.nx, self.nx)
+
+    def cells_of(self, p, it):
+        k = int(self.t["kcount"][p, it].item())
+        off = self.t["cells"][p, it, :k].cpu().numpy()
+        return off // self.fpitch + self.ncell, off % self.fpitch + self.ncell      # (cy, cx)
+
+    def algorithmic_bytes(self, n_window_cells=None):
+        """SURVEY.md 8(d) per particle-scan at this level: field build
+        2*c*Wm^2 + 4*Fh*Fw (c = 2 bytes per count: packed uint32 cell holds both),
+        sweep 4*Fh*Fw + 8*B + 4*Ntheta*Ny*Nx (cube counted at 4 B as in the survey)."""
+        wm = int(2 * self.reach / self.lidar.unit) if n_window_cells is None else n_window_cells
+        f = (self.fmax - 1) ** 2
+        field_build = 2 * 2 * wm * wm + 4 * f
+        sweep = 4 * f + 8 * self.lidar.beams + 4 * self.ntheta * self.nx * self.nx
+        return dict(field_build=field_build, sweep=sweep)
+
+
+# ----------------------------------------------------------------------------
+# The engine: P particles, their maps, two search levels, the kernel calls
+# ----------------------------------------------------------------------------
+class ParticleEngine:
+    """Batched scan matching + map update for P particles on one GPU."""
+
+    def __init__(self, lidar, maps, device):
+        self.device = require_gpu(device)
+        self.L = _lib.lib()
+        self.lidar = lidar
+        self.lidar_c = lidar.on(self.device)
+        self.maps = list(maps)
+        self.P = len(self.maps)
+        self.flags = torch.zeros(self.P, dtype=torch.int32, device=self.device)
+        self.axis_scratch = torch.zeros((self.P, 2, lidar.width), dtype=torch.int32, device=self.device)
+        self.match_buf = {}
+        self.refresh_maps()
+
+    def refresh_maps(self):
+        self.d_maps = upload_map_descs(self.maps, self.device)
+
+    def match_buffer(self, name):
+        if name not in self.match_buf:
+            self.match_buf[name] = torch.zeros((self.P, MATCH_DOUBLES), dtype=torch.float64, device=self.device)
+        return self.match_buf[name]
+
+    @staticmethod
+    def read_matches(buf):
+        return buf.cpu().numpy().view(_MATCH_DTYPE).reshape(-1)
+
+    # -- kernels --
+    def field_build(self, level, d_centre, stride):
+        check(self.L.slam2d_field_build(C.byref(self.lidar_c), C.byref(level.c), _ptr(self.d_maps), self.P,
+                                        _ptr(d_centre), stride, _ptr(self.flags), _stream()), "slam2d_field_build")
+
+    def sweep(self, level, d_est, stride, d_ranges, est_moving_dist, d_psi_cs, d_uniform, d_out):
+        check(self.L.slam2d_sweep(C.byref(self.lidar_c), C.byref(level.c), self.P, _ptr(d_est), stride,
+                                  _ptr(d_ranges), float(est_moving_dist), _ptr(d_psi_cs), _ptr(d_uniform),
+                                  _ptr(d_out), _ptr(self.flags), _stream()), "slam2d_sweep")
+
+    def grid_update(self, d_pose, stride, d_ranges, d_beam_shift=None):
+        check(self.L.slam2d_grid_update(C.byref(self.lidar_c), _ptr(self.d_maps), self.P, _ptr(d_pose), stride,
+                                        _ptr(d_ranges), _ptr(self.axis_scratch), _ptr(d_beam_shift),
+                                        _ptr(self.flags), _stream()), "slam2d_grid_update")
+
+    def take_flags(self, fatal=_lib.FATAL_FLAGS):
+        """Synchronise, fetch and clear the per-particle fault bits; raise on fatal ones."""
+        f = self.flags.cpu().numpy().view(np.uint32).copy()
+        self.flags.zero_()
+        bad = np.flatnonzero(f & fatal)
+        if bad.size:
+            p = int(bad[0])
+            raise _lib.Slam2dError(f"particle {p}: {_lib.describe_flags(int(f[p]) & fatal)}")
+        return f
+
+    # -- uploads --
+    def to_device(self, a, dtype=np.float64):
+        return _dev(np.asarray(a, dtype=dtype), self.device)
+
+    @staticmethod
+    def psi_table(psi):
+        """(math.cos, math.sin) per particle of estMovingTheta; NaN rows for None
+        (Utils/ScanMatcher_OGBased.py:104-107)."""
+        out = np.full((len(psi), 2), np.nan)
+        for i, v in enumerate(psi):
+            if v is not None and not (isinstance(v, float) and math.isnan(v)):
+                out[i] = (math.cos(v), math.sin(v))
+        return out

@@ -1,0 +1,260 @@
+"""Batched FastSLAM particle filter: the behaviour of the reference's
+``ParticleFilter`` / ``Particle`` (Algorithm/FastSlam.py:10-140) with every particle's
+scan match and map update done in one set of kernel launches.
+
+The reference loops over particles serially (:25-27); here the particle index is the
+batch axis of the device state.  Constructor arguments and method names follow the
+reference.  Sharding over several GPUs (one process per GPU) is in ``parallel.py``;
+this class handles the particles of one rank.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .engine import MATCH_DOUBLES, LidarModel, MapState, ParticleEngine, SearchLevel, require_gpu, _ptr, _stream
+
+
+class ParticleView:
+    """What the reference's callers read from a particle (Algorithm/FastSlam.py:164-177)."""
+
+    def __init__(self, pf, i):
+        self._pf, self._i = pf, i
+
+    @property
+    def weight(self):
+        return float(self._pf.weights[self._i])
+
+    @property
+    def xTrajectory(self):
+        return [t[self._i, 0] for t in self._pf.trajectory]
+
+    @property
+    def yTrajectory(self):
+        return [t[self._i, 1] for t in self._pf.trajectory]
+
+    @property
+    def prevMatchedReading(self):
+        m = self._pf.prev_matched[self._i]
+        return {"x": float(m[0]), "y": float(m[1]), "theta": float(m[2]), "range": self._pf.prev_raw["range"]}
+
+    @property
+    def og(self):
+        return MapView(self._pf, self._i)
+
+
+class MapView:
+    def __init__(self, pf, i):
+        self._pf, self._m = pf, pf.engine.maps[i]
+
+    @property
+    def occupancyGridVisited(self):
+        return self._m.download()[0]
+
+    @property
+    def occupancyGridTotal(self):
+        return self._m.download()[1]
+
+    @property
+    def mapXLim(self):
+        return self._m.lim_x
+
+    @property
+    def mapYLim(self):
+        return self._m.lim_y
+
+    def convertRealXYToMapIdx(self, x, y):
+        return self._m.to_map_idx(x, y, self._pf.lidar.unit)
+
+
+def _heading(dx, dy, dist):
+    return math.acos(dx / dist) if dy > 0 else -math.acos(dx / dist)
+
+
+class ParticleFilter:
+    """``ParticleFilter(numParticles, ogParameters, smParameters)`` as in
+    Algorithm/FastSlam.py:11,197-207.
+
+    growable=True reproduces the reference's map growth (host check + device
+    re-allocation per particle; one extra synchronisation per scan).  growable=False
+    skips the growth checks: maps must be pre-sized, and a window that leaves the
+    map raises.  ``updateParticles`` is synchronous per scan (the odometry prior of the
+    next scan needs the matched poses on the host); ``bench.py`` drives the same
+    kernels without host round trips.
+    ``total_particles`` / ``first_index`` describe this rank's slice when sharded;
+    ``rng`` defaults to the legacy global NumPy stream like the reference."""
+
+    def __init__(self, numParticles, ogParameters, smParameters, device=None, growable=True, rng=None,
+                 total_particles=None, first_index=0):
+        (mapX, mapY, initXY, unit, fov, max_range, beams, wall) = ogParameters            # :66
+        (sr, half_rad, sigma, move_sigma, max_dev, turn_sigma, miss, cf) = smParameters   # :67-68
+        self.device = require_gpu(device or "cuda:0")
+        self.numParticles = numParticles
+        self.total_particles = total_particles or numParticles
+        self.first_index = first_index
+        self.growable = growable
+        self.rng = rng
+        self.lidar = LidarModel.get(unit, max_range, fov, beams, wall)
+        maps = [MapState.create(mapX, mapY, initXY, unit, self.device) for _ in range(numParticles)]
+        self.engine = ParticleEngine(self.lidar, maps, self.device)
+        P, dev = numParticles, self.device
+        common = dict(search_radius_ctor=sr, half_rad=half_rad, move_sigma=move_sigma, max_move_dev=max_dev,
+                      turn_sigma=turn_sigma)
+        cstep = cf * unit                                                                 # ScanMatcher_OGBased.py:54
+        self.coarse = SearchLevel(self.lidar, P, dev, step=cstep, sigma=sigma / cf, miss_prob=miss, radius=sr,
+                                  fine=False, **common)
+        self.fine = SearchLevel(self.lidar, P, dev, step=unit, sigma=sigma, miss_prob=miss ** (2 / cf),
+                                radius=cstep, fine=True, **common)                        # :66-73
+        self.m_coarse = self.engine.match_buffer("coarse")
+        self.m_fine = self.engine.match_buffer("fine")
+        self.d_logw = torch.zeros(P, dtype=torch.float64, device=dev)     # log of weight = 1 (:75)
+        self.d_w = torch.full((P,), 1.0, dtype=torch.float64, device=dev)
+        self.d_stats = torch.zeros(2, dtype=torch.float64, device=dev)
+        self.weights = np.ones(P)
+        self.trajectory = []
+        self.prev_matched = None
+        self.prev_raw = None
+        self.prev_raw_heading = None
+        self.prev_matched_heading = [None] * P
+        self.particles = [ParticleView(self, i) for i in range(P)]
+        self.last_confidence = np.ones(P)
+        self.last_variance = None
+        self.step = 0
+
+    # ---- odometry prior, vectorised over particles (Algorithm/FastSlam.py:77-106) ----
+    def _prior(self, raw):
+        pm, pr = self.prev_matched, self.prev_raw
+        est = np.empty((self.numParticles, 3))
+        est[:, 0], est[:, 1] = pm[:, 0], pm[:, 1]
+        est[:, 2] = pm[:, 2] + raw['theta'] - pr['theta']
+        dx, dy = raw['x'] - pr['x'], raw['y'] - pr['y']
+        dist = math.sqrt(dx ** 2 + dy ** 2)
+        psi = [None] * self.numParticles
+        raw_heading = None
+        if dist > 0.3:
+            raw_heading = _heading(dx, dy, dist)
+            if self.prev_raw_heading is not None:
+                turn = raw_heading - self.prev_raw_heading
+                # (the reference raises TypeError if a particle's last matched move was exactly 0)
+                psi = [None if h is None else h + turn for h in self.prev_matched_heading]
+        return est, dist, psi, raw_heading
+
+    def _draw_uniforms(self):
+        """One uniform per particle of the WHOLE filter, in particle order, from the legacy
+        stream -- the order np.random.choice consumes it in the reference's serial loop
+        (ScanMatcher_OGBased.py:138); a rank uses its own slice."""
+        src = self.rng if self.rng is not None else np.random
+        u = src.random_sample(self.total_particles)
+        return u[self.first_index:self.first_index + self.numParticles]
+
+    # ---- Particle.update for all particles (Algorithm/FastSlam.py:25-27,122-135) ----
+    def updateParticles(self, reading, count):
+        eng, P = self.engine, self.numParticles
+        ranges = np.asarray(reading['range'], dtype=np.float64)
+        d_rng = eng.to_device(ranges)
+        if count == 1:
+            self.prev_raw_heading = None
+            self.prev_matched_heading = [None] * P
+            matched = np.tile([reading['x'], reading['y'], reading['theta']], (P, 1)).astype(np.float64)
+            conf = np.ones(P)
+            logconf = np.zeros(P)
+            d_pose, stride = eng.to_device(matched), 3
+        else:
+            est, dist, psi, raw_heading = self._prior(reading)
+            matched, conf, logconf = self._match(est, dist, psi, d_rng)
+            self.prev_raw_heading = raw_heading
+            last = self.trajectory[-1]
+            heads = []
+            for i in range(P):                                     # getMovingTheta (:108-120)
+                mx, my = matched[i, 0] - last[i, 0], matched[i, 1] - last[i, 1]
+                move = math.sqrt(mx ** 2 + my ** 2)
+                heads.append(_heading(mx, my, move) if move != 0 else None)
+            self.prev_matched_heading = heads
+            d_pose, stride = self.m_fine, MATCH_DOUBLES
+        self.trajectory.append(matched[:, :2].copy())
+        if self.growable:
+            self._grow_for_update(matched)
+        eng.grid_update(d_pose, stride, d_rng)                     # :133
+        self.prev_matched, self.prev_raw = matched, reading
+        self.last_confidence = conf
+        self.d_logw += eng.to_device(logconf)                      # weight *= confidence (:135)
+        eng.take_flags()
+        self.step += 1
+
+    def _match(self, est, dist, psi, d_rng):
+        """matchScan(matchMax=False) for every particle (ScanMatcher_OGBased.py:47-79)."""
+        eng = self.engine
+        d_est = eng.to_device(est)
+        d_psi = eng.to_device(eng.psi_table(psi))
+        d_u = eng.to_device(self._draw_uniforms())
+        if self.growable:
+            self._grow_for_windows(est[:, 0], est[:, 1], self.coarse.reach)
+        eng.field_build(self.coarse, d_est, 3)
+        eng.sweep(self.coarse, d_est, 3, d_rng, dist, d_psi, d_u, self.m_coarse)
+        if self.growable:
+            eng.take_flags()
+            c = eng.read_matches(self.m_coarse)
+            self._grow_for_windows(c["x"], c["y"], self.fine.reach)
+        eng.field_build(self.fine, self.m_coarse, MATCH_DOUBLES)
+        eng.sweep(self.fine, self.m_coarse, MATCH_DOUBLES, d_rng, dist, None, None, self.m_fine)
+        eng.take_flags()
+        c = eng.read_matches(self.m_coarse)
+        f = eng.read_matches(self.m_fine)
+        matched = np.stack([f["x"], f["y"], f["theta"]], axis=1)
+        return matched, c["confidence"].copy(), c["log_confidence"].copy()
+
+    def _grow_for_windows(self, xs, ys, reach):
+        grew = False
+        for m, x, y in zip(self.engine.maps, xs, ys):
+            n = len(m.growth_log)
+            m.ensure_contains([x - reach, x + reach], [y - reach, y + reach], self.lidar.unit)
+            grew |= len(m.growth_log) != n
+        if grew:
+            self.engine.refresh_maps()
+
+    def _grow_for_update(self, matched):
+        """The update window (pose +/- R) lies inside the search window that was grown for
+        (estimate +/- (1.1 R + searchRadius)), except on the first scan of a small map."""
+        R = self.lidar.max_range
+        for m, (x, y, _) in zip(self.engine.maps, matched):
+            if x - R < m.lim_x[0] or x + R > m.lim_x[1] or y - R < m.lim_y[0] or y + R > m.lim_y[1]:
+                raise _lib.Slam2dError("the first scan's lidar window leaves the initial map: pre-size the map "
+                                       "(the per-beam growth of Utils/OccupancyGrid.py:147 is only reproduced by "
+                                       "the single-particle OccupancyGrid class)")
+
+    # ---- weights (Algorithm/FastSlam.py:30-48) ----
+    def normalizeWeights(self):
+        L = _lib.lib()
+        _lib.check(L.slam2d_weights_normalize(_ptr(self.d_logw), None, self.numParticles, _ptr(self.d_w),
+                                              _ptr(self.d_stats), _stream()), "slam2d_weights_normalize")
+        self.weights = self.d_w.cpu().numpy()
+        self.last_variance = float(self.d_stats[0].item())
+
+    def weightUnbalanced(self):
+        self.normalizeWeights()
+        n = self.numParticles
+        return self.last_variance > ((n - 1) / n) ** 2 + (n - 1.000000000000001) * (1 / n) ** 2     # :37
+
+    # ---- resample (Algorithm/FastSlam.py:50-62) ----
+    def resample(self):
+        n = self.numParticles
+        src = self.rng if self.rng is not None else np.random
+        idx = src.choice(np.arange(n), n, p=self.weights)                                # :59
+        self.apply_resample(idx)
+        return idx
+
+    def apply_resample(self, idx):
+        old = self.engine.maps
+        self.engine.maps = [old[j].clone() for j in idx]            # deepcopy of the chosen particles (:61)
+        self.engine.refresh_maps()
+        self.prev_matched = self.prev_matched[idx].copy()
+        self.prev_matched_heading = [self.prev_matched_heading[j] for j in idx]
+        self.trajectory = [t[idx].copy() for t in self.trajectory]
+        self.weights = np.full(n := self.numParticles, 1 / n)                            # :62
+        self.d_logw.fill_(math.log(1 / n))
+        self.d_w.fill_(1 / n)
+
+    def best_particle(self):
+        return self.particles[int(np.argmax(self.weights))]

@@ -1,0 +1,200 @@
+"""``OccupancyGrid`` with the reference's class surface (Utils/OccupancyGrid.py:6-175),
+backed by a device-resident packed count map and the HIP update kernel.
+
+Constructor arguments, method names, attribute names and semantics follow the
+reference so that ``Algorithm/FastSlam.py`` and the single-trajectory driver run on
+it unchanged.  ``occupancyGridVisited`` / ``occupancyGridTotal`` are properties that
+download the counts as float64 NumPy arrays (the reference stores float64 arrays).
+"""
+import copy
+
+import numpy as np
+import torch
+
+from . import _lib
+from .engine import LidarModel, MapState, ParticleEngine, require_gpu
+
+DEFAULT_DEVICE = "cuda:0"
+
+
+class OccupancyGrid:
+    def __init__(self, mapXLength, mapYLength, initXY, unitGridSize, lidarFOV, numSamplesPerRev, lidarMaxRange,
+                 wallThickness, device=None):
+        self.device = require_gpu(device or DEFAULT_DEVICE)
+        self.unitGridSize = unitGridSize
+        self.lidarFOV = lidarFOV
+        self.lidarMaxRange = lidarMaxRange
+        self.wallThickness = wallThickness
+        self.numSamplesPerRev = numSamplesPerRev
+        self.lidar = LidarModel.get(unitGridSize, lidarMaxRange, lidarFOV, numSamplesPerRev, wallThickness)
+        self.angularStep = self.lidar.angular_step                 # Utils/OccupancyGrid.py:22
+        self.numSpokes = self.lidar.num_spokes                     # :23
+        self.spokesStartIdx = self.lidar.spoke_start               # :30
+        self.map = MapState.create(mapXLength, mapYLength, initXY, unitGridSize, self.device)
+        self.version = 0            # bumped whenever the device map is re-allocated
+        self._engine = None
+
+    # ---- attributes of the reference ----
+    @property
+    def mapXLim(self):
+        return self.map.lim_x
+
+    @property
+    def mapYLim(self):
+        return self.map.lim_y
+
+    @property
+    def occupancyGridVisited(self):
+        return self.map.download()[0]
+
+    @occupancyGridVisited.setter
+    def occupancyGridVisited(self, value):
+        self.map.upload(value, self.map.download()[1])
+
+    @property
+    def occupancyGridTotal(self):
+        return self.map.download()[1]
+
+    @occupancyGridTotal.setter
+    def occupancyGridTotal(self, value):
+        self.map.upload(self.map.download()[0], value)
+
+    def set_counts(self, visited, total):
+        """Upload both count arrays at once (tests / synthetic worlds)."""
+        self.map.upload(visited, total)
+
+    @property
+    def OccupancyGridX(self):
+        return np.meshgrid(self.map.X, self.map.Y)[0]
+
+    @property
+    def OccupancyGridY(self):
+        return np.meshgrid(self.map.X, self.map.Y)[1]
+
+    # ---- engine (one particle) ----
+    def engine(self):
+        if self._engine is None or self._engine_version != self.version:
+            if self._engine is None:
+                self._engine = ParticleEngine(self.lidar, [self.map], self.device)
+            else:
+                self._engine.refresh_maps()
+            self._engine_version = self.version
+        return self._engine
+
+    # ---- index conversion and growth (Utils/OccupancyGrid.py:59-125) ----
+    def convertRealXYToMapIdx(self, x, y):
+        return self.map.to_map_idx(x, y, self.unitGridSize)
+
+    def checkMapToExpand(self, x, y):
+        return self.map._side_to_grow(x, y)
+
+    def expandOccupancyGrid(self, expandDirection):
+        self.map._grow(expandDirection if expandDirection in (1, 2, 3) else 4, self.unitGridSize)
+        self.version += 1
+
+    def checkAndExapndOG(self, x, y):
+        before = len(self.map.growth_log)
+        shift = self.map.ensure_contains(x, y, self.unitGridSize)
+        if len(self.map.growth_log) != before:
+            self.version += 1
+        return shift
+
+    # ---- per-scan update (Utils/OccupancyGrid.py:127-159) ----
+    def _spoke_lists(self):
+        lid = self.lidar
+        if not hasattr(lid, "_spoke_ptr"):
+            flat = lid.bin.ravel().astype(np.int64)
+            lid._spoke_cells = np.argsort(flat, kind="stable")
+            lid._spoke_ptr = np.concatenate(([0], np.cumsum(np.bincount(flat, minlength=lid.num_spokes))))
+        return lid._spoke_cells, lid._spoke_ptr
+
+    def _beam_cells(self, theta, rng):
+        """Per beam: (flat LUT cells, empty mask, occupied mask), reference order."""
+        lid = self.lidar
+        cells, ptr = self._spoke_lists()
+        S = lid.num_spokes
+        offset = int(np.rint(theta / (2 * np.pi) * S))
+        r_flat = lid.r.ravel()
+        half_w = self.wallThickness / 2
+        for i in range(self.numSamplesPerRev):
+            spoke = int(np.rint((self.spokesStartIdx + offset + i) % S))
+            c = cells[ptr[spoke]:ptr[spoke + 1]]
+            rs = r_flat[c]
+            empty = rs < rng[i] - half_w if rng[i] < self.lidarMaxRange else np.zeros(rs.shape, dtype=bool)
+            occ = (rs > rng[i] - half_w) & (rs < rng[i] + half_w)
+            yield i, c, empty, occ
+
+    def _grow_for_update(self, x, y, theta, rng):
+        """Per-beam growth exactly in the reference's order (:147), returning the
+        [beams, 2] low-side shifts that make the kernel reproduce its stale-index
+        writes (:144-152), or None if nothing grew."""
+        W = self.lidar.width
+        xs = self.lidar.xs
+        shifts = np.zeros((self.numSamplesPerRev, 2), dtype=np.int32)
+        grew = False
+        for i, c, _, occ in self._beam_cells(theta, rng):
+            if not occ.any():
+                continue
+            ox, oy = x + xs[c[occ] % W], y + xs[c[occ] // W]
+            dc, dr = self.checkAndExapndOG(ox, oy)
+            if dc or dr:
+                shifts[i] = (dc, dr)
+                grew = True
+        return shifts if grew else None
+
+    def updateOccupancyGrid(self, reading, dTheta=0, update=True):
+        x, y, theta = reading['x'], reading['y'], reading['theta'] + dTheta
+        rng = np.asarray(reading['range'], dtype=np.float64)
+        if not update:
+            return self._update_points(x, y, theta, rng)
+        R = self.lidarMaxRange
+        m = self.map
+        shifts = None
+        if x - R < m.lim_x[0] or x + R > m.lim_x[1] or y - R < m.lim_y[0] or y + R > m.lim_y[1]:
+            shifts = self._grow_for_update(x, y, theta, rng)      # rare: first scan of a small map
+        eng = self.engine()
+        d_pose = eng.to_device([[x, y, theta]])
+        d_rng = eng.to_device(rng)
+        d_shift = eng.to_device(shifts[None], dtype=np.int32) if shifts is not None else None
+        eng.grid_update(d_pose, 3, d_rng, d_shift)
+        eng.take_flags()
+
+    def _update_points(self, x, y, theta, rng):
+        """update=False variant (:153-159): world coordinates of the empty / occupied cells."""
+        W, xs = self.lidar.width, self.lidar.xs
+        ex, ey, ox, oy = [], [], [], []
+        for _, c, empty, occ in self._beam_cells(theta, rng):
+            ex.extend(x + xs[c[empty] % W]); ey.extend(y + xs[c[empty] // W])
+            ox.extend(x + xs[c[occ] % W]); oy.extend(y + xs[c[occ] // W])
+        return np.asarray(ex), np.asarray(ey), np.asarray(ox), np.asarray(oy)
+
+    # ---- plotting (host Matplotlib, off the hot path; Utils/OccupancyGrid.py:161-175) ----
+    def plotOccupancyGrid(self, xRange=None, yRange=None, plotThreshold=True):
+        import matplotlib.pyplot as plt
+        if xRange is None or xRange[0] < self.mapXLim[0] or xRange[1] > self.mapXLim[1]:
+            xRange = self.mapXLim
+        if yRange is None or yRange[0] < self.mapYLim[0] or yRange[1] > self.mapYLim[1]:
+            yRange = self.mapYLim
+        visited, total = self.map.download()
+        xIdx, yIdx = self.convertRealXYToMapIdx(xRange, yRange)
+        img = np.flipud(1 - (visited / total)[yIdx[0]:yIdx[1], xIdx[0]:xIdx[1]])
+        extent = [xRange[0], xRange[1], yRange[0], yRange[1]]
+        plt.imshow(img, cmap='gray', extent=extent)
+        plt.show()
+        if plotThreshold:
+            plt.matshow(img >= 0.5, cmap='gray', extent=extent)
+            plt.show()
+
+    # ---- copy.deepcopy support (Algorithm/FastSlam.py:58,61) ----
+    def __deepcopy__(self, memo):
+        new = OccupancyGrid.__new__(OccupancyGrid)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k in ("map", "_engine", "lidar", "device"):
+                continue
+            setattr(new, k, copy.deepcopy(v, memo))
+        new.device, new.lidar = self.device, self.lidar
+        new.map = self.map.clone()
+        new._engine = None
+        new.version = 0
+        return new

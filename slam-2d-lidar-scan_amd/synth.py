@@ -89,15 +89,17 @@ def free_pose_near(world, unit, origin_xy, rs, centre=None, spread=3.0):
     raise RuntimeError("no free pose found")
 
 
-def random_walk(world, unit, origin_xy, n_scans, seed=0, step=0.4, turn=0.15):
-    """Seeded trajectory of ``n_scans`` poses that stays in free space; each
-    pose sits on the map lattice (multiples of ``unit`` from the first), like
-    the poses the matcher emits."""
+def random_walk(world, unit, origin_xy, n_scans, seed=0, step=0.4, turn=0.15, max_radius=None):
+    """Seeded trajectory of ``n_scans`` poses that stays in free space (and, if
+    ``max_radius`` is given, within that distance of its start); each pose sits on
+    the map lattice (multiples of ``unit`` from the first), like the poses the
+    matcher emits."""
     rs = np.random.RandomState(seed)
     x, y, th = free_pose_near(world, unit, origin_xy, rs, spread=1.0)
     x = origin_xy[0] + unit * round((x - origin_xy[0]) / unit)
     y = origin_xy[1] + unit * round((y - origin_xy[1]) / unit)
     poses = [(x, y, th)]
+    x0, y0 = x, y
     n = world.shape[0]
     k = max(1, int(0.3 / unit))
     while len(poses) < n_scans:
@@ -107,7 +109,8 @@ def random_walk(world, unit, origin_xy, n_scans, seed=0, step=0.4, turn=0.15):
             ny = y + unit * round(step * np.sin(nth) / unit)
             c = int(round((nx - origin_xy[0]) / unit))
             r = int(round((ny - origin_xy[1]) / unit))
-            if k <= r < n - k and k <= c < n - k and not world[r - k:r + k + 1, c - k:c + k + 1].any():
+            inside = max_radius is None or (nx - x0) ** 2 + (ny - y0) ** 2 <= max_radius ** 2
+            if inside and k <= r < n - k and k <= c < n - k and not world[r - k:r + k + 1, c - k:c + k + 1].any():
                 x, y, th = nx, ny, nth
                 break
             th = th + rs.uniform(-1.0, 1.0)

@@ -1,0 +1,338 @@
+"""Parity of the HIP path (through the C ABI, via the drop-in classes) against the
+golden vectors captured from the reference and against the CPU oracle on the same
+seeded inputs.  Needs an MI355X: run with ``-m gpu``.
+
+Bars (BASELINE.json north_star): arg-max pose indices identical; scores,
+confidences and weights within 1e-5 relative (float32 field, float64 sums --
+observed error is ~1e-7).  Integer work (map counts, cell indices, field dimensions)
+and the float32-rounded field itself are compared bit-exactly.
+"""
+import copy
+import importlib
+
+import numpy as np
+import pytest
+
+import codec
+from conftest import load_golden
+from oracle import slam_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+REF_SM = (1.4, 0.25, 2, 0.1, 0.25, 0.3, 0.15, 5)
+RTOL = 1e-5          # the stated bar
+RTOL_TIGHT = 2e-6    # what float32 field + float64 accumulation actually delivers
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return importlib.import_module("slam-2d-lidar-scan_amd")
+
+
+def _grid_with_state(pkg, packed, X, Y, unit=0.02, fov=np.pi, beams=180, R=10, wall=0.1):
+    """OccupancyGrid whose device map is the captured state (counts + coordinate vectors)."""
+    og = pkg.OccupancyGrid(1, 1, {"x": 0.0, "y": 0.0}, unit, fov, beams, R, wall)
+    og.map = pkg.MapState(X, Y, og.device)
+    v, t = codec.unpack_counts(packed)
+    og.map.upload(v, t)
+    og.version += 1
+    return og
+
+
+LEVEL_SCANS = [2, 3, 12, 15, 16, 40, 150, 234]
+
+
+@pytest.mark.parametrize("scan", LEVEL_SCANS)
+@pytest.mark.parametrize("level", ["coarse", "fine"])
+def test_field_build_matches_reference(pkg, scan, level):
+    """frameSearchSpace + generateProbSearchSpace: float32(probSP) bit-exact, no clamp flips."""
+    z = load_golden("levels.npz")
+    pre = f"s{scan}_{level}_field_"
+    og = _grid_with_state(pkg, z[pre + "map"], z[pre + "X"], z[pre + "Y"])
+    sm = pkg.ScanMatcher(og, *REF_SM)
+    ex, ey, step, sigma, miss = z[pre + "args"]
+    xr, yr, prob = sm.frameSearchSpace(ex, ey, step, sigma, miss)
+    want = codec.decode_field(z[pre + "prob_cls"], z[pre + "prob_floor"], z[pre + "prob_other"])
+    assert og.map.growth_log == []
+    assert np.array_equal(np.array(xr), z[pre + "xr"]) and np.array_equal(np.array(yr), z[pre + "yr"])
+    assert prob.shape == want.shape
+    w32 = want.astype(np.float32).astype(np.float64)
+    flips = int(((prob == 0) != (want == 0)).sum())
+    assert flips == 0, f"{flips} clamp flips"
+    assert np.array_equal(prob, w32), f"max abs diff {np.abs(prob - w32).max():.3e}"
+
+
+@pytest.mark.parametrize("scan", LEVEL_SCANS)
+@pytest.mark.parametrize("level", ["coarse", "fine"])
+def test_sweep_matches_reference(pkg, scan, level):
+    """searchToMatch on the reference's own probSP: arg-max identical, cube and confidence
+    within the bar, matched pose identical."""
+    z = load_golden("levels.npz")
+    fpre, pre = f"s{scan}_{level}_field_", f"s{scan}_{level}_sweep_"
+    prob = codec.decode_field(z[fpre + "prob_cls"], z[fpre + "prob_floor"], z[fpre + "prob_other"])
+    og = pkg.OccupancyGrid(1, 1, {"x": 0.0, "y": 0.0}, 0.02, np.pi, 180, 10, 0.1)
+    sm = pkg.ScanMatcher(og, *REF_SM)
+    ex, ey, eth = z[pre + "est"]
+    radius, half, step, dist, psi, fine, mm = z[pre + "args"]
+    _, _, matched, cube, conf = sm.searchToMatch(prob, ex, ey, eth, z[pre + "ranges"], z[pre + "xr"], z[pre + "yr"],
+                                                 radius, half, step, dist, codec.none_if_nan(psi),
+                                                 fineSearch=bool(fine), matchMax=True)
+    want = z[pre + "cube"]
+    assert cube.shape == want.shape
+    np.testing.assert_allclose(cube, want, rtol=RTOL_TIGHT, atol=0)
+    assert int(sm.last["adhoc"]["argmax"]) == int(z[pre + "pick"])
+    np.testing.assert_allclose(conf, z[pre + "conf"], rtol=RTOL)
+    assert [matched["x"], matched["y"], matched["theta"]] == list(z[pre + "matched"])
+
+
+def test_unique_cells_match_oracle(pkg):
+    """np.unique(axis=0) of the rotated endpoint cells, per theta (bit-exact integer work)."""
+    z = load_golden("levels.npz")
+    fpre, pre = "s150_coarse_field_", "s150_coarse_sweep_"
+    prob = codec.decode_field(z[fpre + "prob_cls"], z[fpre + "prob_floor"], z[fpre + "prob_other"])
+    og = pkg.OccupancyGrid(1, 1, {"x": 0.0, "y": 0.0}, 0.02, np.pi, 180, 10, 0.1)
+    sm = pkg.ScanMatcher(og, *REF_SM)
+    ex, ey, eth = z[pre + "est"]
+    radius, half, step, dist, psi, fine, mm = z[pre + "args"]
+    sm.searchToMatch(prob, ex, ey, eth, z[pre + "ranges"], z[pre + "xr"], z[pre + "yr"], radius, half, step, dist,
+                     codec.none_if_nan(psi), fineSearch=bool(fine), matchMax=True)
+    level = sm._level(step, 1.0, 0.5, radius, half, bool(fine))
+    ogo = so.GridOracle(1, 1, {"x": 0.0, "y": 0.0}, 0.02, np.pi, 180, 10, 0.1, lut=so.SpokeLUT(0.5, 4, np.pi, 180))
+    smo = so.MatcherOracle(ogo, *REF_SM)
+    px, py = smo.covertMeasureToXY(ex, ey, eth, z[pre + "ranges"])
+    for it, th in enumerate(smo.theta_range(half)):
+        cells = smo.unique_cells(ex, ey, px, py, th, z[pre + "xr"][0], z[pre + "yr"][0], step)
+        cy, cx = level.cells_of(0, it)
+        got = set(zip(cx.tolist(), cy.tolist()))
+        assert got == set(map(tuple, cells.tolist())), f"theta {it}"
+
+
+@pytest.mark.parametrize("scan", [1, 2, 40])
+def test_update_matches_reference(pkg, scan):
+    """updateOccupancyGrid: counts bit-exact, incl. the scan-1 growth inside the update."""
+    z = load_golden("update.npz")
+    mapx, mapy, unit, fov, beams, R, wall = z["cfg"]
+    og = pkg.OccupancyGrid(mapx, mapy, {"x": float(z["init"][0]), "y": float(z["init"][1])}, unit, fov, int(beams),
+                           R, wall)
+    before = z[f"s{scan}_before"]
+    if before.shape != (og.map.rows, og.map.cols):
+        xl0, xl1, yl0, yl1 = z[f"s{scan}_lim_after"]
+        X = np.linspace(xl0, xl1, before.shape[1]); Y = np.linspace(yl0, yl1, before.shape[0])
+        X[0], X[-1], Y[0], Y[-1] = xl0, xl1, yl0, yl1
+        og.map = pkg.MapState(X, Y, og.device)
+        og.version += 1
+    og.map.upload(*codec.unpack_counts(before))
+    x, y, th = z[f"s{scan}_pose"]
+    og.updateOccupancyGrid({"x": x, "y": y, "theta": th, "range": z[f"s{scan}_ranges"]})
+    after = codec.pack_counts(og.occupancyGridVisited, og.occupancyGridTotal)
+    assert after.shape == z[f"s{scan}_after"].shape
+    assert np.array_equal(after, z[f"s{scan}_after"])
+    assert np.array_equal(np.array([og.mapXLim[0], og.mapXLim[1], og.mapYLim[0], og.mapYLim[1]]),
+                          z[f"s{scan}_lim_after"])
+
+
+def test_scanmatch_flow_matches_reference(pkg, intel_readings):
+    """Config 1 plumbing on the GPU classes: the single-trajectory flow
+    (Utils/ScanMatcher_OGBased.py:226-256) over the first 40 Intel scans, map growth
+    included: poses identical to the reference's, confidences within the bar, final map
+    identical to the oracle's."""
+    z = load_golden("flow_scanmatch.npz")
+    n = 40
+    r0 = intel_readings[0]
+    og = pkg.OccupancyGrid(10, 10, r0, 0.02, np.pi, 180, 10, 0.1)
+    sm = pkg.ScanMatcher(og, *REF_SM)
+    out, confs = so.run_scanmatch_flow(intel_readings, og, sm, max_scans=n)
+    got = np.array([[m["x"], m["y"], m["theta"]] for m in out])
+    assert np.array_equal(got, z["poses"][:n])
+    np.testing.assert_allclose(np.array(confs, dtype=np.float64), z["confs"][:n], rtol=RTOL)
+    ogo = so.GridOracle(10, 10, r0, 0.02, np.pi, 180, 10, 0.1)
+    smo = so.MatcherOracle(ogo, *REF_SM)
+    so.run_scanmatch_flow(intel_readings, ogo, smo, max_scans=n)
+    assert np.array_equal(og.occupancyGridVisited, ogo.visited) and np.array_equal(og.occupancyGridTotal, ogo.total)
+    assert og.mapXLim == ogo.mapXLim and og.mapYLim == ogo.mapYLim
+    assert og.map.growth_log == ogo.growth_log
+
+
+def test_dropin_under_fastslam_caller(pkg, intel_readings):
+    """The reference's Particle / ParticleFilter caller logic (restated in the oracle module,
+    Algorithm/FastSlam.py:10-140) driving the HIP OccupancyGrid / ScanMatcher classes
+    unchanged, copy.deepcopy resample included, against the golden FastSLAM run."""
+    z = load_golden("flow_fastslam.npz")
+    n_particles, n_scans, seed, map_m = (int(v) for v in z["cfg"])
+    n_scans = 20
+    u = 0.02
+    ogP = [map_m, map_m, intel_readings[0], u, np.pi, 10, 180, 5 * u]
+    np.random.seed(seed)       # the drop-in matcher draws from the legacy global stream, like the reference
+    pf = so.ParticleFilterOracle(n_particles, ogP, list(REF_SM), rng=None, grid_cls=pkg.OccupancyGrid,
+                                 matcher_cls=pkg.ScanMatcher)
+    for count, raw in enumerate(intel_readings[:n_scans], start=1):
+        pf.updateParticles(raw, count)
+        np.testing.assert_allclose(np.array([p.weight for p in pf.particles], dtype=np.float64),
+                                   z["raw_weights"][count - 1], rtol=RTOL)
+        unb = pf.weightUnbalanced()
+        np.testing.assert_allclose(np.array([p.weight for p in pf.particles], dtype=np.float64),
+                                   z["weights"][count - 1], rtol=RTOL)
+        got = np.array([[p.prevMatchedReading[k] for k in ("x", "y", "theta")] for p in pf.particles])
+        assert np.array_equal(got, z["matched"][count - 1])
+        if unb or count in z["force_resample"]:
+            draw = pf.resample()
+            want = z["resamples"][[r[0] == count for r in z["resamples"]]][0][1:]
+            assert np.array_equal(draw, want)
+            assert pf.particles[0].sm.og is pf.particles[0].og          # alias survives deepcopy
+
+
+def test_batched_filter_matches_reference(pkg, intel_readings):
+    """The batched ParticleFilter (all particles in one launch set) against the golden
+    FastSLAM run: same uniforms from the seeded legacy stream, matched poses identical,
+    weights / variance within the bar, resample draws identical, final maps identical."""
+    import hashlib
+    z = load_golden("flow_fastslam.npz")
+    n_particles, n_scans, seed, map_m = (int(v) for v in z["cfg"])
+    u = 0.02
+    ogP = [map_m, map_m, intel_readings[0], u, np.pi, 10, 180, 5 * u]
+    rng = np.random.RandomState(seed)
+    pf = pkg.ParticleFilter(n_particles, ogP, list(REF_SM), rng=rng)
+    resamples = []
+    for count, raw in enumerate(intel_readings[:n_scans], start=1):
+        pf.updateParticles(raw, count)
+        unb = pf.weightUnbalanced()
+        assert unb == bool(z["unbalanced"][count - 1])
+        np.testing.assert_allclose(pf.weights, z["weights"][count - 1], rtol=RTOL)
+        np.testing.assert_allclose(pf.last_variance, z["variance"][count - 1], rtol=RTOL, atol=1e-12)
+        assert np.array_equal(pf.prev_matched, z["matched"][count - 1]), f"scan {count}"
+        if unb or count in z["force_resample"]:
+            resamples.append(np.concatenate(([count], pf.resample())))
+    assert np.array_equal(np.array(resamples), z["resamples"])
+    for p, sha in zip(pf.particles, z["maps_sha"]):
+        packed = codec.pack_counts(p.og.occupancyGridVisited, p.og.occupancyGridTotal)
+        assert hashlib.sha256(packed.tobytes()).digest() == sha.tobytes()
+
+
+@pytest.mark.parametrize("name", ["synth_cfg2.npz", "synth_cfg5s.npz"])
+def test_synthetic_shapes(pkg, name):
+    """BASELINE config-2 shape (field 801^2, cube 36x41x41, 180 beams) and the reduced
+    config-5 shape (1081 beams over 1.5 pi)."""
+    synth = importlib.import_module("slam-2d-lidar-scan_amd.synth")
+    z = load_golden(name)
+    size_m, unit, R, fov, beams, sr, sh, sigma, miss, dist, psi, wall_cells = z["cfg"]
+    world = synth.make_world(size_m, unit, seed=int(z["world_seed"]), wall_cells=int(wall_cells))
+    og = pkg.OccupancyGrid(size_m, size_m, {"x": 0.0, "y": 0.0}, unit, fov, int(beams), R, 5 * unit)
+    og.set_counts(*synth.counts_from_world(world))
+    sm = pkg.ScanMatcher(og, sr, sh, sigma, 0.1, 0.25, 0.3, miss, 1)
+    ex, ey, eth = z["est"]
+    xr, yr, prob = sm.frameSearchSpace(ex, ey, unit, sigma, miss)
+    want = codec.decode_field(z["prob_cls"], z["prob_floor"], z["prob_other"])
+    assert og.map.growth_log == []
+    assert np.array_equal(prob, want.astype(np.float32).astype(np.float64))
+    _, _, matched, cube, conf = sm.searchToMatch(want, ex, ey, eth, z["ranges"], xr, yr, sr, sh, unit, dist,
+                                                 codec.none_if_nan(psi), fineSearch=False, matchMax=True)
+    assert tuple(cube.shape) == tuple(z["cube_shape"])
+    assert int(sm.last["adhoc"]["argmax"]) == int(z["pick"])
+    np.testing.assert_allclose(conf, z["conf"], rtol=RTOL)
+    np.testing.assert_allclose(float(sm.last["adhoc"]["log_confidence"]), np.log(z["conf"]), rtol=1e-9)
+    if "cube" in z.files:
+        np.testing.assert_allclose(cube, z["cube"], rtol=RTOL_TIGHT)
+    else:
+        np.testing.assert_allclose(cube[::4, ::2, ::2], z["cube_sub"], rtol=RTOL_TIGHT)
+    assert [matched["x"], matched["y"], matched["theta"]] == list(z["matched"])
+
+
+def test_softmax_draw_matches_numpy(pkg):
+    """matchMax=False: the index drawn for a given uniform equals
+    cdf.searchsorted(u, 'right') on the reference's cube (np.random.choice semantics)."""
+    z = load_golden("levels.npz")
+    fpre, pre = "s40_coarse_field_", "s40_coarse_sweep_"
+    prob = codec.decode_field(z[fpre + "prob_cls"], z[fpre + "prob_floor"], z[fpre + "prob_other"])
+    og = pkg.OccupancyGrid(1, 1, {"x": 0.0, "y": 0.0}, 0.02, np.pi, 180, 10, 0.1)
+    sm = pkg.ScanMatcher(og, *REF_SM)
+    ex, ey, eth = z[pre + "est"]
+    radius, half, step, dist, psi, fine, mm = z[pre + "args"]
+    flat = z[pre + "cube"].reshape(-1)
+    p = np.exp(flat) / np.exp(flat).sum()
+    cdf = np.cumsum(p); cdf /= cdf[-1]
+    for seed in range(6):
+        np.random.seed(seed)
+        u = np.random.RandomState(seed).random_sample()
+        sm.searchToMatch(prob, ex, ey, eth, z[pre + "ranges"], z[pre + "xr"], z[pre + "yr"], radius, half, step,
+                         dist, codec.none_if_nan(psi), fineSearch=False, matchMax=False)
+        want = int(cdf.searchsorted(u, side="right"))
+        assert int(sm.last["adhoc"]["pick"]) == want, f"seed {seed}"
+
+
+def test_weights_kernel(pkg):
+    import torch
+    from importlib import import_module
+    flt = import_module("slam-2d-lidar-scan_amd.filter")
+    rs = np.random.RandomState(5)
+    for n in (1, 4, 64, 1000):
+        logw = rs.uniform(-300, -5, n)
+        logc = rs.uniform(-200, 1, n)
+        d_lw = torch.from_numpy(logw.copy()).cuda()
+        d_lc = torch.from_numpy(logc).cuda()
+        d_w = torch.zeros(n, dtype=torch.float64, device="cuda")
+        d_s = torch.zeros(2, dtype=torch.float64, device="cuda")
+        L = flt._lib.lib()
+        flt._lib.check(L.slam2d_weights_normalize(flt._ptr(d_lw), flt._ptr(d_lc), n, flt._ptr(d_w), flt._ptr(d_s),
+                                                   flt._stream()), "weights")
+        s = logw + logc
+        w = np.exp(s - s.max()); w /= w.sum()
+        np.testing.assert_allclose(d_w.cpu().numpy(), w, rtol=1e-12)
+        np.testing.assert_allclose(d_s[0].item(), ((w - 1 / n) ** 2).sum(), rtol=1e-9, atol=1e-15)
+        np.testing.assert_allclose(np.exp(d_lw.cpu().numpy()), w, rtol=1e-10)
+
+
+def test_large_synthetic_properties(pkg):
+    """Size-independent properties at BASELINE config-2 size with 8 particles: identical
+    particles give identical results (batch determinism), the update kernel touches each
+    window cell at most once (counts rise by exactly the number of owning beams' hits),
+    and a second identical update doubles the increments (linearity of the counts)."""
+    synth = importlib.import_module("slam-2d-lidar-scan_amd.synth")
+    eng_mod = importlib.import_module("slam-2d-lidar-scan_amd.engine")
+    unit, R, fov, beams, size_m = 0.1, 34.5, np.pi, 180, 90
+    world = synth.make_world(size_m, unit, seed=0)
+    origin = (-size_m / 2, -size_m / 2)
+    rs = np.random.RandomState(1)
+    pose = synth.free_pose_near(world, unit, origin, rs, spread=1.5)
+    pose = (origin[0] + unit * round((pose[0] - origin[0]) / unit), origin[1] + unit * round((pose[1] - origin[1]) / unit), pose[2])
+    ranges = synth.raycast(world, unit, origin, pose, fov, beams, R)
+    P = 8
+    ogP = [size_m, size_m, {"x": 0.0, "y": 0.0}, unit, fov, R, beams, 5 * unit]
+    smP = [2.05, 0.30, 2, 0.1, 0.25, 0.3, 0.15, 1]
+    pf = pkg.ParticleFilter(P, ogP, smP, growable=False, rng=np.random.RandomState(0))
+    v, t = synth.counts_from_world(world)
+    for m in pf.engine.maps:
+        m.upload(v, t)
+    eng = pf.engine
+    est = np.tile([pose[0] + 0.2, pose[1] - 0.1, pose[2] + 0.03], (P, 1))
+    d_est, d_rng = eng.to_device(est), eng.to_device(ranges)
+    eng.field_build(pf.coarse, d_est, 3)
+    eng.sweep(pf.coarse, d_est, 3, d_rng, 0.3, None, None, pf.m_coarse)
+    eng.take_flags()
+    m = eng.read_matches(pf.m_coarse)
+    assert len(set(m["pick"].tolist())) == 1 and len(set(m["confidence"].tolist())) == 1
+    cubes = pf.coarse.t["cube"].cpu().numpy()
+    assert all(np.array_equal(cubes[0], cubes[i]) for i in range(1, P))
+    # oracle on the same inputs (one particle)
+    ogo = so.GridOracle(size_m, size_m, {"x": 0.0, "y": 0.0}, unit, fov, beams, R, 5 * unit)
+    ogo.visited[:], ogo.total[:] = v, t
+    smo = so.MatcherOracle(ogo, *smP)
+    xr, yr, prob = smo.frameSearchSpace(est[0, 0], est[0, 1], unit, 2, 0.15)
+    _, cube_o, conf_o = smo.searchToMatch(prob, est[0, 0], est[0, 1], est[0, 2], ranges, xr, yr, 2.05, 0.30, unit,
+                                          0.3, None, fineSearch=False, matchMax=True)
+    assert int(m["argmax"][0]) == int(cube_o.argmax())
+    np.testing.assert_allclose(cubes[0].reshape(cube_o.shape), cube_o, rtol=RTOL_TIGHT)
+    np.testing.assert_allclose(m["log_confidence"][0], np.log(conf_o), rtol=1e-7)
+    # update: linearity + oracle
+    d_pose = eng.to_device(np.tile(pose, (P, 1)))
+    eng.grid_update(d_pose, 3, d_rng)
+    eng.take_flags()
+    v1, t1 = pf.engine.maps[3].download()
+    ogo.update_cell_major({"x": pose[0], "y": pose[1], "theta": pose[2], "range": ranges})
+    assert np.array_equal(v1, ogo.visited) and np.array_equal(t1, ogo.total)
+    eng.grid_update(d_pose, 3, d_rng)
+    eng.take_flags()
+    v2, t2 = pf.engine.maps[3].download()
+    assert np.array_equal(v2 - v1, v1 - v) and np.array_equal(t2 - t1, t1 - t)
