@@ -286,7 +286,7 @@ def main():
             "value": total_units / elapsed, "unit": "particle-scans/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 field / f64 accumulate / u32 packed counts", "data": "synthetic",
+            "dtype": "u32 fixed-point field, u64 exact accumulate, f64 priors/scores, u32 packed counts", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {cfg['note']}", "particles_per_gpu": P,
                        "total_particles": P * world, "pose_hypotheses_per_particle_scan":
                        hot.coarse.ntheta * hot.coarse.nx ** 2 + (hot.fine.ntheta * hot.fine.nx ** 2 if hot.fine else 0),

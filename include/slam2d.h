@@ -24,6 +24,14 @@
  *     access is skipped, never performed out of bounds.
  *   - row-major everywhere; images are [rows = y][cols = x].
  *
+ * Search field format (Slam2dLevel.field, one uint32 per field cell): the reference's
+ *   probSP (Utils/ScanMatcher_OGBased.py:41-45) holds values in [probMin, 0]; the field
+ *   stores the non-negative fixed-point COST  c = rint(-probSP * cost_scale),
+ *   cost_scale = 2^k chosen per level so that -probMin * 2^k < 2^32 (k = 31 for the
+ *   reference's parameters: resolution 4.7e-10, ~30x finer than float32 at the same
+ *   4 bytes).  Pose scores are then exact integer sums (uint64), so they do not depend
+ *   on summation order and exact ties of the reference stay exact ties.
+ *
  * Cell format of a particle's map (one uint32 per cell):
  *     bits 31..16 = occupancyGridVisited count, bits 15..0 = occupancyGridTotal count
  *   (reference: two float64 arrays initialised to 1 and 2, Utils/OccupancyGrid.py:13-14;
@@ -102,6 +110,14 @@ typedef struct {
     unsigned long long min_bits; /* scratch: order-preserving bits of the running minimum */
 } Slam2dFrame;
 
+/* Reduction of the 64*R consecutive cube entries one wave of the sweep scored. */
+typedef struct {
+    double  max;             /* largest score of the chunk (NaN if the chunk holds a NaN) */
+    double  sumexp;          /* sum exp(score - max) over the chunk */
+    int32_t argmax;          /* flat cube index of max (lowest on ties; first NaN if any) */
+    int32_t has_nan;
+} Slam2dPartial;
+
 /* One search level (coarse or fine) for P particles: parameters + workspaces.
  * Reference: the two halves of ScanMatcher.matchScan,
  * Utils/ScanMatcher_OGBased.py:53-60 (coarse) and :65-73 (fine). */
@@ -111,6 +127,7 @@ typedef struct {
     double reach;            /* 1.1*lidarMaxRange + searchRadius (ctor value, both levels) */
     double log_miss;         /* log(missMatchProb) of this level */
     double floor_value;      /* analytic field minimum: blur of an all-free neighbourhood */
+    double cost_scale;       /* 2^k: field stores rint(-probSP * cost_scale) as uint32 */
     int32_t blur_radius;     /* int(4*sigma + 0.5) */
     int32_t fmax;            /* max field rows/cols over particles: int(2*reach/step) + 2 */
     int32_t fpitch;          /* row pitch (elements) of field / occ images, >= fmax */
@@ -132,11 +149,14 @@ typedef struct {
     int32_t* axis_x;         /* [P][wmax] field column of every window map column */
     int32_t* axis_y;         /* [P][wmax] */
     uint8_t* occ;            /* [P][fmax][fpitch] */
-    float*   field;          /* [P][fmax][fpitch]  probSP, float32 */
+    uint32_t* field;         /* [P][fmax][fpitch]  fixed-point cost of probSP (see above) */
     int32_t* cells;          /* [P][ntheta][kmax] unique endpoint cells (patch-corner offsets) */
     int32_t* kcount;         /* [P][ntheta] */
     double*  prior;          /* [P][2][ny][nx]  rv plane, thetaWeight plane */
     double*  cube;           /* [P][ntheta][ny][nx] convTotal */
+    Slam2dPartial* partials; /* [P][npartial] per-wave reductions of the cube (sweep -> select) */
+    int32_t npartial;        /* capacity per particle: ntheta * ceil(ny*nx / 64) */
+    int32_t _pad;
 } Slam2dLevel;
 
 /* Result of one level for one particle. */
@@ -175,7 +195,7 @@ int slam2d_field_build(const Slam2dLidar* lidar, const Slam2dLevel* level, const
  *                                (NULL: None for every particle; ignored when level->fine)
  *   d_uniform[P]               = one uniform in [0,1) per particle for the soft-max draw
  *                                (matchMax=False, :136-139); NULL selects argmax (matchMax=True)
- * Writes level->cube[p] (convTotal) and d_out[p]. */
+ * Writes level->cube[p] (convTotal), level->partials[p] and d_out[p]. */
 int slam2d_sweep(const Slam2dLidar* lidar, const Slam2dLevel* level, int32_t P,
                  const double* d_est, int32_t est_stride, const double* d_ranges,
                  double est_moving_dist, const double* d_psi_cs, const double* d_uniform,

@@ -64,15 +64,21 @@ class Slam2dFrame(C.Structure):
                 ("min_bits", C.c_uint64)]
 
 
+class Slam2dPartial(C.Structure):
+    _fields_ = [("max", C.c_double), ("sumexp", C.c_double), ("argmax", C.c_int32), ("has_nan", C.c_int32)]
+
+
 class Slam2dLevel(C.Structure):
     _fields_ = [("step", C.c_double), ("reach", C.c_double), ("log_miss", C.c_double), ("floor_value", C.c_double),
+                ("cost_scale", C.c_double),
                 ("blur_radius", C.c_int32), ("fmax", C.c_int32), ("fpitch", C.c_int32), ("wmax", C.c_int32),
                 ("blur_w", _vp),
                 ("ncell", C.c_int32), ("ntheta", C.c_int32), ("fine", C.c_int32), ("kmax", C.c_int32),
                 ("thetas", _vp), ("theta_cos", _vp), ("theta_sin", _vp),
                 ("rv_coef", C.c_double), ("tw_coef", C.c_double), ("max_move_dev", C.c_double),
                 ("frames", _vp), ("axis_x", _vp), ("axis_y", _vp), ("occ", _vp), ("field", _vp),
-                ("cells", _vp), ("kcount", _vp), ("prior", _vp), ("cube", _vp)]
+                ("cells", _vp), ("kcount", _vp), ("prior", _vp), ("cube", _vp),
+                ("partials", _vp), ("npartial", C.c_int32), ("_pad", C.c_int32)]
 
 
 class Slam2dMatch(C.Structure):
@@ -82,7 +88,7 @@ class Slam2dMatch(C.Structure):
 
 
 STRUCTS = {"Slam2dMap": Slam2dMap, "Slam2dLidar": Slam2dLidar, "Slam2dFrame": Slam2dFrame,
-           "Slam2dLevel": Slam2dLevel, "Slam2dMatch": Slam2dMatch}
+           "Slam2dLevel": Slam2dLevel, "Slam2dMatch": Slam2dMatch, "Slam2dPartial": Slam2dPartial}
 
 # name -> (restype, argtypes); every symbol include/slam2d.h declares
 SIGNATURES = {

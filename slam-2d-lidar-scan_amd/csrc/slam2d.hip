@@ -36,7 +36,7 @@ unsigned g_prof_mask = 0;
 struct StageScope {
     int stage; hipStream_t s; int slot = -1;
     StageScope(int st, hipStream_t stream) : stage(st), s(stream) {
-        if ((g_prof_mask >> st) & 1u) {
+        if (st >= 0 && ((g_prof_mask >> st) & 1u)) {
             StageProf& p = g_prof[st];
             if (p.used < p.capacity) { slot = p.used++; (void)hipEventRecord(p.start[slot], s); }
         }
@@ -135,21 +135,28 @@ __global__ void k_axis_index(Slam2dLevel lv, const Slam2dMap* __restrict__ maps,
 __global__ __launch_bounds__(256) void k_occ_scatter(Slam2dLevel lv, const Slam2dMap* __restrict__ maps) {
     const int p = blockIdx.z;
     const Slam2dFrame fr = lv.frames[p];
-    const int j = blockIdx.x * 64 + threadIdx.x;
-    if (j >= fr.mx1 - fr.mx0) return;
+    // one thread = 4 consecutive map columns (one 16-byte load; rows are 64-byte aligned)
+    const int col0 = (fr.mx0 & ~3) + 4 * (blockIdx.x * 64 + threadIdx.x);
+    if (col0 >= fr.mx1) return;
     const Slam2dMap m = maps[p];
-    const int fx = lv.axis_x[(size_t)p * lv.wmax + j];
     uint8_t* occ = lv.occ + (size_t)p * lv.fmax * lv.fpitch;
+    const int32_t* __restrict__ ax = lv.axis_x + (size_t)p * lv.wmax;
+    const int32_t* __restrict__ ay = lv.axis_y + (size_t)p * lv.wmax;
     const int i0 = blockIdx.y * SCATTER_ROWS + threadIdx.y;
     const int nrow = fr.my1 - fr.my0;
 #pragma unroll
     for (int rr = 0; rr < SCATTER_ROWS / 4; ++rr) {
         const int i = i0 + rr * 4;
         if (i >= nrow) break;
-        const uint32_t c = m.cells[(size_t)(fr.my0 + i) * m.pitch + fr.mx0 + j];
-        if (2u * (c >> 16) > (c & 0xffffu)) {
-            const int fy = lv.axis_y[(size_t)p * lv.wmax + i];
-            if (fx >= 0 && fy >= 0) occ[(size_t)fy * lv.fpitch + fx] = 1;
+        const uint4 c4 = *reinterpret_cast<const uint4*>(m.cells + (size_t)(fr.my0 + i) * m.pitch + col0);
+        const uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int col = col0 + e;
+            if (col >= fr.mx0 && col < fr.mx1 && 2u * (c[e] >> 16) > (c[e] & 0xffffu)) {       // :29-31
+                const int fx = ax[col - fr.mx0], fy = ay[i];
+                if (fx >= 0 && fy >= 0) occ[(size_t)fy * lv.fpitch + fx] = 1;
+            }
         }
     }
 }
@@ -164,6 +171,11 @@ __global__ __launch_bounds__(256) void k_occ_scatter(Slam2dLevel lv, const Slam2
 // ------------------------------------------------------------------------------------
 #define BLUR_TILE 32
 #define BLUR_EXT (BLUR_TILE + 2 * SLAM2D_MAX_BLUR_RADIUS)
+// RAD > 0: radius known at compile time (register sliding windows, fully unrolled);
+// RAD == 0: any radius up to SLAM2D_MAX_BLUR_RADIUS (loops over LDS).
+// A tile whose halo holds no occupied cell is all "free": every value equals the analytic
+// floor bit for bit, so it is filled without arithmetic.
+template <int RAD>
 __global__ __launch_bounds__(256) void k_blur_clamp(Slam2dLevel lv, int mode) {
     const int p = blockIdx.z;
     const Slam2dFrame fr = lv.frames[p];
@@ -171,47 +183,96 @@ __global__ __launch_bounds__(256) void k_blur_clamp(Slam2dLevel lv, int mode) {
     const int fh = fr.fh, fw = fr.fw;
     const int ty0 = blockIdx.y * BLUR_TILE, tx0 = blockIdx.x * BLUR_TILE;
     if (ty0 >= fh || tx0 >= fw) return;
-    const int r = lv.blur_radius;
+    const int r = RAD > 0 ? RAD : lv.blur_radius;
     const int ext = BLUR_TILE + 2 * r;
     const int tid = threadIdx.x;
 
-    __shared__ double w_s[2 * SLAM2D_MAX_BLUR_RADIUS + 1];
     __shared__ uint8_t occ_s[BLUR_EXT][BLUR_EXT + 4];
     __shared__ double mid_s[BLUR_TILE][BLUR_EXT + 1];
     __shared__ double red_s[4];
 
-    if (tid < 2 * r + 1) w_s[tid] = lv.blur_w[tid];
     const uint8_t* occ = lv.occ + (size_t)p * lv.fmax * lv.fpitch;
+    int any = 0;
     for (int idx = tid; idx < ext * ext; idx += 256) {
         const int ly = idx / ext, lx = idx - ly * ext;
         const int gy = reflect_index(ty0 - r + ly, fh), gx = reflect_index(tx0 - r + lx, fw);
-        occ_s[ly][lx] = occ[(size_t)gy * lv.fpitch + gx];
+        const uint8_t o = occ[(size_t)gy * lv.fpitch + gx];
+        occ_s[ly][lx] = o;
+        any |= o;
     }
-    __syncthreads();
+    any = __syncthreads_or(any);
     const double L = lv.log_miss;
-    // axis-0 pass: out = a[c]*w[c]; for j=-r..-1: out += (a[c+j] + a[c-j]) * w[j]
-    for (int idx = tid; idx < BLUR_TILE * ext; idx += 256) {
-        const int y = idx / ext, lx = idx - y * ext;
-        double acc = (occ_s[y + r][lx] ? 0.0 : L) * w_s[r];
-        for (int j = -r; j < 0; ++j) {
-            const double a = occ_s[y + r + j][lx] ? 0.0 : L;
-            const double b = occ_s[y + r - j][lx] ? 0.0 : L;
-            acc = acc + (a + b) * w_s[r + j];
+    const double fmin_used = mode == 1 ? fr.field_min : lv.floor_value;
+    const double thr = 0.5 * fmin_used;                                            // :44
+    uint32_t* field = lv.field + (size_t)p * lv.fmax * lv.fpitch;
+    const double* __restrict__ w = lv.blur_w;
+    if (!any) {
+        const double v = lv.floor_value;
+        const uint32_t c = v > thr ? 0u : (uint32_t)rint(-v * lv.cost_scale);
+        for (int idx = tid; idx < BLUR_TILE * BLUR_TILE; idx += 256) {
+            const int y = idx / BLUR_TILE, x = idx - y * BLUR_TILE;
+            if (ty0 + y < fh && tx0 + x < fw) field[(size_t)(ty0 + y) * lv.fpitch + tx0 + x] = c;
         }
-        mid_s[y][lx] = acc;
+        if (mode == 0 && tid == 0) atomicMin(&lv.frames[p].min_bits, order_bits(v));
+        return;
     }
-    __syncthreads();
-    const double thr = 0.5 * (mode == 1 ? fr.field_min : lv.floor_value);
-    float* field = lv.field + (size_t)p * lv.fmax * lv.fpitch;
     double lmin = INFINITY;
-    for (int idx = tid; idx < BLUR_TILE * BLUR_TILE; idx += 256) {
-        const int y = idx / BLUR_TILE, x = idx - y * BLUR_TILE;
-        double acc = mid_s[y][x + r] * w_s[r];
-        for (int j = -r; j < 0; ++j) acc = acc + (mid_s[y][x + r + j] + mid_s[y][x + r - j]) * w_s[r + j];
-        const int gy = ty0 + y, gx = tx0 + x;
-        if (gy < fh && gx < fw) {
-            lmin = fmin(lmin, acc);
-            field[(size_t)gy * lv.fpitch + gx] = acc > thr ? 0.0f : (float)acc;   // :44
+    // SciPy symmetric correlate1d order: out = a[c]*w[c]; for j=-r..-1: out += (a[c+j] + a[c-j]) * w[j]
+    if constexpr (RAD > 0) {
+        {   // axis-0 pass: thread = (column lx, 8 consecutive rows)
+            const int lx = tid & 63, g = tid >> 6;
+            if (lx < ext) {
+                double f[8 + 2 * RAD];
+#pragma unroll
+                for (int k = 0; k < 8 + 2 * RAD; ++k) f[k] = occ_s[g * 8 + k][lx] ? 0.0 : L;
+#pragma unroll
+                for (int o = 0; o < 8; ++o) {
+                    double acc = f[o + RAD] * w[RAD];
+#pragma unroll
+                    for (int j = -RAD; j < 0; ++j) acc = acc + (f[o + RAD + j] + f[o + RAD - j]) * w[RAD + j];
+                    mid_s[g * 8 + o][lx] = acc;
+                }
+            }
+        }
+        __syncthreads();
+        {   // axis-1 pass: thread = (row y, 4 consecutive columns)
+            const int y = tid >> 3, x0 = (tid & 7) * 4;
+            double mrow[4 + 2 * RAD];
+#pragma unroll
+            for (int k = 0; k < 4 + 2 * RAD; ++k) mrow[k] = mid_s[y][x0 + k];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                double acc = mrow[o + RAD] * w[RAD];
+#pragma unroll
+                for (int j = -RAD; j < 0; ++j) acc = acc + (mrow[o + RAD + j] + mrow[o + RAD - j]) * w[RAD + j];
+                const int gy = ty0 + y, gx = tx0 + x0 + o;
+                if (gy < fh && gx < fw) {
+                    lmin = fmin(lmin, acc);
+                    field[(size_t)gy * lv.fpitch + gx] = acc > thr ? 0u : (uint32_t)rint(-acc * lv.cost_scale);
+                }
+            }
+        }
+    } else {
+        for (int idx = tid; idx < BLUR_TILE * ext; idx += 256) {
+            const int y = idx / ext, lx = idx - y * ext;
+            double acc = (occ_s[y + r][lx] ? 0.0 : L) * w[r];
+            for (int j = -r; j < 0; ++j) {
+                const double a = occ_s[y + r + j][lx] ? 0.0 : L;
+                const double b = occ_s[y + r - j][lx] ? 0.0 : L;
+                acc = acc + (a + b) * w[r + j];
+            }
+            mid_s[y][lx] = acc;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < BLUR_TILE * BLUR_TILE; idx += 256) {
+            const int y = idx / BLUR_TILE, x = idx - y * BLUR_TILE;
+            double acc = mid_s[y][x + r] * w[r];
+            for (int j = -r; j < 0; ++j) acc = acc + (mid_s[y][x + r + j] + mid_s[y][x + r - j]) * w[r + j];
+            const int gy = ty0 + y, gx = tx0 + x;
+            if (gy < fh && gx < fw) {
+                lmin = fmin(lmin, acc);
+                field[(size_t)gy * lv.fpitch + gx] = acc > thr ? 0u : (uint32_t)rint(-acc * lv.cost_scale);
+            }
         }
     }
     if (mode == 0) {
@@ -362,6 +423,27 @@ __global__ void k_priors(Slam2dLevel lv, double est_dist, const double* __restri
 //      Blocks of one particle are pinned to one XCD (block b runs on XCD b % 8) so that
 //      particle's field stays in that XCD's 4 MiB L2 while its cube is swept.
 // ------------------------------------------------------------------------------------
+struct Best { double v; int i; int nan; };
+__device__ __forceinline__ bool better(const Best& a, const Best& b) {
+    // np.argmax semantics: first NaN wins; otherwise the largest value, lowest index on ties
+    if (a.nan != b.nan) return a.nan > b.nan;
+    if (a.nan) return a.i < b.i;
+    return a.v > b.v || (a.v == b.v && a.i < b.i);
+}
+__device__ __forceinline__ Best wave_best(Best me) {
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        Best ot{__shfl_xor(me.v, o), __shfl_xor(me.i, o), __shfl_xor(me.nan, o)};
+        if (better(ot, me)) me = ot;
+    }
+    return me;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) v += __shfl_xor(v, o);      // fixed butterfly: deterministic
+    return v;
+}
+
 template <int R>
 __global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks, int bpp) {
     const int b = blockIdx.x;
@@ -374,7 +456,7 @@ __global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks
     if (w >= lv.ntheta * chunks) return;
     const int it = w / chunks, ch = w - it * chunks;
     const int nx = 2 * lv.ncell + 1, npose = nx * nx;
-    const float* __restrict__ F = lv.field + (size_t)p * lv.fmax * lv.fpitch;
+    const uint32_t* __restrict__ F = lv.field + (size_t)p * lv.fmax * lv.fpitch;
     const int* __restrict__ cl = lv.cells + ((size_t)p * lv.ntheta + it) * lv.kmax;
     const int K = lv.kcount[p * lv.ntheta + it];
     const int q0 = ch * (WAVE * R) + lane;
@@ -382,112 +464,148 @@ __global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks
     // over k) + wave-uniform SGPR byte offset (the cell) -- no vector address arithmetic in
     // the loop, and out-of-range offsets read 0 instead of faulting.
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)F, (short)0, (int)((size_t)lv.fmax * lv.fpitch * sizeof(float)), 0x00020000);
+        (void*)F, (short)0, (int)((size_t)lv.fmax * lv.fpitch * sizeof(uint32_t)), 0x00020000);
     int off[R];
-    double acc[R];
+    unsigned long long acc[R];           // exact integer sum of fixed-point costs
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int q = q0 + r * WAVE;
         const int qq = q < npose ? q : 0;
         const int iy = qq / nx;
         off[r] = (iy * lv.fpitch + (qq - iy * nx)) * 4;
-        acc[r] = 0.0;
+        acc[r] = 0ull;
     }
 #pragma unroll 4
     for (int k = 0; k < K; ++k) {
         const int cell = cl[k] * 4;
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            acc[r] += (double)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off[r], cell, 0));
+            acc[r] += (unsigned long long)(unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsrc, off[r], cell, 0);
     }
     const double* __restrict__ pr = lv.prior + (size_t)p * 2 * npose;
     double* __restrict__ out = lv.cube + ((size_t)p * lv.ntheta + it) * npose;
+    const double inv = 1.0 / lv.cost_scale;
+    double sc[R];
+    Best me{-INFINITY, INT_MAX, 0};
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int q = q0 + r * WAVE;
-        if (q < npose) out[q] = (acc[r] + pr[q]) + pr[npose + q];                  // :131
+        sc[r] = -INFINITY;
+        if (q < npose) {
+            const double sum = -((double)acc[r] * inv);                            // sum of probSP values
+            sc[r] = (sum + pr[q]) + pr[npose + q];                                 // :131
+            out[q] = sc[r];
+            Best cand{sc[r], it * npose + q, isnan(sc[r]) ? 1 : 0};
+            if (better(cand, me)) me = cand;
+        }
+    }
+    // per-wave reduction for k_select: max / argmax / sum exp(score - max)
+    me = wave_best(me);
+    double e = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (q0 + r * WAVE < npose) e += exp(sc[r] - me.v);
+    e = wave_sum(e);
+    if (lane == 0) {
+        Slam2dPartial pt;
+        pt.max = me.v; pt.sumexp = e; pt.argmax = me.i; pt.has_nan = me.nan;
+        lv.partials[(size_t)p * lv.npartial + w] = pt;
     }
 }
 
 // ------------------------------------------------------------------------------------
 // K1d  arg-max / soft-max draw / confidence / matched pose   (Utils/ScanMatcher_OGBased.py:133-143)
-//      one block per particle
+//      one wave per particle, working on the per-wave partials of the sweep
 // ------------------------------------------------------------------------------------
-struct Best { double v; int i; int nan; };
-__device__ __forceinline__ bool better(const Best& a, const Best& b) {
-    // np.argmax semantics: first NaN wins; otherwise the largest value, lowest index on ties
-    if (a.nan != b.nan) return a.nan > b.nan;
-    if (a.nan) return a.i < b.i;
-    return a.v > b.v || (a.v == b.v && a.i < b.i);
-}
-#define RED_T 512
-__global__ __launch_bounds__(RED_T) void k_select(Slam2dLevel lv, const double* __restrict__ est, int estride,
-                                                  const double* __restrict__ uniform, Slam2dMatch* out) {
-    __shared__ double sv[RED_T];
-    __shared__ int si[RED_T];
-    __shared__ int sn[RED_T];
-    __shared__ int pick_s;
-    const int p = blockIdx.x, tid = threadIdx.x;
-    const int nx = 2 * lv.ncell + 1, npose = nx * nx, N = lv.ntheta * npose;
-    const double* __restrict__ c = lv.cube + (size_t)p * N;
+__global__ __launch_bounds__(64) void k_select(Slam2dLevel lv, int chunks, int R, const double* __restrict__ est,
+                                               int estride, const double* __restrict__ uniform, Slam2dMatch* out) {
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int nx = 2 * lv.ncell + 1, npose = nx * nx;
+    const int nW = lv.ntheta * chunks;
+    const Slam2dPartial* __restrict__ pt = lv.partials + (size_t)p * lv.npartial;
+    const double* __restrict__ c = lv.cube + (size_t)p * lv.ntheta * npose;
+    // global max / argmax
     Best me{-INFINITY, INT_MAX, 0};
-    for (int i = tid; i < N; i += RED_T) {
-        const double v = c[i];
-        Best cand{v, i, isnan(v) ? 1 : 0};
+    for (int w = lane; w < nW; w += WAVE) {
+        Best cand{pt[w].max, pt[w].argmax, pt[w].has_nan};
         if (better(cand, me)) me = cand;
     }
-    sv[tid] = me.v; si[tid] = me.i; sn[tid] = me.nan;
-    __syncthreads();
-    for (int o = RED_T / 2; o > 0; o >>= 1) {
-        if (tid < o) {
-            Best a{sv[tid], si[tid], sn[tid]}, b{sv[tid + o], si[tid + o], sn[tid + o]};
-            if (better(b, a)) { sv[tid] = b.v; si[tid] = b.i; sn[tid] = b.nan; }
-        }
-        __syncthreads();
+    me = wave_best(me);
+    const double M = me.v;
+    // total = sum_w sumexp_w * exp(max_w - M): each lane owns a contiguous run of partials
+    const int per = (nW + WAVE - 1) / WAVE;
+    const int w0 = lane * per, w1 = min(nW, w0 + per);
+    double mine = 0.0;
+    for (int w = w0; w < w1; ++w) mine += pt[w].sumexp * exp(pt[w].max - M);
+    double incl = mine;                           // inclusive scan over lanes
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const double up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
     }
-    const double m = sv[0];
-    const int amax = si[0];
-    __syncthreads();
-    // sum exp(s - m) over contiguous chunks (fixed order => deterministic)
-    const int chunk = (N + RED_T - 1) / RED_T;
-    const int i0 = tid * chunk, i1 = min(N, i0 + chunk);
-    double part = 0.0;
-    for (int i = i0; i < i1; ++i) part += exp(c[i] - m);
-    sv[tid] = part;
-    __syncthreads();
-    if (tid == 0) {
-        double total = 0.0;
-        for (int t = 0; t < RED_T; ++t) total += sv[t];
-        int pick = amax;
-        if (uniform != nullptr && !isnan(total)) {
-            // np.random.choice(n, 1, p): cdf.searchsorted(u, 'right') on the normalised cdf (:137-138)
-            const double target = uniform[p] * total;
-            double run = 0.0;
-            int t = 0;
-            while (t < RED_T - 1 && run + sv[t] <= target) { run += sv[t]; ++t; }
-            pick = -1;
-            for (; t < RED_T && pick < 0; ++t) {
-                const int j0 = t * chunk, j1 = min(N, j0 + chunk);
-                for (int i = j0; i < j1; ++i) {
-                    run += exp(c[i] - m);
-                    if (run > target) { pick = i; break; }
-                }
-            }
-            if (pick < 0) pick = N - 1;
+    const double total = __shfl(incl, WAVE - 1);
+    int pick = me.i;
+    if (uniform != nullptr && !isnan(total)) {
+        // np.random.choice(n, 1, p): first index whose normalised cdf exceeds u (:137-138)
+        const double target = uniform[p] * total;
+        const unsigned long long ahead = __ballot(incl > target);
+        const int lsel = ahead ? __ffsll((long long)ahead) - 1 : WAVE - 1;
+        double run = __shfl(incl - mine, lsel);                   // cdf before lane lsel's partials
+        const int s0 = min(lsel * per, nW - 1), s1 = max(s0 + 1, min(nW, lsel * per + per));
+        int wsel = s1 - 1;
+        for (int w = s0; w < s1; ++w) {                           // wave-uniform loop
+            const double t = pt[w].sumexp * exp(pt[w].max - M);
+            if (run + t > target || w == s1 - 1) { wsel = w; break; }
+            run += t;
         }
-        Slam2dMatch r;
+        // inside chunk wsel: lane l owns entries [l*R, l*R+R) of its 64*R consecutive poses
+        const int it = wsel / chunks, ch = wsel - it * chunks;
+        const int qb = ch * WAVE * R + lane * R;
+        double ev[8];
+        double lsum = 0.0;
+        for (int r = 0; r < 8; ++r) {
+            const int q = qb + r;
+            ev[r] = (r < R && q < npose) ? exp(c[(size_t)it * npose + q] - M) : 0.0;
+            lsum += ev[r];
+        }
+        double linc = lsum;
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const double up = __shfl_up(linc, o);
+            if (lane >= o) linc += up;
+        }
+        const unsigned long long hit = __ballot(run + linc > target);
+        const int last_q = min(npose, (ch + 1) * WAVE * R) - 1;
+        pick = it * npose + last_q;                               // rounding fallback: chunk's last pose
+        if (hit) {
+            const int l2 = __ffsll((long long)hit) - 1;
+            double r2 = run + __shfl(linc - lsum, l2);
+            int found = -1;
+            if (lane == l2) {
+                for (int r = 0; r < 8; ++r) {
+                    if (r >= R) break;
+                    r2 += ev[r];
+                    if (r2 > target) { found = it * npose + qb + r; break; }
+                }
+                if (found < 0) found = it * npose + min(qb + R - 1, last_q);
+            }
+            pick = __shfl(found, l2);
+        }
+    }
+    if (lane == 0) {
+        Slam2dMatch m;
         const int it = pick / npose, rem = pick - it * npose;
         const int iy = rem / nx, ix = rem - iy * nx;
         const double ex = est[(size_t)p * estride], ey = est[(size_t)p * estride + 1], eth = est[(size_t)p * estride + 2];
-        r.x = ex + (double)(ix - lv.ncell) * lv.step;                               // :142-143
-        r.y = ey + (double)(iy - lv.ncell) * lv.step;
-        r.theta = eth + lv.thetas[it];
-        r.confidence = exp(m) * total;                                              // :141
-        r.log_confidence = m + log(total);
-        r.best_score = m;
-        r.pick = pick;
-        r.argmax = amax;
-        out[p] = r;
+        m.x = ex + (double)(ix - lv.ncell) * lv.step;                               // :142-143
+        m.y = ey + (double)(iy - lv.ncell) * lv.step;
+        m.theta = eth + lv.thetas[it];
+        m.confidence = exp(M) * total;                                              // :141
+        m.log_confidence = M + log(total);
+        m.best_score = M;
+        m.pick = pick;
+        m.argmax = me.i;
+        out[p] = m;
     }
 }
 
@@ -506,7 +624,7 @@ __global__ void k_update_axis(Slam2dLidar lid, const Slam2dMap* __restrict__ map
     axis[((size_t)p * 2 + a) * lid.lut_w + j] = (int)rint(((base + lid.lut_xs[j]) - lim0) / lid.unit);
 }
 
-#define UPD_ROWS 16
+#define UPD_ROWS 64
 __global__ __launch_bounds__(256) void k_grid_update(Slam2dLidar lid, const Slam2dMap* __restrict__ maps, int P,
                                                      const double* __restrict__ pose, int pstride,
                                                      const double* __restrict__ ranges,
@@ -639,6 +757,7 @@ int slam2d_sizeof(const char* name) {
     if (!strcmp(name, "Slam2dFrame")) return (int)sizeof(Slam2dFrame);
     if (!strcmp(name, "Slam2dLevel")) return (int)sizeof(Slam2dLevel);
     if (!strcmp(name, "Slam2dMatch")) return (int)sizeof(Slam2dMatch);
+    if (!strcmp(name, "Slam2dPartial")) return (int)sizeof(Slam2dPartial);
     return -1;
 }
 
@@ -653,6 +772,7 @@ static int check_level(const Slam2dLidar* lidar, const Slam2dLevel* lv, int P) {
     if (lv->blur_radius < 0 || lv->blur_radius > SLAM2D_MAX_BLUR_RADIUS) return SLAM2D_E_TOOLARGE;
     if (lidar->beams < 2 || lidar->beams > SLAM2D_MAX_BEAMS) return SLAM2D_E_TOOLARGE;
     if (lv->fmax <= 0 || lv->fpitch < lv->fmax || lv->wmax <= 0 || lv->ncell < 0 || lv->ntheta <= 0) return SLAM2D_E_BADARG;
+    if (!(lv->cost_scale > 0.0)) return SLAM2D_E_BADARG;
     if ((long long)lv->fmax * lv->fpitch >= (1ll << 31)) return SLAM2D_E_TOOLARGE;
     return 0;
 }
@@ -670,15 +790,20 @@ int slam2d_field_build(const Slam2dLidar* lidar, const Slam2dLevel* level, const
     if (e != hipSuccess) return (int)e;
     {
         StageScope prof(SLAM2D_STAGE_SCATTER, s);
-        k_occ_scatter<<<dim3(cdiv(lv.wmax, 64), cdiv(lv.wmax, SCATTER_ROWS), P), dim3(64, 4), 0, s>>>(lv, d_maps);
+        k_occ_scatter<<<dim3(cdiv(lv.wmax + 3, 256), cdiv(lv.wmax, SCATTER_ROWS), P), dim3(64, 4), 0, s>>>(lv, d_maps);
     }
     const dim3 bgrid(cdiv(lv.fmax, BLUR_TILE), cdiv(lv.fmax, BLUR_TILE), P);
-    {
-        StageScope prof(SLAM2D_STAGE_BLUR, s);
-        k_blur_clamp<<<bgrid, 256, 0, s>>>(lv, 0);
+    for (int mode = 0; mode < 2; ++mode) {
+        {
+            StageScope prof(mode == 0 ? SLAM2D_STAGE_BLUR : -1, s);
+            switch (lv.blur_radius) {
+                case 2: k_blur_clamp<2><<<bgrid, 256, 0, s>>>(lv, mode); break;
+                case 8: k_blur_clamp<8><<<bgrid, 256, 0, s>>>(lv, mode); break;
+                default: k_blur_clamp<0><<<bgrid, 256, 0, s>>>(lv, mode); break;
+            }
+        }
+        if (mode == 0) k_floor_check<<<cdiv(P, 64), 64, 0, s>>>(lv, P, d_flags);
     }
-    k_floor_check<<<cdiv(P, 64), 64, 0, s>>>(lv, P, d_flags);
-    k_blur_clamp<<<bgrid, 256, 0, s>>>(lv, 1);
     return launch_status();
 }
 
@@ -689,7 +814,7 @@ int slam2d_sweep(const Slam2dLidar* lidar, const Slam2dLevel* level, int32_t P, 
     if (rc) return rc;
     if (!d_est || !d_ranges || !d_out || !d_flags || est_stride < 3) return SLAM2D_E_BADARG;
     const Slam2dLevel& lv = *level;
-    if (lv.kmax < lidar->beams) return SLAM2D_E_BADARG;
+    if (lv.kmax < lidar->beams || !lv.partials) return SLAM2D_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     const int nx = 2 * lv.ncell + 1, npose = nx * nx;
     {
@@ -705,6 +830,7 @@ int slam2d_sweep(const Slam2dLidar* lidar, const Slam2dLevel* level, int32_t P, 
         if (waste <= bestWaste) { bestWaste = waste; bestR = R; }
     }
     const int chunks = cdiv(need, bestR);
+    if (lv.ntheta * chunks > lv.npartial) return SLAM2D_E_BADARG;
     {
         StageScope prof(SLAM2D_STAGE_SWEEP, s);
         switch (bestR) {
@@ -720,7 +846,7 @@ int slam2d_sweep(const Slam2dLidar* lidar, const Slam2dLevel* level, int32_t P, 
     }
     {
         StageScope prof(SLAM2D_STAGE_SELECT, s);
-        k_select<<<P, RED_T, 0, s>>>(lv, d_est, est_stride, d_uniform, d_out);
+        k_select<<<P, WAVE, 0, s>>>(lv, chunks, bestR, d_est, est_stride, d_uniform, d_out);
     }
     return launch_status();
 }

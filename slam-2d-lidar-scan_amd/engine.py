@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import Slam2dFrame, Slam2dLevel, Slam2dLidar, Slam2dMap, Slam2dMatch, check
+from ._lib import Slam2dFrame, Slam2dLevel, Slam2dLidar, Slam2dMap, Slam2dMatch, Slam2dPartial, check
 
 MATCH_DOUBLES = C.sizeof(Slam2dMatch) // 8      # stride of a Slam2dMatch array viewed as double*
 _MATCH_DTYPE = np.dtype([("x", "f8"), ("y", "f8"), ("theta", "f8"), ("confidence", "f8"),
@@ -76,6 +76,24 @@ def blurred_free_value(log_miss, taps, radius):
             acc = acc + (v + v) * taps[radius + j]
         return acc
     return float(one_pass(one_pass(L)))
+
+
+def cost_scale_for(min_value):
+    """2^k with -min_value * 2^k < 2^32 (k <= 31): the fixed-point scale of a search field
+    whose values lie in [min_value, 0] (include/slam2d.h, "Search field format")."""
+    m = abs(float(min_value))
+    if not m > 0.0 or math.isinf(m) or math.isnan(m):
+        return float(2 ** 31)
+    k = min(31, int(math.floor(math.log2(4294967295.0 / m))))
+    return float(2.0 ** k)
+
+
+def encode_cost(prob, scale):
+    """probSP (values in [min, 0]) -> uint32 fixed-point cost, as the blur kernel stores it."""
+    c = np.rint(-np.asarray(prob, dtype=np.float64) * scale)
+    if c.min() < 0 or c.max() > 4294967295:
+        raise ValueError("search field values must lie in [min, 0] with -min * scale < 2^32")
+    return c.astype(np.uint32)
 
 
 # ----------------------------------------------------------------------------
@@ -293,6 +311,7 @@ class SearchLevel:
             raise ValueError(f"blur radius {self.blur_radius} exceeds {_lib.MAX_BLUR_RADIUS}")
         self.log_miss = math.log(miss_prob)                                       # :25
         self.floor_value = blurred_free_value(self.log_miss, self.taps, self.blur_radius)
+        self.cost_scale = cost_scale_for(self.floor_value)
         self.ncell = int(radius / step)                                           # :94
         self.nx = 2 * self.ncell + 1
         self.thetas = np.arange(-half_rad, half_rad + lidar.angular_step, lidar.angular_step)   # :114
@@ -305,6 +324,7 @@ class SearchLevel:
         self.tw_coef = -1 / (2 * turn_sigma ** 2)                                 # :108
         self.max_move_dev = max_move_dev
         npose = self.nx * self.nx
+        self.npartial = self.ntheta * (-(-npose // 64))
         i32, f64 = torch.int32, torch.float64
         t = self.t = dict(
             blur_w=_dev(self.taps, device),
@@ -316,31 +336,46 @@ class SearchLevel:
             axis_x=torch.zeros((P, self.wmax), dtype=i32, device=device),
             axis_y=torch.zeros((P, self.wmax), dtype=i32, device=device),
             occ=torch.zeros((P, self.fmax, self.fpitch), dtype=torch.uint8, device=device),
-            field=torch.zeros((P, self.fmax, self.fpitch), dtype=torch.float32, device=device),
+            field=torch.zeros((P, self.fmax, self.fpitch), dtype=i32, device=device),     # uint32 costs
             cells=torch.zeros((P, self.ntheta, self.kmax), dtype=i32, device=device),
             kcount=torch.zeros((P, self.ntheta), dtype=i32, device=device),
             prior=torch.zeros((P, 2, npose), dtype=f64, device=device),
             cube=torch.zeros((P, self.ntheta, npose), dtype=f64, device=device),
+            partials=torch.zeros((P, self.npartial, C.sizeof(Slam2dPartial)), dtype=torch.uint8, device=device),
         )
         self.c = Slam2dLevel(
             step=step, reach=self.reach, log_miss=self.log_miss, floor_value=self.floor_value,
-            blur_radius=self.blur_radius, fmax=self.fmax, fpitch=self.fpitch, wmax=self.wmax,
+            cost_scale=self.cost_scale, blur_radius=self.blur_radius, fmax=self.fmax, fpitch=self.fpitch, wmax=self.wmax,
             blur_w=t["blur_w"].data_ptr(), ncell=self.ncell, ntheta=self.ntheta, fine=int(self.fine),
             kmax=self.kmax, thetas=t["thetas"].data_ptr(), theta_cos=t["cos"].data_ptr(),
             theta_sin=t["sin"].data_ptr(), rv_coef=self.rv_coef, tw_coef=self.tw_coef,
             max_move_dev=max_move_dev, frames=t["frames"].data_ptr(), axis_x=t["axis_x"].data_ptr(),
             axis_y=t["axis_y"].data_ptr(), occ=t["occ"].data_ptr(), field=t["field"].data_ptr(),
             cells=t["cells"].data_ptr(), kcount=t["kcount"].data_ptr(), prior=t["prior"].data_ptr(),
-            cube=t["cube"].data_ptr())
+            cube=t["cube"].data_ptr(), partials=t["partials"].data_ptr(), npartial=self.npartial, _pad=0)
 
     # -- results --
     def frames(self):
         return self.t["frames"].cpu().numpy().view(_FRAME_DTYPE).reshape(-1)
 
-    def field(self, p=0):
-        """probSP of particle p as a float64 host array [fh, fw] (float32 values)."""
+    def field_cost(self, p=0):
+        """Fixed-point cost image of particle p, uint32 [fh, fw]."""
         fr = self.frames()[p]
-        return self.t["field"][p, :fr["fh"], :fr["fw"]].cpu().numpy().astype(np.float64)
+        return self.t["field"][p, :fr["fh"], :fr["fw"]].cpu().numpy().view(np.uint32)
+
+    def field(self, p=0):
+        """probSP of particle p as a float64 host array [fh, fw] (= -cost / cost_scale)."""
+        return -(self.field_cost(p).astype(np.float64) / self.c.cost_scale)
+
+    def set_field(self, prob, p=0):
+        """Load a caller-supplied probSP for particle p (re-quantised at a scale fitted to it)."""
+        prob = np.asarray(prob, dtype=np.float64)
+        scale = cost_scale_for(prob.min())
+        cost = encode_cost(prob, scale)
+        self.c.cost_scale = scale
+        fh, fw = prob.shape
+        self.t["field"][p, :fh, :fw] = torch.from_numpy(cost.view(np.int32)).to(self.device)
+        return scale
 
     def cube(self, p=0):
         return self.t["cube"][p].cpu().numpy().reshape(self.ntheta, self.nx, self.nx)
@@ -353,11 +388,11 @@ class SearchLevel:
     def algorithmic_bytes(self, n_window_cells=None):
         """SURVEY.md 8(d) per particle-scan at this level: field build
         2*c*Wm^2 + 4*Fh*Fw (c = 2 bytes per count: packed uint32 cell holds both),
-        sweep 4*Fh*Fw + 8*B + 4*Ntheta*Ny*Nx (cube counted at 4 B as in the survey)."""
+        sweep 4*Fh*Fw + 8*B + 8*Ntheta*Ny*Nx (the cube is float64 here)."""
         wm = int(2 * self.reach / self.lidar.unit) if n_window_cells is None else n_window_cells
         f = (self.fmax - 1) ** 2
         field_build = 2 * 2 * wm * wm + 4 * f
-        sweep = 4 * f + 8 * self.lidar.beams + 4 * self.ntheta * self.nx * self.nx
+        sweep = 4 * f + 8 * self.lidar.beams + 8 * self.ntheta * self.nx * self.nx
         return dict(field_build=field_build, sweep=sweep)
 
 

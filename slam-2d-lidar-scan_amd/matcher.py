@@ -69,8 +69,8 @@ class ScanMatcher:
         return eng
 
     def frameSearchSpace(self, estimatedX, estimatedY, unitLength, sigma, missMatchProbAtCoarse):
-        """(:20-39)  Returns xRangeList, yRangeList, probSP (host float64 array holding the
-        float32 field)."""
+        """(:20-39)  Returns xRangeList, yRangeList, probSP (host float64 array decoded from
+        the device's fixed-point field: values exact to 2^-32 relative to probMin)."""
         level = self._level(unitLength, sigma, missMatchProbAtCoarse, self.searchRadius, self.searchHalfRad, False)
         eng = self.og.engine()
         d_c = eng.to_device([[estimatedX, estimatedY]])
@@ -109,14 +109,14 @@ class ScanMatcher:
     def searchToMatch(self, probSP, estimatedX, estimatedY, estimatedTheta, rMeasure, xRangeList, yRangeList,
                       searchRadius, searchHalfRad, unitLength, estMovingDist, estMovingTheta, fineSearch=False,
                       matchMax=True):
-        """(:91-151) on a caller-supplied field (uploaded as float32)."""
+        """(:91-151) on a caller-supplied field (re-quantised to the device's fixed-point format)."""
         rMeasure = np.asarray(rMeasure)
         level = self._level(unitLength, 1.0, 0.5, searchRadius, searchHalfRad, fineSearch)
         eng = self.og.engine()
         fh, fw = probSP.shape
         if fh > level.fmax or fw > level.fmax:
             raise ValueError("field larger than this matcher's search window")
-        level.t["field"][0, :fh, :fw] = torch.from_numpy(np.asarray(probSP, dtype=np.float32)).to(eng.device)
+        level.set_field(probSP, 0)
         fr = level.frames()
         fr[0]["xlo"], fr[0]["xhi"], fr[0]["ylo"], fr[0]["yhi"] = xRangeList[0], xRangeList[1], yRangeList[0], yRangeList[1]
         fr[0]["fh"], fr[0]["fw"] = fh, fw
