@@ -14,6 +14,7 @@
 #include <string.h>
 #include <math.h>
 #include <limits.h>
+#include <stdlib.h>
 
 #include "slam2d.h"
 
@@ -131,31 +132,42 @@ __global__ void k_axis_index(Slam2dLevel lv, const Slam2dMap* __restrict__ maps,
 // K2c  occupied map cells -> occupied field cells  (Utils/ScanMatcher_OGBased.py:29-37)
 //      HBM-bound: streams the map window once (4 B / map cell), byte scatter into occ.
 // ------------------------------------------------------------------------------------
-#define SCATTER_ROWS 16
+#define SCATTER_ROWS 32
 __global__ __launch_bounds__(256) void k_occ_scatter(Slam2dLevel lv, const Slam2dMap* __restrict__ maps) {
     const int p = blockIdx.z;
     const Slam2dFrame fr = lv.frames[p];
-    // one thread = 4 consecutive map columns (one 16-byte load; rows are 64-byte aligned)
+    // one thread = 4 consecutive map columns (one 16-byte load; rows are 64-byte aligned) x 8 rows
     const int col0 = (fr.mx0 & ~3) + 4 * (blockIdx.x * 64 + threadIdx.x);
     if (col0 >= fr.mx1) return;
     const Slam2dMap m = maps[p];
     uint8_t* occ = lv.occ + (size_t)p * lv.fmax * lv.fpitch;
+    uint8_t* tiles = lv.tilemask + (size_t)p * lv.tmax * lv.tmax;
     const int32_t* __restrict__ ax = lv.axis_x + (size_t)p * lv.wmax;
     const int32_t* __restrict__ ay = lv.axis_y + (size_t)p * lv.wmax;
     const int i0 = blockIdx.y * SCATTER_ROWS + threadIdx.y;
     const int nrow = fr.my1 - fr.my0;
+    if (nrow <= 0) return;
+    constexpr int NR = SCATTER_ROWS / 4;
+    uint4 c4[NR];
 #pragma unroll
-    for (int rr = 0; rr < SCATTER_ROWS / 4; ++rr) {
+    for (int rr = 0; rr < NR; ++rr) {          // all loads first: 8 x 16 B in flight per lane
+        const int i = min(i0 + rr * 4, nrow - 1);
+        c4[rr] = *reinterpret_cast<const uint4*>(m.cells + (size_t)(fr.my0 + i) * m.pitch + col0);
+    }
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
         const int i = i0 + rr * 4;
         if (i >= nrow) break;
-        const uint4 c4 = *reinterpret_cast<const uint4*>(m.cells + (size_t)(fr.my0 + i) * m.pitch + col0);
-        const uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
+        const uint32_t c[4] = {c4[rr].x, c4[rr].y, c4[rr].z, c4[rr].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int col = col0 + e;
             if (col >= fr.mx0 && col < fr.mx1 && 2u * (c[e] >> 16) > (c[e] & 0xffffu)) {       // :29-31
                 const int fx = ax[col - fr.mx0], fy = ay[i];
-                if (fx >= 0 && fy >= 0) occ[(size_t)fy * lv.fpitch + fx] = 1;
+                if (fx >= 0 && fy >= 0) {
+                    occ[(size_t)fy * lv.fpitch + fx] = 1;
+                    tiles[(fy >> 5) * lv.tmax + (fx >> 5)] = 1;
+                }
             }
         }
     }
@@ -171,36 +183,68 @@ __global__ __launch_bounds__(256) void k_occ_scatter(Slam2dLevel lv, const Slam2
 // ------------------------------------------------------------------------------------
 #define BLUR_TILE 32
 #define BLUR_EXT (BLUR_TILE + 2 * SLAM2D_MAX_BLUR_RADIUS)
-// RAD > 0: radius known at compile time (register sliding windows, fully unrolled);
-// RAD == 0: any radius up to SLAM2D_MAX_BLUR_RADIUS (loops over LDS).
-// A tile whose halo holds no occupied cell is all "free": every value equals the analytic
-// floor bit for bit, so it is filled without arithmetic.
+// RAD > 0: radius known at compile time (register sliding windows, fully unrolled, LDS sized
+// for it); RAD == 0: any radius up to SLAM2D_MAX_BLUR_RADIUS (loops over LDS).
+//
+// Work avoidance (all bit-exact):
+//  * a tile whose halo holds no occupied cell is all "free": every value equals the analytic
+//    floor, so it is filled with that constant without arithmetic;
+//  * lv.tilestate remembers, across scans, which tiles of the (reused) field buffer already
+//    hold that constant: a tile that was free at the previous build and is free now is not
+//    touched at all -- the field build then costs HBM traffic only where walls are.
 template <int RAD>
-__global__ __launch_bounds__(256) void k_blur_clamp(Slam2dLevel lv, int mode) {
-    const int p = blockIdx.z;
-    const Slam2dFrame fr = lv.frames[p];
-    if (mode == 1 && !fr.redo) return;
+struct BlurLds {
+    static constexpr int EXT = RAD > 0 ? BLUR_TILE + 2 * RAD : BLUR_EXT;
+    uint8_t occ[EXT][EXT + 4];
+    double mid[BLUR_TILE][EXT + 1];
+    double red[4];
+};
+
+template <int RAD>
+__device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& sm, const int p, const Slam2dFrame& fr,
+                                          const int tby, const int tbx, const int mode) {
     const int fh = fr.fh, fw = fr.fw;
-    const int ty0 = blockIdx.y * BLUR_TILE, tx0 = blockIdx.x * BLUR_TILE;
+    const int ty0 = tby * BLUR_TILE, tx0 = tbx * BLUR_TILE;
     if (ty0 >= fh || tx0 >= fw) return;
     const int r = RAD > 0 ? RAD : lv.blur_radius;
     const int ext = BLUR_TILE + 2 * r;
     const int tid = threadIdx.x;
-
-    __shared__ uint8_t occ_s[BLUR_EXT][BLUR_EXT + 4];
-    __shared__ double mid_s[BLUR_TILE][BLUR_EXT + 1];
-    __shared__ double red_s[4];
-
     const uint8_t* occ = lv.occ + (size_t)p * lv.fmax * lv.fpitch;
+    uint8_t* state = lv.tilestate + ((size_t)p * lv.tmax + tby) * lv.tmax + tbx;
+    // activity: an occupied cell within the halo (r <= 16 < 32) lies in one of the 3x3 tiles around
     int any = 0;
-    for (int idx = tid; idx < ext * ext; idx += 256) {
-        const int ly = idx / ext, lx = idx - ly * ext;
-        const int gy = reflect_index(ty0 - r + ly, fh), gx = reflect_index(tx0 - r + lx, fw);
-        const uint8_t o = occ[(size_t)gy * lv.fpitch + gx];
-        occ_s[ly][lx] = o;
-        any |= o;
+    {
+        const uint8_t* tiles = lv.tilemask + (size_t)p * lv.tmax * lv.tmax;
+        const int nty = (fh + 31) >> 5, ntx = (fw + 31) >> 5;
+        if (tid < 9) {
+            const int yy = tby + tid / 3 - 1, xx = tbx + tid % 3 - 1;
+            if (yy >= 0 && yy < nty && xx >= 0 && xx < ntx) any = tiles[yy * lv.tmax + xx];
+        }
+        any = __syncthreads_or(any);
     }
-    any = __syncthreads_or(any);
+    if (any) {
+        // word loads when the halo is interior and 4-byte aligned (r % 4 == 0), bytes + reflect otherwise
+        const bool interior = ty0 - r >= 0 && ty0 + BLUR_TILE + r <= fh && tx0 - r >= 0 && tx0 + BLUR_TILE + r <= fw;
+        int exact = 0;                 // the tile flags are conservative: re-test on the halo itself
+        if ((r & 3) == 0 && interior) {
+            const int wpr = ext >> 2;
+            for (int idx = tid; idx < ext * wpr; idx += 256) {
+                const int ly = idx / wpr, lw = idx - ly * wpr;
+                const uint32_t v = *reinterpret_cast<const uint32_t*>(occ + (size_t)(ty0 - r + ly) * lv.fpitch + (tx0 - r) + 4 * lw);
+                *reinterpret_cast<uint32_t*>(&sm.occ[ly][4 * lw]) = v;
+                exact |= (v != 0u);
+            }
+        } else {
+            for (int idx = tid; idx < ext * ext; idx += 256) {
+                const int ly = idx / ext, lx = idx - ly * ext;
+                const int gy = reflect_index(ty0 - r + ly, fh), gx = reflect_index(tx0 - r + lx, fw);
+                const uint8_t o = occ[(size_t)gy * lv.fpitch + gx];
+                sm.occ[ly][lx] = o;
+                exact |= o;
+            }
+        }
+        any = __syncthreads_or(exact);
+    }
     const double L = lv.log_miss;
     const double fmin_used = mode == 1 ? fr.field_min : lv.floor_value;
     const double thr = 0.5 * fmin_used;                                            // :44
@@ -208,14 +252,17 @@ __global__ __launch_bounds__(256) void k_blur_clamp(Slam2dLevel lv, int mode) {
     const double* __restrict__ w = lv.blur_w;
     if (!any) {
         const double v = lv.floor_value;
+        if (mode == 0 && tid == 0) atomicMin(&lv.frames[p].min_bits, order_bits(v));
+        if (mode == 0 && *state == 0) return;          // already holds the constant: nothing to write
         const uint32_t c = v > thr ? 0u : (uint32_t)rint(-v * lv.cost_scale);
         for (int idx = tid; idx < BLUR_TILE * BLUR_TILE; idx += 256) {
             const int y = idx / BLUR_TILE, x = idx - y * BLUR_TILE;
-            if (ty0 + y < fh && tx0 + x < fw) field[(size_t)(ty0 + y) * lv.fpitch + tx0 + x] = c;
+            if (tx0 + x < lv.fpitch && ty0 + y < lv.fmax) field[(size_t)(ty0 + y) * lv.fpitch + tx0 + x] = c;
         }
-        if (mode == 0 && tid == 0) atomicMin(&lv.frames[p].min_bits, order_bits(v));
+        if (tid == 0) *state = mode == 0 ? 0 : 1;
         return;
     }
+    if (tid == 0) *state = 1;
     double lmin = INFINITY;
     // SciPy symmetric correlate1d order: out = a[c]*w[c]; for j=-r..-1: out += (a[c+j] + a[c-j]) * w[j]
     if constexpr (RAD > 0) {
@@ -224,13 +271,13 @@ __global__ __launch_bounds__(256) void k_blur_clamp(Slam2dLevel lv, int mode) {
             if (lx < ext) {
                 double f[8 + 2 * RAD];
 #pragma unroll
-                for (int k = 0; k < 8 + 2 * RAD; ++k) f[k] = occ_s[g * 8 + k][lx] ? 0.0 : L;
+                for (int k = 0; k < 8 + 2 * RAD; ++k) f[k] = sm.occ[g * 8 + k][lx] ? 0.0 : L;
 #pragma unroll
                 for (int o = 0; o < 8; ++o) {
                     double acc = f[o + RAD] * w[RAD];
 #pragma unroll
                     for (int j = -RAD; j < 0; ++j) acc = acc + (f[o + RAD + j] + f[o + RAD - j]) * w[RAD + j];
-                    mid_s[g * 8 + o][lx] = acc;
+                    sm.mid[g * 8 + o][lx] = acc;
                 }
             }
         }
@@ -239,7 +286,7 @@ __global__ __launch_bounds__(256) void k_blur_clamp(Slam2dLevel lv, int mode) {
             const int y = tid >> 3, x0 = (tid & 7) * 4;
             double mrow[4 + 2 * RAD];
 #pragma unroll
-            for (int k = 0; k < 4 + 2 * RAD; ++k) mrow[k] = mid_s[y][x0 + k];
+            for (int k = 0; k < 4 + 2 * RAD; ++k) mrow[k] = sm.mid[y][x0 + k];
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
                 double acc = mrow[o + RAD] * w[RAD];
@@ -255,19 +302,19 @@ __global__ __launch_bounds__(256) void k_blur_clamp(Slam2dLevel lv, int mode) {
     } else {
         for (int idx = tid; idx < BLUR_TILE * ext; idx += 256) {
             const int y = idx / ext, lx = idx - y * ext;
-            double acc = (occ_s[y + r][lx] ? 0.0 : L) * w[r];
+            double acc = (sm.occ[y + r][lx] ? 0.0 : L) * w[r];
             for (int j = -r; j < 0; ++j) {
-                const double a = occ_s[y + r + j][lx] ? 0.0 : L;
-                const double b = occ_s[y + r - j][lx] ? 0.0 : L;
+                const double a = sm.occ[y + r + j][lx] ? 0.0 : L;
+                const double b = sm.occ[y + r - j][lx] ? 0.0 : L;
                 acc = acc + (a + b) * w[r + j];
             }
-            mid_s[y][lx] = acc;
+            sm.mid[y][lx] = acc;
         }
         __syncthreads();
         for (int idx = tid; idx < BLUR_TILE * BLUR_TILE; idx += 256) {
             const int y = idx / BLUR_TILE, x = idx - y * BLUR_TILE;
-            double acc = mid_s[y][x + r] * w[r];
-            for (int j = -r; j < 0; ++j) acc = acc + (mid_s[y][x + r + j] + mid_s[y][x + r - j]) * w[r + j];
+            double acc = sm.mid[y][x + r] * w[r];
+            for (int j = -r; j < 0; ++j) acc = acc + (sm.mid[y][x + r + j] + sm.mid[y][x + r - j]) * w[r + j];
             const int gy = ty0 + y, gx = tx0 + x;
             if (gy < fh && gx < fw) {
                 lmin = fmin(lmin, acc);
@@ -277,12 +324,31 @@ __global__ __launch_bounds__(256) void k_blur_clamp(Slam2dLevel lv, int mode) {
     }
     if (mode == 0) {
         for (int o = 32; o > 0; o >>= 1) lmin = fmin(lmin, __shfl_down(lmin, o));
-        if ((tid & 63) == 0) red_s[tid >> 6] = lmin;
+        if ((tid & 63) == 0) sm.red[tid >> 6] = lmin;
         __syncthreads();
         if (tid == 0) {
-            lmin = fmin(fmin(red_s[0], red_s[1]), fmin(red_s[2], red_s[3]));
+            lmin = fmin(fmin(sm.red[0], sm.red[1]), fmin(sm.red[2], sm.red[3]));
             atomicMin(&lv.frames[p].min_bits, order_bits(lmin));
         }
+    }
+}
+
+// mode 0: one tile per block.  mode 1 (clamp redo with the measured minimum; rare): one block
+// per particle walks all tiles, and only if that particle needs it.
+template <int RAD>
+__global__ __launch_bounds__(256) void k_blur_clamp(Slam2dLevel lv, int mode) {
+    __shared__ BlurLds<RAD> sm;
+    const int p = blockIdx.z;
+    const Slam2dFrame fr = lv.frames[p];
+    if (mode == 0) {
+        blur_tile<RAD>(lv, sm, p, fr, blockIdx.y, blockIdx.x, 0);
+        return;
+    }
+    if (!fr.redo) return;
+    const int nty = (fr.fh + 31) >> 5, ntx = (fr.fw + 31) >> 5;
+    for (int t = 0; t < nty * ntx; ++t) {
+        blur_tile<RAD>(lv, sm, p, fr, t / ntx, t % ntx, 1);
+        __syncthreads();
     }
 }
 
@@ -466,22 +532,31 @@ __global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)F, (short)0, (int)((size_t)lv.fmax * lv.fpitch * sizeof(uint32_t)), 0x00020000);
     int off[R];
-    unsigned long long acc[R];           // exact integer sum of fixed-point costs
-#pragma unroll
+    unsigned lo[R], hi[R];               // exact 64-bit integer sum of fixed-point costs, as two
+#pragma unroll                           // 32-bit halves so every load lands in its own register
     for (int r = 0; r < R; ++r) {
         const int q = q0 + r * WAVE;
         const int qq = q < npose ? q : 0;
         const int iy = qq / nx;
         off[r] = (iy * lv.fpitch + (qq - iy * nx)) * 4;
-        acc[r] = 0ull;
+        lo[r] = 0u; hi[r] = 0u;
     }
 #pragma unroll 4
     for (int k = 0; k < K; ++k) {
         const int cell = cl[k] * 4;
+        unsigned v[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r)
-            acc[r] += (unsigned long long)(unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsrc, off[r], cell, 0);
+        for (int r = 0; r < R; ++r) v[r] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsrc, off[r], cell, 0);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const unsigned s = lo[r] + v[r];
+            hi[r] += s < v[r] ? 1u : 0u;
+            lo[r] = s;
+        }
     }
+    unsigned long long acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = ((unsigned long long)hi[r] << 32) | lo[r];
     const double* __restrict__ pr = lv.prior + (size_t)p * 2 * npose;
     double* __restrict__ out = lv.cube + ((size_t)p * lv.ntheta + it) * npose;
     const double inv = 1.0 / lv.cost_scale;
@@ -624,7 +699,7 @@ __global__ void k_update_axis(Slam2dLidar lid, const Slam2dMap* __restrict__ map
     axis[((size_t)p * 2 + a) * lid.lut_w + j] = (int)rint(((base + lid.lut_xs[j]) - lim0) / lid.unit);
 }
 
-#define UPD_ROWS 64
+#define UPD_ROWS 32
 __global__ __launch_bounds__(256) void k_grid_update(Slam2dLidar lid, const Slam2dMap* __restrict__ maps, int P,
                                                      const double* __restrict__ pose, int pstride,
                                                      const double* __restrict__ ranges,
@@ -644,36 +719,54 @@ __global__ __launch_bounds__(256) void k_grid_update(Slam2dLidar lid, const Slam
     // spokesOffsetIdxByTheta = int(rint(theta / (2*pi) * numSpokes))  (:131)
     const double th = pose[(size_t)p * pstride + 2];
     const int offset = (int)rint(th / (2 * 3.141592653589793) * (double)S);
+    int first_spoke = (lid.spoke_start + offset) % S;            // spoke of beam 0 (:134), in [0, S)
+    if (first_spoke < 0) first_spoke += S;
     const Slam2dMap m = maps[p];
     const int mx_base = axis[((size_t)p * 2 + 0) * W + j];
+    constexpr int NR = UPD_ROWS / 4;
+    // every load of a stage is issued before the first use (the window is latency-, not
+    // bandwidth-bound: LUT and maps mostly hit L2/MALL)
+    int row[NR], bin[NR], my[NR];
+    double r[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        row[k] = ty * UPD_ROWS + k * 4 + threadIdx.y;
+        const int i = min(row[k], W - 1);
+        bin[k] = lid.lut_bin[(size_t)i * W + j];
+        r[k] = lid.lut_r[(size_t)i * W + j];
+        my[k] = axis[((size_t)p * 2 + 1) * W + i];
+    }
+    uint32_t inc[NR];
+    int mxk[NR];
     uint32_t f = 0;
 #pragma unroll
-    for (int rr = 0; rr < UPD_ROWS / 4; ++rr) {
-        const int i = ty * UPD_ROWS + rr * 4 + threadIdx.y;
-        if (i >= W) break;
-        const int bin = lid.lut_bin[(size_t)i * W + j];
-        int beam = (bin - lid.spoke_start - offset) % S;                             // inverse of :134
+    for (int k = 0; k < NR; ++k) {
+        inc[k] = 0;
+        mxk[k] = mx_base;
+        int beam = bin[k] - first_spoke;                                             // inverse of :134
         if (beam < 0) beam += S;
-        if (beam >= lid.beams) continue;
+        if (row[k] >= W || beam >= lid.beams) continue;
         const double rg = rng_s[beam];
-        const double r = lid.lut_r[(size_t)i * W + j];
         const double lo = rg - lid.wall_half, hi = rg + lid.wall_half;
-        uint32_t inc = 0;
-        if (rg < lid.max_range && r < lo) inc = 1u;                                  // :138-139,149
-        else if (r > lo && r < hi) inc = 0x00020002u;                                // :142-143,151-152
-        if (!inc) continue;
-        int mx = mx_base, my = axis[((size_t)p * 2 + 1) * W + i];
+        if (rg < lid.max_range && r[k] < lo) inc[k] = 1u;                            // :138-139,149
+        else if (r[k] > lo && r[k] < hi) inc[k] = 0x00020002u;                       // :142-143,151-152
+        if (!inc[k]) continue;
         if (beam_shift) {   // stale indices after a low-side growth inside this beam (:144-147)
-            mx -= beam_shift[((size_t)p * lid.beams + beam) * 2 + 0];
-            my -= beam_shift[((size_t)p * lid.beams + beam) * 2 + 1];
-            if (mx < 0) mx += m.cols;
-            if (my < 0) my += m.rows;
+            mxk[k] -= beam_shift[((size_t)p * lid.beams + beam) * 2 + 0];
+            my[k] -= beam_shift[((size_t)p * lid.beams + beam) * 2 + 1];
+            if (mxk[k] < 0) mxk[k] += m.cols;
+            if (my[k] < 0) my[k] += m.rows;
         }
-        if (mx < 0 || mx >= m.cols || my < 0 || my >= m.rows) { f |= SLAM2D_F_UPDATE_OUTSIDE_MAP; continue; }
-        uint32_t* cell = m.cells + (size_t)my * m.pitch + mx;
-        const uint32_t c = *cell;
-        if ((c & 0xffffu) + (inc & 0xffffu) > 0xffffu) { f |= SLAM2D_F_COUNT_OVERFLOW; continue; }
-        *cell = c + inc;
+        if (mxk[k] < 0 || mxk[k] >= m.cols || my[k] < 0 || my[k] >= m.rows) { f |= SLAM2D_F_UPDATE_OUTSIDE_MAP; inc[k] = 0; }
+    }
+    uint32_t c[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) c[k] = inc[k] ? m.cells[(size_t)my[k] * m.pitch + mxk[k]] : 0u;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        if (!inc[k]) continue;
+        if ((c[k] & 0xffffu) + (inc[k] & 0xffffu) > 0xffffu) { f |= SLAM2D_F_COUNT_OVERFLOW; continue; }
+        m.cells[(size_t)my[k] * m.pitch + mxk[k]] = c[k] + inc[k];
     }
     if (f) atomicOr(&flags[p], f);
 }
@@ -786,7 +879,8 @@ int slam2d_field_build(const Slam2dLidar* lidar, const Slam2dLevel* level, const
     const Slam2dLevel& lv = *level;
     k_frame_setup<<<cdiv(P, 64), 64, 0, s>>>(*lidar, lv, d_maps, P, d_centre, centre_stride, d_flags);
     k_axis_index<<<dim3(cdiv(lv.wmax, 256), P, 2), 256, 0, s>>>(lv, d_maps, d_flags);
-    hipError_t e = hipMemsetAsync(lv.occ, 0, (size_t)P * lv.fmax * lv.fpitch, s);
+    if (lv.tilemask != lv.occ + (size_t)P * lv.fmax * lv.fpitch || !lv.tilestate) return SLAM2D_E_BADARG;
+    hipError_t e = hipMemsetAsync(lv.occ, 0, (size_t)P * lv.fmax * lv.fpitch + (size_t)P * lv.tmax * lv.tmax, s);
     if (e != hipSuccess) return (int)e;
     {
         StageScope prof(SLAM2D_STAGE_SCATTER, s);
@@ -794,12 +888,13 @@ int slam2d_field_build(const Slam2dLidar* lidar, const Slam2dLevel* level, const
     }
     const dim3 bgrid(cdiv(lv.fmax, BLUR_TILE), cdiv(lv.fmax, BLUR_TILE), P);
     for (int mode = 0; mode < 2; ++mode) {
+        const dim3 g = mode == 0 ? bgrid : dim3(1, 1, P);
         {
             StageScope prof(mode == 0 ? SLAM2D_STAGE_BLUR : -1, s);
             switch (lv.blur_radius) {
-                case 2: k_blur_clamp<2><<<bgrid, 256, 0, s>>>(lv, mode); break;
-                case 8: k_blur_clamp<8><<<bgrid, 256, 0, s>>>(lv, mode); break;
-                default: k_blur_clamp<0><<<bgrid, 256, 0, s>>>(lv, mode); break;
+                case 2: k_blur_clamp<2><<<g, 256, 0, s>>>(lv, mode); break;
+                case 8: k_blur_clamp<8><<<g, 256, 0, s>>>(lv, mode); break;
+                default: k_blur_clamp<0><<<g, 256, 0, s>>>(lv, mode); break;
             }
         }
         if (mode == 0) k_floor_check<<<cdiv(P, 64), 64, 0, s>>>(lv, P, d_flags);
@@ -822,12 +917,17 @@ int slam2d_sweep(const Slam2dLidar* lidar, const Slam2dLevel* level, int32_t P, 
         k_endpoints<<<dim3(lv.ntheta, P), 256, 0, s>>>(*lidar, lv, d_est, est_stride, d_ranges, d_flags);
     }
     k_priors<<<dim3(cdiv(npose, 256), P), 256, 0, s>>>(lv, est_moving_dist, lv.fine ? nullptr : d_psi_cs);
-    // poses per lane: the largest R <= 8 that wastes the fewest lanes
+    // poses per lane R: the k loop costs ~(R + 1) issue slots per cell and wave (R gathers + the
+    // scalar cell load / loop), so minimise chunks * (R + 1); ties go to the larger R
     const int need = cdiv(npose, WAVE);
-    int bestR = 1, bestWaste = INT_MAX;
+    int bestR = 1, bestCost = INT_MAX;
     for (int R = 1; R <= 8; ++R) {
-        const int waste = cdiv(need, R) * R - need;
-        if (waste <= bestWaste) { bestWaste = waste; bestR = R; }
+        const int cost = cdiv(need, R) * (R + 1);
+        if (cost <= bestCost) { bestCost = cost; bestR = R; }
+    }
+    if (const char* ov = getenv("SLAM2D_SWEEP_R")) {              // tuning knob
+        const int R = atoi(ov);
+        if (R >= 1 && R <= 8) bestR = R;
     }
     const int chunks = cdiv(need, bestR);
     if (lv.ntheta * chunks > lv.npartial) return SLAM2D_E_BADARG;

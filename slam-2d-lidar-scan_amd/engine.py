@@ -325,6 +325,7 @@ class SearchLevel:
         self.max_move_dev = max_move_dev
         npose = self.nx * self.nx
         self.npartial = self.ntheta * (-(-npose // 64))
+        self.tmax = -(-self.fmax // 32)
         i32, f64 = torch.int32, torch.float64
         t = self.t = dict(
             blur_w=_dev(self.taps, device),
@@ -335,13 +336,15 @@ class SearchLevel:
             frames=torch.zeros((P, C.sizeof(Slam2dFrame)), dtype=torch.uint8, device=device),
             axis_x=torch.zeros((P, self.wmax), dtype=i32, device=device),
             axis_y=torch.zeros((P, self.wmax), dtype=i32, device=device),
-            occ=torch.zeros((P, self.fmax, self.fpitch), dtype=torch.uint8, device=device),
+            # occupied-cell image of every particle, followed by the 32x32 tile flags (one memset clears both)
+            occ=torch.zeros(P * self.fmax * self.fpitch + P * self.tmax * self.tmax, dtype=torch.uint8, device=device),
             field=torch.zeros((P, self.fmax, self.fpitch), dtype=i32, device=device),     # uint32 costs
             cells=torch.zeros((P, self.ntheta, self.kmax), dtype=i32, device=device),
             kcount=torch.zeros((P, self.ntheta), dtype=i32, device=device),
             prior=torch.zeros((P, 2, npose), dtype=f64, device=device),
             cube=torch.zeros((P, self.ntheta, npose), dtype=f64, device=device),
             partials=torch.zeros((P, self.npartial, C.sizeof(Slam2dPartial)), dtype=torch.uint8, device=device),
+            tilestate=torch.ones((P, self.tmax, self.tmax), dtype=torch.uint8, device=device),   # all dirty
         )
         self.c = Slam2dLevel(
             step=step, reach=self.reach, log_miss=self.log_miss, floor_value=self.floor_value,
@@ -352,7 +355,8 @@ class SearchLevel:
             max_move_dev=max_move_dev, frames=t["frames"].data_ptr(), axis_x=t["axis_x"].data_ptr(),
             axis_y=t["axis_y"].data_ptr(), occ=t["occ"].data_ptr(), field=t["field"].data_ptr(),
             cells=t["cells"].data_ptr(), kcount=t["kcount"].data_ptr(), prior=t["prior"].data_ptr(),
-            cube=t["cube"].data_ptr(), partials=t["partials"].data_ptr(), npartial=self.npartial, _pad=0)
+            cube=t["cube"].data_ptr(), partials=t["partials"].data_ptr(), npartial=self.npartial, tmax=self.tmax,
+            tilemask=t["occ"].data_ptr() + P * self.fmax * self.fpitch, tilestate=t["tilestate"].data_ptr())
 
     # -- results --
     def frames(self):
@@ -375,6 +379,7 @@ class SearchLevel:
         self.c.cost_scale = scale
         fh, fw = prob.shape
         self.t["field"][p, :fh, :fw] = torch.from_numpy(cost.view(np.int32)).to(self.device)
+        self.t["tilestate"][p].fill_(1)          # the buffer no longer holds what field_build left there
         return scale
 
     def cube(self, p=0):

@@ -1,0 +1,24 @@
+#!/bin/bash
+# quick A/B of tuning knobs on the GPU box (bench only, no CPU baseline)
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests -m gpu -q --maxfail=60 -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
+echo "pytest rc=$?"; tail -n 5 gpurun_out/pytest_gpu.log
+for R in 0 2 3 4 7; do
+  if [ "$R" = "0" ]; then unset SLAM2D_SWEEP_R; else export SLAM2D_SWEEP_R=$R; fi
+  echo "== SWEEP_R=$R"
+  timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
+import sys, json
+for line in sys.stdin:
+    if line.startswith('{'):
+        d = json.loads(line); print('value', round(d['value']), 'ms/step', round(d['ms_per_step'],3), {k: v['avg_us'] for k, v in d['stages'].items()})
+"
+done
+unset SLAM2D_SWEEP_R
+echo "== ref2level"
+timeout 300 python bench.py --workload ref2level --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
+import sys, json
+for line in sys.stdin:
+    if line.startswith('{'):
+        d = json.loads(line); print('value', round(d['value']), 'ms/step', round(d['ms_per_step'],3), {k: v['avg_us'] for k, v in d['stages'].items()})
+"
