@@ -121,7 +121,7 @@ class HotPath:
         self.d_w = torch.zeros(P, dtype=torch.float64, device=device)
         self.d_stats = torch.zeros(2, dtype=torch.float64, device=device)
         self.L = E._lib.lib()
-        self.sharded = dist.is_initialized() and dist.get_world_size() > 1
+        self.sharded = dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("SLAM2D_FORCE_DIST") == "1")
         self.par = importlib.import_module("slam-2d-lidar-scan_amd.parallel")
         self.total_particles = P * (dist.get_world_size() if dist.is_initialized() else 1)
 
@@ -214,8 +214,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    force_dist = os.environ.get("SLAM2D_FORCE_DIST") == "1"     # exercise the sharded code path on one GPU
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -239,19 +241,19 @@ def main():
               E._lib.STAGE_SELECT, E._lib.STAGE_ENDPOINTS]
     E._lib.check(lib.slam2d_prof_enable(sum(1 << s for s in stages), 4 * K + 8), "prof_enable")
 
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(W, W + K):
         hot.step(s)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     flags = hot.eng.take_flags()
     lib.slam2d_prof_disable()
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -304,7 +306,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, scen, args.cpu_seconds)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

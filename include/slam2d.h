@@ -107,7 +107,7 @@ typedef struct {
     int32_t mx0, mx1;        /* map column window [mx0, mx1) */
     int32_t my0, my1;        /* map row window    [my0, my1) */
     int32_t redo, _pad;
-    unsigned long long min_bits; /* scratch: order-preserving bits of the running minimum */
+    unsigned long long min_bits; /* reserved */
 } Slam2dFrame;
 
 /* Reduction of the 64*R consecutive cube entries one wave of the sweep scored. */
@@ -163,6 +163,10 @@ typedef struct {
                                 the free-space constant (no rewrite needed), 1 = dirty/unknown.
                                 Initialise to 1; set to 1 whenever the field buffer is written by
                                 anything other than slam2d_field_build */
+    double*  tilemin;        /* [P][tmax][tmax] scratch: per-tile minimum of the blurred field */
+    const double* vtable;    /* NULL, or [2^(2*blur_radius+1)] axis-0 blur result of every binary column
+                                window (bit k set = window row k occupied), filled with the kernel's
+                                operation order; used when blur_radius is 2 or 8 */
 } Slam2dLevel;
 
 /* Result of one level for one particle. */

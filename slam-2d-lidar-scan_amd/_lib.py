@@ -79,7 +79,7 @@ class Slam2dLevel(C.Structure):
                 ("frames", _vp), ("axis_x", _vp), ("axis_y", _vp), ("occ", _vp), ("field", _vp),
                 ("cells", _vp), ("kcount", _vp), ("prior", _vp), ("cube", _vp),
                 ("partials", _vp), ("npartial", C.c_int32), ("tmax", C.c_int32), ("tilemask", _vp),
-                ("tilestate", _vp)]
+                ("tilestate", _vp), ("tilemin", _vp), ("vtable", _vp)]
 
 
 class Slam2dMatch(C.Structure):

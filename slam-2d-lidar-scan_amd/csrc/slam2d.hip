@@ -252,7 +252,7 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
     const double* __restrict__ w = lv.blur_w;
     if (!any) {
         const double v = lv.floor_value;
-        if (mode == 0 && tid == 0) atomicMin(&lv.frames[p].min_bits, order_bits(v));
+        if (mode == 0 && tid == 0) lv.tilemin[((size_t)p * lv.tmax + tby) * lv.tmax + tbx] = v;
         if (mode == 0 && *state == 0) return;          // already holds the constant: nothing to write
         const uint32_t c = v > thr ? 0u : (uint32_t)rint(-v * lv.cost_scale);
         for (int idx = tid; idx < BLUR_TILE * BLUR_TILE; idx += 256) {
@@ -269,15 +269,35 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
         {   // axis-0 pass: thread = (column lx, 8 consecutive rows)
             const int lx = tid & 63, g = tid >> 6;
             if (lx < ext) {
-                double f[8 + 2 * RAD];
+                if (lv.vtable != nullptr) {
+                    // The axis-0 input is binary (free / occupied), so its result is a function of the
+                    // (2r+1)-bit occupancy pattern of the column window: one lookup in a table that
+                    // was filled with the same operation order (bit k = occupied at window row k).
+                    unsigned pat = 0;
 #pragma unroll
-                for (int k = 0; k < 8 + 2 * RAD; ++k) f[k] = sm.occ[g * 8 + k][lx] ? 0.0 : L;
+                    for (int k = 0; k < 2 * RAD + 1; ++k) pat |= (sm.occ[g * 8 + k][lx] ? 1u : 0u) << k;
+                    unsigned pats[8];
 #pragma unroll
-                for (int o = 0; o < 8; ++o) {
-                    double acc = f[o + RAD] * w[RAD];
+                    for (int o = 0; o < 8; ++o) {
+                        pats[o] = pat;
+                        if (o < 7) pat = (pat >> 1) | ((sm.occ[g * 8 + o + 2 * RAD + 1][lx] ? 1u : 0u) << (2 * RAD));
+                    }
+                    double v[8];
 #pragma unroll
-                    for (int j = -RAD; j < 0; ++j) acc = acc + (f[o + RAD + j] + f[o + RAD - j]) * w[RAD + j];
-                    sm.mid[g * 8 + o][lx] = acc;
+                    for (int o = 0; o < 8; ++o) v[o] = lv.vtable[pats[o]];
+#pragma unroll
+                    for (int o = 0; o < 8; ++o) sm.mid[g * 8 + o][lx] = v[o];
+                } else {
+                    double f[8 + 2 * RAD];
+#pragma unroll
+                    for (int k = 0; k < 8 + 2 * RAD; ++k) f[k] = sm.occ[g * 8 + k][lx] ? 0.0 : L;
+#pragma unroll
+                    for (int o = 0; o < 8; ++o) {
+                        double acc = f[o + RAD] * w[RAD];
+#pragma unroll
+                        for (int j = -RAD; j < 0; ++j) acc = acc + (f[o + RAD + j] + f[o + RAD - j]) * w[RAD + j];
+                        sm.mid[g * 8 + o][lx] = acc;
+                    }
                 }
             }
         }
@@ -328,7 +348,7 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
         __syncthreads();
         if (tid == 0) {
             lmin = fmin(fmin(sm.red[0], sm.red[1]), fmin(sm.red[2], sm.red[3]));
-            atomicMin(&lv.frames[p].min_bits, order_bits(lmin));
+            lv.tilemin[((size_t)p * lv.tmax + tby) * lv.tmax + tbx] = lmin;   // reduced by k_floor_check
         }
     }
 }
@@ -352,12 +372,23 @@ __global__ __launch_bounds__(256) void k_blur_clamp(Slam2dLevel lv, int mode) {
     }
 }
 
-__global__ void k_floor_check(Slam2dLevel lv, int P, uint32_t* flags) {
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
-    const double measured = unorder_bits(lv.frames[p].min_bits);
-    lv.frames[p].field_min = measured;                            // probMin (:43)
-    if (measured != lv.floor_value) { lv.frames[p].redo = 1; atomicOr(&flags[p], SLAM2D_F_FLOOR_REDO); }
+// probMin (:43): minimum over the per-tile minima; one block per particle.
+__global__ __launch_bounds__(256) void k_floor_check(Slam2dLevel lv, int P, uint32_t* flags) {
+    __shared__ double red[4];
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const Slam2dFrame fr = lv.frames[p];
+    const int nty = (fr.fh + 31) >> 5, ntx = (fr.fw + 31) >> 5;
+    const double* __restrict__ tm = lv.tilemin + (size_t)p * lv.tmax * lv.tmax;
+    double m = INFINITY;
+    for (int t = tid; t < nty * ntx; t += 256) m = fmin(m, tm[(t / ntx) * lv.tmax + (t % ntx)]);
+    for (int o = 32; o > 0; o >>= 1) m = fmin(m, __shfl_down(m, o));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {
+        m = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+        lv.frames[p].field_min = m;
+        if (m != lv.floor_value) { lv.frames[p].redo = 1; atomicOr(&flags[p], SLAM2D_F_FLOOR_REDO); }
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -879,7 +910,7 @@ int slam2d_field_build(const Slam2dLidar* lidar, const Slam2dLevel* level, const
     const Slam2dLevel& lv = *level;
     k_frame_setup<<<cdiv(P, 64), 64, 0, s>>>(*lidar, lv, d_maps, P, d_centre, centre_stride, d_flags);
     k_axis_index<<<dim3(cdiv(lv.wmax, 256), P, 2), 256, 0, s>>>(lv, d_maps, d_flags);
-    if (lv.tilemask != lv.occ + (size_t)P * lv.fmax * lv.fpitch || !lv.tilestate) return SLAM2D_E_BADARG;
+    if (lv.tilemask != lv.occ + (size_t)P * lv.fmax * lv.fpitch || !lv.tilestate || !lv.tilemin) return SLAM2D_E_BADARG;
     hipError_t e = hipMemsetAsync(lv.occ, 0, (size_t)P * lv.fmax * lv.fpitch + (size_t)P * lv.tmax * lv.tmax, s);
     if (e != hipSuccess) return (int)e;
     {
@@ -897,7 +928,7 @@ int slam2d_field_build(const Slam2dLidar* lidar, const Slam2dLevel* level, const
                 default: k_blur_clamp<0><<<g, 256, 0, s>>>(lv, mode); break;
             }
         }
-        if (mode == 0) k_floor_check<<<cdiv(P, 64), 64, 0, s>>>(lv, P, d_flags);
+        if (mode == 0) k_floor_check<<<P, 256, 0, s>>>(lv, P, d_flags);
     }
     return launch_status();
 }

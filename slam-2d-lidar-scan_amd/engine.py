@@ -78,6 +78,19 @@ def blurred_free_value(log_miss, taps, radius):
     return float(one_pass(one_pass(L)))
 
 
+def column_pass_table(log_miss, taps, radius):
+    """Axis-0 blur result of every binary column window: entry `pat` has bit k set when
+    window row k is occupied.  Same operation order as the kernel / SciPy's symmetric
+    correlate1d (out = a[c]*w[c]; for j=-r..-1: out += (a[c+j] + a[c-j]) * w[j])."""
+    n = 2 * radius + 1
+    pat = np.arange(1 << n, dtype=np.uint32)
+    f = np.where(((pat[:, None] >> np.arange(n, dtype=np.uint32)[None, :]) & 1) == 1, 0.0, np.float64(log_miss))
+    acc = f[:, radius] * taps[radius]
+    for j in range(-radius, 0):
+        acc = acc + (f[:, radius + j] + f[:, radius - j]) * taps[radius + j]
+    return np.ascontiguousarray(acc)
+
+
 def cost_scale_for(min_value):
     """2^k with -min_value * 2^k < 2^32 (k <= 31): the fixed-point scale of a search field
     whose values lie in [min_value, 0] (include/slam2d.h, "Search field format")."""
@@ -345,6 +358,9 @@ class SearchLevel:
             cube=torch.zeros((P, self.ntheta, npose), dtype=f64, device=device),
             partials=torch.zeros((P, self.npartial, C.sizeof(Slam2dPartial)), dtype=torch.uint8, device=device),
             tilestate=torch.ones((P, self.tmax, self.tmax), dtype=torch.uint8, device=device),   # all dirty
+            tilemin=torch.zeros((P, self.tmax, self.tmax), dtype=f64, device=device),
+            vtable=(_dev(column_pass_table(self.log_miss, self.taps, self.blur_radius), device)
+                    if self.blur_radius in (2, 8) else None),
         )
         self.c = Slam2dLevel(
             step=step, reach=self.reach, log_miss=self.log_miss, floor_value=self.floor_value,
@@ -356,7 +372,8 @@ class SearchLevel:
             axis_y=t["axis_y"].data_ptr(), occ=t["occ"].data_ptr(), field=t["field"].data_ptr(),
             cells=t["cells"].data_ptr(), kcount=t["kcount"].data_ptr(), prior=t["prior"].data_ptr(),
             cube=t["cube"].data_ptr(), partials=t["partials"].data_ptr(), npartial=self.npartial, tmax=self.tmax,
-            tilemask=t["occ"].data_ptr() + P * self.fmax * self.fpitch, tilestate=t["tilestate"].data_ptr())
+            tilemask=t["occ"].data_ptr() + P * self.fmax * self.fpitch, tilestate=t["tilestate"].data_ptr(),
+            tilemin=t["tilemin"].data_ptr(), vtable=t["vtable"].data_ptr() if t["vtable"] is not None else None)
 
     # -- results --
     def frames(self):
