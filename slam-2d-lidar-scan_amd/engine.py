@@ -78,6 +78,9 @@ def blurred_free_value(log_miss, taps, radius):
     return float(one_pass(one_pass(L)))
 
 
+USE_COLUMN_TABLE = False
+
+
 def column_pass_table(log_miss, taps, radius):
     """Axis-0 blur result of every binary column window: entry `pat` has bit k set when
     window row k is occupied.  Same operation order as the kernel / SciPy's symmetric
@@ -359,8 +362,10 @@ class SearchLevel:
             partials=torch.zeros((P, self.npartial, C.sizeof(Slam2dPartial)), dtype=torch.uint8, device=device),
             tilestate=torch.ones((P, self.tmax, self.tmax), dtype=torch.uint8, device=device),   # all dirty
             tilemin=torch.zeros((P, self.tmax, self.tmax), dtype=f64, device=device),
+            # optional table-driven axis-0 pass; measured slower than the arithmetic on MI355X
+            # (178 vs 164 us at config 2: the kernel is latency-, not ALU-bound), so off by default
             vtable=(_dev(column_pass_table(self.log_miss, self.taps, self.blur_radius), device)
-                    if self.blur_radius in (2, 8) else None),
+                    if (USE_COLUMN_TABLE and self.blur_radius in (2, 8)) else None),
         )
         self.c = Slam2dLevel(
             step=step, reach=self.reach, log_miss=self.log_miss, floor_value=self.floor_value,
