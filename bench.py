@@ -282,7 +282,9 @@ def main():
         traffic = None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(f"{args.workload}:{dom}")
+            # measured offline for the same command (tools/gpu_session.sh prof): per-launch HBM bytes,
+            # 2*FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950
+            traffic = (json.load(open(tpath)).get(f"{args.workload}:{dom}") or {}).get("hbm_bytes_corrected")
         out = {
             "metric": "scans/sec (180-beam) x particles at fixed search volume",
             "value": total_units / elapsed, "unit": "particle-scans/s",

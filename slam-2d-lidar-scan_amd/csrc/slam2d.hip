@@ -353,17 +353,22 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
     }
 }
 
-// mode 0: one tile per block.  mode 1 (clamp redo with the measured minimum; rare): one block
-// per particle walks all tiles, and only if that particle needs it.
+// One tile per block.
 template <int RAD>
-__global__ __launch_bounds__(256) void k_blur_clamp(Slam2dLevel lv, int mode) {
+__global__ __launch_bounds__(256) void k_blur_clamp(Slam2dLevel lv) {
     __shared__ BlurLds<RAD> sm;
     const int p = blockIdx.z;
     const Slam2dFrame fr = lv.frames[p];
-    if (mode == 0) {
-        blur_tile<RAD>(lv, sm, p, fr, blockIdx.y, blockIdx.x, 0);
-        return;
-    }
+    blur_tile<RAD>(lv, sm, p, fr, blockIdx.y, blockIdx.x, 0);
+}
+
+// Clamp redo with the measured minimum (rare: only when no cell of the field has an all-free
+// neighbourhood): one block per particle walks all tiles, and only if that particle needs it.
+template <int RAD>
+__global__ __launch_bounds__(256) void k_blur_redo(Slam2dLevel lv) {
+    __shared__ BlurLds<RAD> sm;
+    const int p = blockIdx.z;
+    const Slam2dFrame fr = lv.frames[p];
     if (!fr.redo) return;
     const int nty = (fr.fh + 31) >> 5, ntx = (fr.fw + 31) >> 5;
     for (int t = 0; t < nty * ntx; ++t) {
@@ -918,17 +923,19 @@ int slam2d_field_build(const Slam2dLidar* lidar, const Slam2dLevel* level, const
         k_occ_scatter<<<dim3(cdiv(lv.wmax + 3, 256), cdiv(lv.wmax, SCATTER_ROWS), P), dim3(64, 4), 0, s>>>(lv, d_maps);
     }
     const dim3 bgrid(cdiv(lv.fmax, BLUR_TILE), cdiv(lv.fmax, BLUR_TILE), P);
-    for (int mode = 0; mode < 2; ++mode) {
-        const dim3 g = mode == 0 ? bgrid : dim3(1, 1, P);
-        {
-            StageScope prof(mode == 0 ? SLAM2D_STAGE_BLUR : -1, s);
-            switch (lv.blur_radius) {
-                case 2: k_blur_clamp<2><<<g, 256, 0, s>>>(lv, mode); break;
-                case 8: k_blur_clamp<8><<<g, 256, 0, s>>>(lv, mode); break;
-                default: k_blur_clamp<0><<<g, 256, 0, s>>>(lv, mode); break;
-            }
+    {
+        StageScope prof(SLAM2D_STAGE_BLUR, s);
+        switch (lv.blur_radius) {
+            case 2: k_blur_clamp<2><<<bgrid, 256, 0, s>>>(lv); break;
+            case 8: k_blur_clamp<8><<<bgrid, 256, 0, s>>>(lv); break;
+            default: k_blur_clamp<0><<<bgrid, 256, 0, s>>>(lv); break;
         }
-        if (mode == 0) k_floor_check<<<P, 256, 0, s>>>(lv, P, d_flags);
+    }
+    k_floor_check<<<P, 256, 0, s>>>(lv, P, d_flags);
+    switch (lv.blur_radius) {
+        case 2: k_blur_redo<2><<<dim3(1, 1, P), 256, 0, s>>>(lv); break;
+        case 8: k_blur_redo<8><<<dim3(1, 1, P), 256, 0, s>>>(lv); break;
+        default: k_blur_redo<0><<<dim3(1, 1, P), 256, 0, s>>>(lv); break;
     }
     return launch_status();
 }

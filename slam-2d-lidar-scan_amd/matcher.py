@@ -75,7 +75,7 @@ class ScanMatcher:
         eng = self.og.engine()
         d_c = eng.to_device([[estimatedX, estimatedY]])
         eng = self._build_field(eng, level, d_c, 2, estimatedX, estimatedY)
-        eng.take_flags()
+        self.last_flags = int(eng.take_flags()[0])
         fr = level.frames()[0]
         return [fr["xlo"], fr["xhi"]], [fr["ylo"], fr["yhi"]], level.field(0)
 

@@ -246,6 +246,42 @@ def test_synthetic_shapes(pkg, name):
     assert [matched["x"], matched["y"], matched["theta"]] == list(z["matched"])
 
 
+def test_floor_redo_path(pkg):
+    """Rare branch: no cell of the field has an all-free neighbourhood, so the field minimum is
+    NOT the analytic floor and the clamp pass is redone with the measured minimum.  Forced with a
+    map whose occupied cells form a dense lattice; field and probMin must still be bit-exact."""
+    lib = importlib.import_module("slam-2d-lidar-scan_amd._lib")
+    unit, R, size_m = 0.1, 5.0, 20
+    og = pkg.OccupancyGrid(size_m, size_m, {"x": 0.0, "y": 0.0}, unit, np.pi, 90, R, 0.5)
+    n = og.map.rows
+    v = np.ones((n, n)); t = np.full((n, n), 5.0)
+    v[::5, ::5] = 7.0; t[::5, ::5] = 8.0                 # occupied every 5th cell in both directions
+    og.set_counts(v, t)
+    sm = pkg.ScanMatcher(og, 1.0, 0.25, 2, 0.1, 0.25, 0.3, 0.15, 1)
+    xr, yr, prob = sm.frameSearchSpace(0.3, -0.2, unit, 2, 0.15)
+    assert sm.last_flags & lib.F_FLOOR_REDO
+    ogo = so.GridOracle(size_m, size_m, {"x": 0.0, "y": 0.0}, unit, np.pi, 90, R, 0.5,
+                        lut=so.SpokeLUT(0.5, 4, np.pi, 90))
+    ogo.visited[:], ogo.total[:] = v, t
+    smo = so.MatcherOracle(ogo, 1.0, 0.25, 2, 0.1, 0.25, 0.3, 0.15, 1)
+    xro, yro, want = smo.frameSearchSpace(0.3, -0.2, unit, 2, 0.15)
+    level = sm._level(unit, 2, 0.15, sm.searchRadius, sm.searchHalfRad, False)
+    assert want.min() > level.floor_value                                   # the premise of the test
+    assert level.frames()[0]["field_min"] == want.min()
+    assert prob.shape == want.shape and int(((prob == 0) != (want == 0)).sum()) == 0
+    assert np.array_equal(level.field_cost(0), E.encode_cost(want, level.c.cost_scale))
+    # and the next ordinary build on the same (shared) workspace is unaffected by the redo
+    og.set_counts(np.ones((n, n)), np.full((n, n), 5.0))
+    ogo.visited[:], ogo.total[:] = 1.0, 5.0
+    v2 = np.ones((n, n)); v2[40:44, 30:90] = 7.0
+    t2 = np.full((n, n), 5.0); t2[40:44, 30:90] = 8.0
+    og.set_counts(v2, t2); ogo.visited[:], ogo.total[:] = v2, t2
+    _, _, prob2 = sm.frameSearchSpace(0.3, -0.2, unit, 2, 0.15)
+    _, _, want2 = smo.frameSearchSpace(0.3, -0.2, unit, 2, 0.15)
+    assert not (sm.last_flags & lib.F_FLOOR_REDO)
+    assert np.array_equal(level.field_cost(0), E.encode_cost(want2, level.c.cost_scale))
+
+
 def test_softmax_draw_matches_numpy(pkg):
     """matchMax=False: the index drawn for a given uniform equals
     cdf.searchsorted(u, 'right') on the reference's cube (np.random.choice semantics)."""

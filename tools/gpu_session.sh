@@ -23,10 +23,26 @@ if [ "$MODE" != "quick" ]; then
 fi
 if [ "$MODE" = "prof" ]; then
   cd /tmp
-  timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_config2 -o config2 -- \
-      python $GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_config2.log 2>&1
-  echo "rocprof rc=$?"
+  for WL in config2 ref2level; do
+    rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof_$WL
+    timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$WL -o $WL -- \
+        python $GRAFT_REPO_ROOT/bench.py --workload $WL --steps 30 --warmup 5 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_$WL.log 2>&1
+    echo "rocprof $WL rc=$?"; tail -n 1 $GRAFT_REPO_ROOT/gpurun_out/prof_$WL.log | cut -c1-200
+  done
   cd $GRAFT_REPO_ROOT
-  find gpurun_out/prof_config2 -name "*stats*" | head
+  find gpurun_out/prof_config2 gpurun_out/prof_ref2level -name "*stats*" | head
+  # HBM traffic of the default bench command: separate PMC passes (FETCH_SIZE / WRITE_SIZE cannot share one)
+  cd /tmp
+  for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
+    N=$(echo $C | cut -d' ' -f1)
+    rm -rf $GRAFT_REPO_ROOT/gpurun_out/pmc_$N
+    timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$N -o pmc -- \
+        python $GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/pmc_$N.log 2>&1
+    echo "pmc $N rc=$?"
+  done
+  cd $GRAFT_REPO_ROOT
+  python tools/summarize_profiles.py > gpurun_out/profile_summary.txt 2>&1; tail -n 30 gpurun_out/profile_summary.txt
+  SLAM2D_FORCE_DIST=1 timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/bench_forced_dist.log 2>&1
+  echo "forced-dist rc=$?"; grep -c '"metric"' gpurun_out/bench_forced_dist.log
 fi
 echo "== done $(date)"
