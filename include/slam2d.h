@@ -75,8 +75,11 @@ typedef struct {
     uint32_t*     cells;     /* [rows][pitch] */
     const double* X;         /* [cols] */
     const double* Y;         /* [rows] */
-    int32_t rows, cols, pitch, _pad;
+    int32_t rows, cols, pitch, bits_pitch;
     double  lim_x0, lim_x1, lim_y0, lim_y1;
+    uint32_t*     occ_bits;  /* [rows][bits_pitch] 1 bit per cell: occupied (2*visited > total).  Kept in
+                                step by slam2d_grid_update; after any other write to `cells` call
+                                slam2d_map_refresh_bits.  The field build reads only these bits. */
 } Slam2dMap;
 
 /* Lidar + polar spoke lookup table shared by all particles
@@ -164,6 +167,8 @@ typedef struct {
                                 Initialise to 1; set to 1 whenever the field buffer is written by
                                 anything other than slam2d_field_build */
     double*  tilemin;        /* [P][tmax][tmax] scratch: per-tile minimum of the blurred field */
+    int32_t* tilelist;       /* [P][2][tmax*tmax] scratch: work lists (tiles to blur, tiles to fill) */
+    int32_t* tilecount;      /* [P][2] scratch: their lengths */
     const double* vtable;    /* NULL, or [2^(2*blur_radius+1)] axis-0 blur result of every binary column
                                 window (bit k set = window row k occupied), filled with the kernel's
                                 operation order; used when blur_radius is 2 or 8 */
@@ -236,6 +241,10 @@ int slam2d_weights_normalize(double* d_logw, const double* d_logconf, int32_t N,
  * plain device-to-device copies instead. */
 int slam2d_gather_maps(const Slam2dMap* d_src, const Slam2dMap* d_dst, const int32_t* d_index,
                        int32_t P, int64_t cells_per_map, void* stream);
+
+/* Recompute occ_bits from cells for the maps d_maps[d_index[0..n)] (d_index NULL: maps 0..n-1).
+ * Needed after the caller wrote `cells` itself (upload, growth copy, resample copy). */
+int slam2d_map_refresh_bits(const Slam2dMap* d_maps, const int32_t* d_index, int32_t n, void* stream);
 
 /* Fill a map with SLAM2D_INIT_CELL (np.ones / 2*np.ones, Utils/OccupancyGrid.py:13-14). */
 int slam2d_map_fill(uint32_t* d_cells, int64_t n, uint32_t value, void* stream);

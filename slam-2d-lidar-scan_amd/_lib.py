@@ -46,8 +46,9 @@ _vp = C.c_void_p
 
 class Slam2dMap(C.Structure):
     _fields_ = [("cells", _vp), ("X", _vp), ("Y", _vp),
-                ("rows", C.c_int32), ("cols", C.c_int32), ("pitch", C.c_int32), ("_pad", C.c_int32),
-                ("lim_x0", C.c_double), ("lim_x1", C.c_double), ("lim_y0", C.c_double), ("lim_y1", C.c_double)]
+                ("rows", C.c_int32), ("cols", C.c_int32), ("pitch", C.c_int32), ("bits_pitch", C.c_int32),
+                ("lim_x0", C.c_double), ("lim_x1", C.c_double), ("lim_y0", C.c_double), ("lim_y1", C.c_double),
+                ("occ_bits", _vp)]
 
 
 class Slam2dLidar(C.Structure):
@@ -79,7 +80,8 @@ class Slam2dLevel(C.Structure):
                 ("frames", _vp), ("axis_x", _vp), ("axis_y", _vp), ("occ", _vp), ("field", _vp),
                 ("cells", _vp), ("kcount", _vp), ("prior", _vp), ("cube", _vp),
                 ("partials", _vp), ("npartial", C.c_int32), ("tmax", C.c_int32), ("tilemask", _vp),
-                ("tilestate", _vp), ("tilemin", _vp), ("vtable", _vp)]
+                ("tilestate", _vp), ("tilemin", _vp),
+                ("tilelist", _vp), ("tilecount", _vp), ("vtable", _vp)]
 
 
 class Slam2dMatch(C.Structure):
@@ -104,6 +106,7 @@ SIGNATURES = {
     "slam2d_weights_normalize": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, _vp]),
     "slam2d_gather_maps": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int64, _vp]),
     "slam2d_map_fill": (C.c_int, [_vp, C.c_int64, C.c_uint32, _vp]),
+    "slam2d_map_refresh_bits": (C.c_int, [_vp, _vp, C.c_int32, _vp]),
     "slam2d_prof_enable": (C.c_int, [C.c_uint32, C.c_int32]),
     "slam2d_prof_collect": (C.c_int, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "slam2d_prof_disable": (None, []),

@@ -106,6 +106,7 @@ __global__ void k_frame_setup(Slam2dLidar lid, Slam2dLevel lv, const Slam2dMap* 
     fr.field_min = lv.floor_value; fr.redo = 0; fr._pad = 0;
     fr.min_bits = ~0ull;
     lv.frames[p] = fr;
+    lv.tilecount[2 * p] = 0; lv.tilecount[2 * p + 1] = 0;
     if (f) atomicOr(&flags[p], f);
 }
 
@@ -132,44 +133,50 @@ __global__ void k_axis_index(Slam2dLevel lv, const Slam2dMap* __restrict__ maps,
 // K2c  occupied map cells -> occupied field cells  (Utils/ScanMatcher_OGBased.py:29-37)
 //      HBM-bound: streams the map window once (4 B / map cell), byte scatter into occ.
 // ------------------------------------------------------------------------------------
-#define SCATTER_ROWS 32
+// The occupied / free state of every map cell is kept as one bit (Slam2dMap.occ_bits, maintained by
+// the update kernel), so the field build reads 1/32 of the bytes the count map holds.
+// One thread = one 32-cell word of the map window.
 __global__ __launch_bounds__(256) void k_occ_scatter(Slam2dLevel lv, const Slam2dMap* __restrict__ maps) {
     const int p = blockIdx.z;
     const Slam2dFrame fr = lv.frames[p];
-    // one thread = 4 consecutive map columns (one 16-byte load; rows are 64-byte aligned) x 8 rows
-    const int col0 = (fr.mx0 & ~3) + 4 * (blockIdx.x * 64 + threadIdx.x);
-    if (col0 >= fr.mx1) return;
+    const int w0 = fr.mx0 >> 5;
+    const int w = w0 + blockIdx.x * 64 + threadIdx.x;
+    const int i = blockIdx.y * 4 + threadIdx.y;
+    if (w > ((fr.mx1 - 1) >> 5) || i >= fr.my1 - fr.my0 || fr.mx1 <= fr.mx0) return;
     const Slam2dMap m = maps[p];
+    uint32_t word = m.occ_bits[(size_t)(fr.my0 + i) * m.bits_pitch + w];
+    if (!word) return;
+    const int col_base = w << 5;
+    if (col_base < fr.mx0) word &= ~0u << (fr.mx0 - col_base);                    // window edges
+    if (col_base + 32 > fr.mx1) word &= ~0u >> (col_base + 32 - fr.mx1);
     uint8_t* occ = lv.occ + (size_t)p * lv.fmax * lv.fpitch;
     uint8_t* tiles = lv.tilemask + (size_t)p * lv.tmax * lv.tmax;
     const int32_t* __restrict__ ax = lv.axis_x + (size_t)p * lv.wmax;
-    const int32_t* __restrict__ ay = lv.axis_y + (size_t)p * lv.wmax;
-    const int i0 = blockIdx.y * SCATTER_ROWS + threadIdx.y;
-    const int nrow = fr.my1 - fr.my0;
-    if (nrow <= 0) return;
-    constexpr int NR = SCATTER_ROWS / 4;
-    uint4 c4[NR];
-#pragma unroll
-    for (int rr = 0; rr < NR; ++rr) {          // all loads first: 8 x 16 B in flight per lane
-        const int i = min(i0 + rr * 4, nrow - 1);
-        c4[rr] = *reinterpret_cast<const uint4*>(m.cells + (size_t)(fr.my0 + i) * m.pitch + col0);
-    }
-#pragma unroll
-    for (int rr = 0; rr < NR; ++rr) {
-        const int i = i0 + rr * 4;
-        if (i >= nrow) break;
-        const uint32_t c[4] = {c4[rr].x, c4[rr].y, c4[rr].z, c4[rr].w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int col = col0 + e;
-            if (col >= fr.mx0 && col < fr.mx1 && 2u * (c[e] >> 16) > (c[e] & 0xffffu)) {       // :29-31
-                const int fx = ax[col - fr.mx0], fy = ay[i];
-                if (fx >= 0 && fy >= 0) {
-                    occ[(size_t)fy * lv.fpitch + fx] = 1;
-                    tiles[(fy >> 5) * lv.tmax + (fx >> 5)] = 1;
-                }
-            }
+    const int fy = lv.axis_y[(size_t)p * lv.wmax + i];
+    while (word) {
+        const int bit = __ffs(word) - 1;
+        word &= word - 1;
+        const int fx = ax[col_base + bit - fr.mx0];
+        if (fx >= 0 && fy >= 0) {                                                  // :36-37
+            occ[(size_t)fy * lv.fpitch + fx] = 1;
+            tiles[(fy >> 5) * lv.tmax + (fx >> 5)] = 1;
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_refresh_bits(const Slam2dMap* __restrict__ maps, const int32_t* __restrict__ index) {
+    const Slam2dMap m = maps[index ? index[blockIdx.y] : blockIdx.y];
+    const long long nwords = (long long)m.rows * m.bits_pitch;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < nwords; t += (long long)gridDim.x * 256) {
+        const int row = (int)(t / m.bits_pitch), w = (int)(t - (long long)row * m.bits_pitch);
+        uint32_t word = 0;
+        const uint32_t* c = m.cells + (size_t)row * m.pitch + (w << 5);
+        const int n = min(32, m.cols - (w << 5));
+        for (int b = 0; b < n; ++b) {
+            const uint32_t v = c[b];
+            if (2u * (v >> 16) > (v & 0xffffu)) word |= 1u << b;                   // :29-31
+        }
+        m.occ_bits[t] = word;
     }
 }
 
@@ -182,6 +189,7 @@ __global__ __launch_bounds__(256) void k_occ_scatter(Slam2dLevel lv, const Slam2
 //      mode 1 redoes the clamp with the measured minimum otherwise.
 // ------------------------------------------------------------------------------------
 #define BLUR_TILE 32
+#define SLAM2D_BLUR_BLOCKS_PER_PARTICLE 96
 #define BLUR_EXT (BLUR_TILE + 2 * SLAM2D_MAX_BLUR_RADIUS)
 // RAD > 0: radius known at compile time (register sliding windows, fully unrolled, LDS sized
 // for it); RAD == 0: any radius up to SLAM2D_MAX_BLUR_RADIUS (loops over LDS).
@@ -202,7 +210,7 @@ struct BlurLds {
 
 template <int RAD>
 __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& sm, const int p, const Slam2dFrame& fr,
-                                          const int tby, const int tbx, const int mode) {
+                                          const int tby, const int tbx, const int mode, const bool use_flags) {
     const int fh = fr.fh, fw = fr.fw;
     const int ty0 = tby * BLUR_TILE, tx0 = tbx * BLUR_TILE;
     if (ty0 >= fh || tx0 >= fw) return;
@@ -212,8 +220,9 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
     const uint8_t* occ = lv.occ + (size_t)p * lv.fmax * lv.fpitch;
     uint8_t* state = lv.tilestate + ((size_t)p * lv.tmax + tby) * lv.tmax + tbx;
     // activity: an occupied cell within the halo (r <= 16 < 32) lies in one of the 3x3 tiles around
-    int any = 0;
-    {
+    int any = 1;
+    if (use_flags) {
+        any = 0;
         const uint8_t* tiles = lv.tilemask + (size_t)p * lv.tmax * lv.tmax;
         const int nty = (fh + 31) >> 5, ntx = (fw + 31) >> 5;
         if (tid < 9) {
@@ -353,13 +362,70 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
     }
 }
 
-// One tile per block.
+// Tile triage, one thread per 32x32 field tile: tiles with an occupied cell in their 3x3 tile
+// neighbourhood go to the blur work list; free tiles get their minimum recorded and, if the
+// field buffer does not already hold the free-space constant there, go to the fill list.
+// (Per-wave aggregated atomics: a wave's tiles belong to one particle.)
+__global__ __launch_bounds__(256) void k_tile_classify(Slam2dLevel lv) {
+    const int p = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const Slam2dFrame fr = lv.frames[p];
+    const int nty = (fr.fh + 31) >> 5, ntx = (fr.fw + 31) >> 5;
+    const int ty = t / lv.tmax, tx = t - ty * lv.tmax;
+    if (ty >= nty || tx >= ntx) return;
+    const uint8_t* tiles = lv.tilemask + (size_t)p * lv.tmax * lv.tmax;
+    int any = 0;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int yy = ty + dy, xx = tx + dx;
+            if (yy >= 0 && yy < nty && xx >= 0 && xx < ntx) any |= tiles[yy * lv.tmax + xx];
+        }
+    int* count = lv.tilecount + 2 * p;
+    int* list = lv.tilelist + (size_t)p * 2 * lv.tmax * lv.tmax;
+    if (any) {
+        list[atomicAdd(&count[0], 1)] = t;
+    } else {
+        lv.tilemin[(size_t)p * lv.tmax * lv.tmax + t] = lv.floor_value;
+        uint8_t* state = lv.tilestate + (size_t)p * lv.tmax * lv.tmax + t;
+        if (*state) { *state = 0; list[lv.tmax * lv.tmax + atomicAdd(&count[1], 1)] = t; }
+    }
+}
+
+// Free tiles whose buffer content is stale: store the free-space constant (whole 32x32 tile, also
+// beyond the current frame, so that the tile stays valid when the frame grows by its +-1 jitter).
+__global__ __launch_bounds__(256) void k_tile_fill(Slam2dLevel lv) {
+    const int p = blockIdx.y, tid = threadIdx.x;
+    const int n = lv.tilecount[2 * p + 1];
+    const int* list = lv.tilelist + (size_t)p * 2 * lv.tmax * lv.tmax + lv.tmax * lv.tmax;
+    const double v = lv.floor_value;
+    const uint32_t c = v > 0.5 * v ? 0u : (uint32_t)rint(-v * lv.cost_scale);
+    uint32_t* field = lv.field + (size_t)p * lv.fmax * lv.fpitch;
+    for (int b = blockIdx.x; b < n; b += gridDim.x) {
+        const int t = list[b];
+        const int ty0 = (t / lv.tmax) * BLUR_TILE, tx0 = (t % lv.tmax) * BLUR_TILE;
+        for (int idx = tid; idx < BLUR_TILE * BLUR_TILE / 4; idx += 256) {
+            const int y = idx / (BLUR_TILE / 4), x = (idx - y * (BLUR_TILE / 4)) * 4;
+            if (ty0 + y < lv.fmax && tx0 + x + 3 < lv.fpitch)
+                *reinterpret_cast<uint4*>(field + (size_t)(ty0 + y) * lv.fpitch + tx0 + x) = make_uint4(c, c, c, c);
+        }
+    }
+}
+
+// Blur of the work list: gridDim.x blocks per particle walk that particle's active tiles.
 template <int RAD>
 __global__ __launch_bounds__(256) void k_blur_clamp(Slam2dLevel lv) {
     __shared__ BlurLds<RAD> sm;
-    const int p = blockIdx.z;
+    const int p = blockIdx.y;
+    const int n = lv.tilecount[2 * p];
+    if ((int)blockIdx.x >= n) return;
     const Slam2dFrame fr = lv.frames[p];
-    blur_tile<RAD>(lv, sm, p, fr, blockIdx.y, blockIdx.x, 0);
+    const int* list = lv.tilelist + (size_t)p * 2 * lv.tmax * lv.tmax;
+    for (int b = blockIdx.x; b < n; b += gridDim.x) {
+        const int t = list[b];
+        blur_tile<RAD>(lv, sm, p, fr, t / lv.tmax, t % lv.tmax, 0, false);
+    }
 }
 
 // Clamp redo with the measured minimum (rare: only when no cell of the field has an all-free
@@ -372,7 +438,7 @@ __global__ __launch_bounds__(256) void k_blur_redo(Slam2dLevel lv) {
     if (!fr.redo) return;
     const int nty = (fr.fh + 31) >> 5, ntx = (fr.fw + 31) >> 5;
     for (int t = 0; t < nty * ntx; ++t) {
-        blur_tile<RAD>(lv, sm, p, fr, t / ntx, t % ntx, 1);
+        blur_tile<RAD>(lv, sm, p, fr, t / ntx, t % ntx, 1, true);
         __syncthreads();
     }
 }
@@ -802,7 +868,13 @@ __global__ __launch_bounds__(256) void k_grid_update(Slam2dLidar lid, const Slam
     for (int k = 0; k < NR; ++k) {
         if (!inc[k]) continue;
         if ((c[k] & 0xffffu) + (inc[k] & 0xffffu) > 0xffffu) { f |= SLAM2D_F_COUNT_OVERFLOW; continue; }
-        m.cells[(size_t)my[k] * m.pitch + mxk[k]] = c[k] + inc[k];
+        const uint32_t nc = c[k] + inc[k];
+        m.cells[(size_t)my[k] * m.pitch + mxk[k]] = nc;
+        const bool was = 2u * (c[k] >> 16) > (c[k] & 0xffffu), is = 2u * (nc >> 16) > (nc & 0xffffu);
+        if (was != is) {                                                          // keep the occupancy bit in step
+            uint32_t* word = m.occ_bits + (size_t)my[k] * m.bits_pitch + (mxk[k] >> 5);
+            if (is) atomicOr(word, 1u << (mxk[k] & 31)); else atomicAnd(word, ~(1u << (mxk[k] & 31)));
+        }
     }
     if (f) atomicOr(&flags[p], f);
 }
@@ -915,16 +987,20 @@ int slam2d_field_build(const Slam2dLidar* lidar, const Slam2dLevel* level, const
     const Slam2dLevel& lv = *level;
     k_frame_setup<<<cdiv(P, 64), 64, 0, s>>>(*lidar, lv, d_maps, P, d_centre, centre_stride, d_flags);
     k_axis_index<<<dim3(cdiv(lv.wmax, 256), P, 2), 256, 0, s>>>(lv, d_maps, d_flags);
-    if (lv.tilemask != lv.occ + (size_t)P * lv.fmax * lv.fpitch || !lv.tilestate || !lv.tilemin) return SLAM2D_E_BADARG;
+    if (lv.tilemask != lv.occ + (size_t)P * lv.fmax * lv.fpitch || !lv.tilestate || !lv.tilemin || !lv.tilelist || !lv.tilecount)
+        return SLAM2D_E_BADARG;
     hipError_t e = hipMemsetAsync(lv.occ, 0, (size_t)P * lv.fmax * lv.fpitch + (size_t)P * lv.tmax * lv.tmax, s);
     if (e != hipSuccess) return (int)e;
     {
         StageScope prof(SLAM2D_STAGE_SCATTER, s);
-        k_occ_scatter<<<dim3(cdiv(lv.wmax + 3, 256), cdiv(lv.wmax, SCATTER_ROWS), P), dim3(64, 4), 0, s>>>(lv, d_maps);
+        k_occ_scatter<<<dim3(cdiv(cdiv(lv.wmax, 32) + 1, 64), cdiv(lv.wmax, 4), P), dim3(64, 4), 0, s>>>(lv, d_maps);
     }
-    const dim3 bgrid(cdiv(lv.fmax, BLUR_TILE), cdiv(lv.fmax, BLUR_TILE), P);
+    const int ntile = lv.tmax * lv.tmax;
+    k_tile_classify<<<dim3(cdiv(ntile, 256), P), 256, 0, s>>>(lv);
+    k_tile_fill<<<dim3(min(ntile, 32), P), 256, 0, s>>>(lv);
     {
         StageScope prof(SLAM2D_STAGE_BLUR, s);
+        const dim3 bgrid(min(ntile, SLAM2D_BLUR_BLOCKS_PER_PARTICLE), P);
         switch (lv.blur_radius) {
             case 2: k_blur_clamp<2><<<bgrid, 256, 0, s>>>(lv); break;
             case 8: k_blur_clamp<8><<<bgrid, 256, 0, s>>>(lv); break;
@@ -1019,6 +1095,12 @@ int slam2d_gather_maps(const Slam2dMap* d_src, const Slam2dMap* d_dst, const int
     if (!d_src || !d_dst || !d_index || P <= 0 || cells_per_map <= 0) return SLAM2D_E_BADARG;
     const int gx = (int)((cells_per_map + 256 * 8 - 1) / (256 * 8));
     k_gather_maps<<<dim3(gx < 1 ? 1 : gx, P), 256, 0, (hipStream_t)stream>>>(d_src, d_dst, d_index);
+    return launch_status();
+}
+
+int slam2d_map_refresh_bits(const Slam2dMap* d_maps, const int32_t* d_index, int32_t n, void* stream) {
+    if (!d_maps || n <= 0) return SLAM2D_E_BADARG;
+    k_refresh_bits<<<dim3(256, n), 256, 0, (hipStream_t)stream>>>(d_maps, d_index);
     return launch_status();
 }
 

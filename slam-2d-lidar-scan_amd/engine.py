@@ -188,6 +188,7 @@ class MapState:
         if cells is None:
             cells = torch.full((self.rows, self.pitch), _lib.INIT_CELL, dtype=torch.int32, device=device)
         self.cells = cells
+        self._alloc_bits()
         self._sync_coords()
         self.growth_log = []
 
@@ -203,6 +204,13 @@ class MapState:
         Y = np.linspace(-xNum * unit / 2, xNum * unit / 2, num=yNum + 1) + initXY['y']
         return cls(X, Y, device)
 
+    def _alloc_bits(self):
+        """1 bit per cell (occupied), [rows][bits_pitch] words; rebuilt on the device by
+        ParticleEngine.refresh_bits() whenever the host wrote `cells` (bits_valid False)."""
+        self.bits_pitch = -(-self.cols // 32)
+        self.bits = torch.zeros((self.rows, self.bits_pitch), dtype=torch.int32, device=self.device)
+        self.bits_valid = False
+
     def _sync_coords(self):
         self.lim_x = [self.X[0], self.X[-1]]           # mapXLim (:19, :86-87)
         self.lim_y = [self.Y[0], self.Y[-1]]           # mapYLim (:20, :88-89)
@@ -211,8 +219,9 @@ class MapState:
 
     def desc(self):
         return Slam2dMap(cells=self.cells.data_ptr(), X=self.dX.data_ptr(), Y=self.dY.data_ptr(),
-                         rows=self.rows, cols=self.cols, pitch=self.pitch, _pad=0,
-                         lim_x0=self.lim_x[0], lim_x1=self.lim_x[1], lim_y0=self.lim_y[0], lim_y1=self.lim_y[1])
+                         rows=self.rows, cols=self.cols, pitch=self.pitch, bits_pitch=self.bits_pitch,
+                         lim_x0=self.lim_x[0], lim_x1=self.lim_x[1], lim_y0=self.lim_y[0], lim_y1=self.lim_y[1],
+                         occ_bits=self.bits.data_ptr())
 
     # -- growth: expandOccupancyGridHelper (:59-89) --
     def _side_to_grow(self, x, y):                                            # :108-118
@@ -259,6 +268,7 @@ class MapState:
         cells[shift[1]:shift[1] + rows, shift[0]:shift[0] + cols] = self.cells[:, :cols]
         self.cells, self.X, self.Y = cells, X, Y
         self.rows, self.cols, self.pitch = nrows, ncols, pitch
+        self._alloc_bits()
         self._sync_coords()
         self.growth_log.append((side, n))
         return shift
@@ -293,6 +303,7 @@ class MapState:
             raise ValueError("counts must be integers in [0, 65535]")
         packed = (v.astype(np.uint32) << np.uint32(16)) | t.astype(np.uint32)
         self.cells[:, :self.cols] = torch.from_numpy(packed.view(np.int32)).to(self.device)
+        self.bits_valid = False
 
     def clone(self):
         m = MapState.__new__(MapState)
@@ -300,6 +311,7 @@ class MapState:
         m.X, m.Y = self.X.copy(), self.Y.copy()
         m.rows, m.cols, m.pitch = self.rows, self.cols, self.pitch
         m.cells = self.cells.clone()
+        m.bits_pitch, m.bits, m.bits_valid = self.bits_pitch, self.bits.clone(), self.bits_valid
         m._sync_coords()
         m.growth_log = list(self.growth_log)
         return m
@@ -362,6 +374,8 @@ class SearchLevel:
             partials=torch.zeros((P, self.npartial, C.sizeof(Slam2dPartial)), dtype=torch.uint8, device=device),
             tilestate=torch.ones((P, self.tmax, self.tmax), dtype=torch.uint8, device=device),   # all dirty
             tilemin=torch.zeros((P, self.tmax, self.tmax), dtype=f64, device=device),
+            tilelist=torch.zeros((P, 2, self.tmax * self.tmax), dtype=i32, device=device),
+            tilecount=torch.zeros((P, 2), dtype=i32, device=device),
             # optional table-driven axis-0 pass; measured slower than the arithmetic on MI355X
             # (178 vs 164 us at config 2: the kernel is latency-, not ALU-bound), so off by default
             vtable=(_dev(column_pass_table(self.log_miss, self.taps, self.blur_radius), device)
@@ -378,7 +392,8 @@ class SearchLevel:
             cells=t["cells"].data_ptr(), kcount=t["kcount"].data_ptr(), prior=t["prior"].data_ptr(),
             cube=t["cube"].data_ptr(), partials=t["partials"].data_ptr(), npartial=self.npartial, tmax=self.tmax,
             tilemask=t["occ"].data_ptr() + P * self.fmax * self.fpitch, tilestate=t["tilestate"].data_ptr(),
-            tilemin=t["tilemin"].data_ptr(), vtable=t["vtable"].data_ptr() if t["vtable"] is not None else None)
+            tilemin=t["tilemin"].data_ptr(), tilelist=t["tilelist"].data_ptr(),
+            tilecount=t["tilecount"].data_ptr(), vtable=t["vtable"].data_ptr() if t["vtable"] is not None else None)
 
     # -- results --
     def frames(self):
@@ -443,6 +458,18 @@ class ParticleEngine:
 
     def refresh_maps(self):
         self.d_maps = upload_map_descs(self.maps, self.device)
+        self.refresh_bits()
+
+    def refresh_bits(self):
+        """Rebuild the occupancy bits of every map the host has written since the last build."""
+        stale = [i for i, m in enumerate(self.maps) if not m.bits_valid]
+        if not stale:
+            return
+        idx = _dev(np.asarray(stale, dtype=np.int32), self.device)
+        check(self.L.slam2d_map_refresh_bits(_ptr(self.d_maps), _ptr(idx), len(stale), _stream()),
+              "slam2d_map_refresh_bits")
+        for i in stale:
+            self.maps[i].bits_valid = True
 
     def match_buffer(self, name):
         if name not in self.match_buf:
@@ -455,6 +482,7 @@ class ParticleEngine:
 
     # -- kernels --
     def field_build(self, level, d_centre, stride):
+        self.refresh_bits()
         check(self.L.slam2d_field_build(C.byref(self.lidar_c), C.byref(level.c), _ptr(self.d_maps), self.P,
                                         _ptr(d_centre), stride, _ptr(self.flags), _stream()), "slam2d_field_build")
 
@@ -464,6 +492,7 @@ class ParticleEngine:
                                   _ptr(d_out), _ptr(self.flags), _stream()), "slam2d_sweep")
 
     def grid_update(self, d_pose, stride, d_ranges, d_beam_shift=None):
+        self.refresh_bits()
         check(self.L.slam2d_grid_update(C.byref(self.lidar_c), _ptr(self.d_maps), self.P, _ptr(d_pose), stride,
                                         _ptr(d_ranges), _ptr(self.axis_scratch), _ptr(d_beam_shift),
                                         _ptr(self.flags), _stream()), "slam2d_grid_update")

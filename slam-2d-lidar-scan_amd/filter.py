@@ -193,7 +193,7 @@ class ParticleFilter:
             self._grow_for_windows(est[:, 0], est[:, 1], self.coarse.reach)
         eng.field_build(self.coarse, d_est, 3)
         eng.sweep(self.coarse, d_est, 3, d_rng, dist, d_psi, d_u, self.m_coarse)
-        if self.growable:
+        if self.growable and not self._fine_window_cannot_grow(est, (self.coarse.ncell + 1) * self.coarse.step):
             eng.take_flags()
             c = eng.read_matches(self.m_coarse)
             self._grow_for_windows(c["x"], c["y"], self.fine.reach)
@@ -206,13 +206,30 @@ class ParticleFilter:
         return matched, c["confidence"].copy(), c["log_confidence"].copy()
 
     def _grow_for_windows(self, xs, ys, reach):
+        """checkAndExapndOG of every particle's search window (ScanMatcher_OGBased.py:27).  The
+        common case (window inside the map) is decided with four float compares per particle."""
         grew = False
         for m, x, y in zip(self.engine.maps, xs, ys):
+            lx, ly = m.lim_x, m.lim_y
+            if x - reach >= lx[0] and x + reach <= lx[1] and y - reach >= ly[0] and y + reach <= ly[1]:
+                continue
             n = len(m.growth_log)
             m.ensure_contains([x - reach, x + reach], [y - reach, y + reach], self.lidar.unit)
             grew |= len(m.growth_log) != n
         if grew:
             self.engine.refresh_maps()
+        return grew
+
+    def _fine_window_cannot_grow(self, est, margin):
+        """True when every particle's coarse window, widened by `margin` (the largest coarse
+        displacement), lies inside its map: the fine window then needs no growth whatever the
+        coarse result is, and the mid-scan synchronisation can be skipped."""
+        reach = self.coarse.reach + margin
+        for m, (x, y, _) in zip(self.engine.maps, est):
+            lx, ly = m.lim_x, m.lim_y
+            if not (x - reach >= lx[0] and x + reach <= lx[1] and y - reach >= ly[0] and y + reach <= ly[1]):
+                return False
+        return True
 
     def _grow_for_update(self, matched):
         """The update window (pose +/- R) lies inside the search window that was grown for
@@ -230,7 +247,10 @@ class ParticleFilter:
         _lib.check(L.slam2d_weights_normalize(_ptr(self.d_logw), None, self.numParticles, _ptr(self.d_w),
                                               _ptr(self.d_stats), _stream()), "slam2d_weights_normalize")
         self.weights = self.d_w.cpu().numpy()
-        self.last_variance = float(self.d_stats[0].item())
+        # sum (w_i - 1/N)^2 in the reference's sequential order (:32-35): its resample trigger sits at
+        # total degeneracy, where the outcome is decided by the rounding of this very sum
+        n = self.numParticles
+        self.last_variance = float(np.cumsum((self.weights - 1 / n) ** 2)[-1])
 
     def weightUnbalanced(self):
         self.normalizeWeights()

@@ -73,11 +73,12 @@ class OccupancyGrid:
 
     # ---- engine (one particle) ----
     def engine(self):
-        if self._engine is None or self._engine_version != self.version:
-            if self._engine is None:
-                self._engine = ParticleEngine(self.lidar, [self.map], self.device)
-            else:
-                self._engine.refresh_maps()
+        if self._engine is None:
+            self._engine = ParticleEngine(self.lidar, [self.map], self.device)
+            self._engine_version = self.version
+        elif self._engine_version != self.version or self._engine.maps[0] is not self.map:
+            self._engine.maps = [self.map]
+            self._engine.refresh_maps()
             self._engine_version = self.version
         return self._engine
 
