@@ -153,8 +153,7 @@ typedef struct {
     int32_t* axis_y;         /* [P][wmax] */
     uint8_t* occ;            /* [P][fmax][fpitch] occupied field cells; then [P][tmax][tmax] tile flags */
     uint32_t* field;         /* [P][fmax][fpitch]  fixed-point cost of probSP (see above) */
-    int32_t* cells;          /* [P][ntheta][kmax] unique endpoint cells: patch corner (y0 << 16 | x0), sorted
-                                by 64x64 field tile, then row, then column */
+    int32_t* cells;          /* [P][ntheta][kmax] unique endpoint cells (patch-corner offsets) */
     int32_t* kcount;         /* [P][ntheta] */
     double*  prior;          /* [P][2][ny][nx]  rv plane, thetaWeight plane */
     double*  cube;           /* [P][ntheta][ny][nx] convTotal */
@@ -168,10 +167,6 @@ typedef struct {
                                 Initialise to 1; set to 1 whenever the field buffer is written by
                                 anything other than slam2d_field_build */
     double*  tilemin;        /* [P][tmax][tmax] scratch: per-tile minimum of the blurred field */
-    int32_t* tiledir;        /* NULL, or [P][ntheta][t64*t64][2]: (first list position, count) of the cells of
-                                every 64x64 field tile -- enables the LDS-staged sweep */
-    int32_t  t64;            /* ceil(fmax / 64) */
-    int32_t  _pad2;
     int32_t* tilelist;       /* [P][2][tmax*tmax] scratch: work lists (tiles to blur, tiles to fill) */
     int32_t* tilecount;      /* [P][2] scratch: their lengths */
     const double* vtable;    /* NULL, or [2^(2*blur_radius+1)] axis-0 blur result of every binary column

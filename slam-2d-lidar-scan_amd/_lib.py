@@ -81,7 +81,7 @@ class Slam2dLevel(C.Structure):
                 ("cells", _vp), ("kcount", _vp), ("prior", _vp), ("cube", _vp),
                 ("partials", _vp), ("npartial", C.c_int32), ("tmax", C.c_int32), ("tilemask", _vp),
                 ("tilestate", _vp), ("tilemin", _vp),
-                ("tiledir", _vp), ("t64", C.c_int32), ("_pad2", C.c_int32), ("tilelist", _vp), ("tilecount", _vp), ("vtable", _vp)]
+                ("tilelist", _vp), ("tilecount", _vp), ("vtable", _vp)]
 
 
 class Slam2dMatch(C.Structure):

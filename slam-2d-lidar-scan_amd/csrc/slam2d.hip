@@ -468,13 +468,10 @@ __global__ __launch_bounds__(256) void k_floor_check(Slam2dLevel lv, int P, uint
 //      A cell is stored as the offset of the corner of its (2*ncell+1)^2 patch:
 //      (cy - ncell) * fpitch + (cx - ncell).
 // ------------------------------------------------------------------------------------
-#define SWEEP_TILE 64                 // field tile edge of the LDS-staged sweep
-#define SWEEP_MAX_TILES 1024          // directory capacity per (particle, theta): (fmax/64)^2 must fit
 __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel lv, const double* __restrict__ est,
                                                    int estride, const double* __restrict__ ranges, uint32_t* flags) {
     __shared__ int keys[SLAM2D_MAX_BEAMS];
     __shared__ int cnt_s[257];
-    __shared__ int tcount[SWEEP_MAX_TILES];
     const int it = blockIdx.x, p = blockIdx.y, tid = threadIdx.x;
     const Slam2dFrame fr = lv.frames[p];
     const double ex = est[(size_t)p * estride], ey = est[(size_t)p * estride + 1], eth = est[(size_t)p * estride + 2];
@@ -486,9 +483,6 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
     const double astep = (a1 - a0) / (double)(B - 1);
     const double c = lv.theta_cos[it], s = lv.theta_sin[it];
     const int nc = lv.ncell;
-    const int t64 = lv.t64, ntile = t64 * t64;
-    const bool use_dir = lv.tiledir != nullptr && ntile <= SWEEP_MAX_TILES;
-    if (use_dir) for (int t = tid; t < ntile; t += 256) tcount[t] = 0;
     bool bad = false;
     for (int b = tid; b < n; b += 256) {
         int key = INT_MAX;
@@ -504,8 +498,7 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
                 const int cy = (int)((qy - fr.ylo) / lv.step);                      // :175
                 const int x0 = cx - nc, y0 = cy - nc;
                 if (x0 < 0 || y0 < 0 || cx + nc >= fr.fw || cy + nc >= fr.fh) bad = true;
-                // sort key: 64x64 field tile first, then row, then column inside the tile
-                else key = (((y0 >> 6) * t64 + (x0 >> 6)) << 12) | ((y0 & 63) << 6) | (x0 & 63);
+                else key = y0 * lv.fpitch + x0;
             }
         }
         keys[b] = key;
@@ -542,15 +535,7 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
     for (int q = 0; q < chunk; ++q) {
         const int i = tid * chunk + q;
         const int k = keys[i];
-        if (k != INT_MAX && (i == 0 || k != keys[i - 1])) {
-            if (pos < lv.kmax) {
-                const int tile = k >> 12;
-                const int y0 = ((tile / t64) << 6) | ((k >> 6) & 63), x0 = ((tile % t64) << 6) | (k & 63);
-                out[pos] = (y0 << 16) | x0;                 // patch corner, packed
-                if (use_dir) atomicAdd(&tcount[tile], 1);
-            }
-            ++pos;
-        }
+        if (k != INT_MAX && (i == 0 || k != keys[i - 1])) { if (pos < lv.kmax) out[pos] = k; ++pos; }
     }
     if (tid == 0) {
         int K = cnt_s[256];
@@ -558,22 +543,6 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
         lv.kcount[p * lv.ntheta + it] = K;
     }
     if (bad) atomicOr(&flags[p], SLAM2D_F_ENDPOINT_OUTSIDE);
-    if (use_dir) {      // directory: first list position and number of cells of every 64x64 tile
-        __syncthreads();
-        int* dir = lv.tiledir + ((size_t)p * lv.ntheta + it) * ntile * 2;
-        // exclusive scan of tcount over tiles, 256 threads x contiguous runs
-        const int per = (ntile + 255) / 256;
-        const int t0 = tid * per, t1 = min(ntile, t0 + per);
-        int sum = 0;
-        for (int t = t0; t < t1; ++t) sum += tcount[t];
-        cnt_s[tid + 1] = sum;
-        if (tid == 0) cnt_s[0] = 0;
-        __syncthreads();
-        if (tid == 0) for (int t = 1; t <= 256; ++t) cnt_s[t] += cnt_s[t - 1];
-        __syncthreads();
-        int run = cnt_s[tid];
-        for (int t = t0; t < t1; ++t) { dir[2 * t] = run; dir[2 * t + 1] = tcount[t]; run += tcount[t]; }
-    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -676,8 +645,7 @@ __global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks
     }
 #pragma unroll 4
     for (int k = 0; k < K; ++k) {
-        const unsigned pc = (unsigned)cl[k];                                   // (y0 << 16) | x0
-        const int cell = (int)((pc >> 16) * (unsigned)lv.fpitch + (pc & 0xffffu)) * 4;
+        const int cell = cl[k] * 4;
         unsigned v[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) v[r] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsrc, off[r], cell, 0);
@@ -719,151 +687,6 @@ __global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks
         Slam2dPartial pt;
         pt.max = me.v; pt.sumexp = e; pt.argmax = me.i; pt.has_nan = me.nan;
         lv.partials[(size_t)p * lv.npartial + w] = pt;
-    }
-}
-
-// ------------------------------------------------------------------------------------
-// K1c'  pose-cube sweep with the field staged in LDS (large cubes)
-//      One block = (particle, TG consecutive thetas), 256 threads = every pose of the cube plane
-//      (R per thread), accumulators for all TG thetas in registers.  The block walks the 64x64
-//      field tiles that hold endpoint cells of any of its thetas: the tile plus its (2*ncell)
-//      halo is copied once into LDS with coalesced 16-byte loads, then every cell of that tile
-//      (all TG thetas) adds its patch from LDS.  Consecutive lanes hold consecutive poses of the
-//      flattened (dy, dx) plane and the LDS row pitch is congruent to nx modulo 32, so a
-//      32-lane group always reads 32 consecutive banks (conflict-free).  Cells were sorted
-//      tile-major by k_endpoints, which also wrote the (start, count) directory used here.
-// ------------------------------------------------------------------------------------
-template <int R, int TG>
-__global__ __launch_bounds__(256) void k_sweep_lds(Slam2dLevel lv, int P, int ngroups, int LP) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t region[];
-    const int b = blockIdx.x;
-    const int xcd = b & 7, slot = b >> 3;
-    const int p = (slot / ngroups) * 8 + xcd;
-    if (p >= P) return;
-    const int g = slot % ngroups;
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    const int nc = lv.ncell, nx = 2 * nc + 1, npose = nx * nx;
-    const int RH = SWEEP_TILE + 2 * nc;                    // region rows and (used) columns
-    const int t64 = lv.t64, ntile = t64 * t64;
-    const uint32_t* __restrict__ F = lv.field + (size_t)p * lv.fmax * lv.fpitch;
-    int poff[R];
-    unsigned lo[TG][R], hi[TG][R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int q = (wave * R + r) * WAVE + lane;
-        const int qq = q < npose ? q : 0;
-        const int iy = qq / nx;
-        poff[r] = iy * LP + (qq - iy * nx);
-#pragma unroll
-        for (int j = 0; j < TG; ++j) { lo[j][r] = 0u; hi[j][r] = 0u; }
-    }
-    const int th0 = g * TG;
-    const int* __restrict__ dir = lv.tiledir + ((size_t)p * lv.ntheta + th0) * ntile * 2;
-    const int rw4 = (RH + 3) >> 2;                         // 16-byte groups per region row
-    constexpr int NPF = 12;                                // 16-byte loads per thread per region (covers RH <= 110)
-    const int nload = RH * rw4;
-
-    // next non-empty tile at or after `from` for this theta group (block-uniform scalar walk)
-    auto next_tile = [&](int from) {
-        for (int t = from; t < ntile; ++t) {
-            int any = 0;
-#pragma unroll
-            for (int j = 0; j < TG; ++j)
-                if (th0 + j < lv.ntheta) any |= dir[((size_t)j * ntile + t) * 2 + 1];
-            if (any) return t;
-        }
-        return ntile;
-    };
-    // the region of tile t is fetched into registers one tile ahead of its use, so the global
-    // latency hides behind the gathers of the current tile
-    uint4 pf[NPF];
-    auto fetch = [&](int t) {
-        const int gy0 = (t / t64) * SWEEP_TILE, gx0 = (t % t64) * SWEEP_TILE;
-#pragma unroll
-        for (int u = 0; u < NPF; ++u) {
-            const int idx = tid + u * 256;
-            pf[u] = make_uint4(0u, 0u, 0u, 0u);
-            if (idx < nload) {
-                const int row = idx / rw4, c4 = (idx - row * rw4) * 4;
-                const int gy = gy0 + row, gx = gx0 + c4;
-                if (gy < lv.fmax && gx + 3 < lv.fpitch) pf[u] = *reinterpret_cast<const uint4*>(F + (size_t)gy * lv.fpitch + gx);
-            }
-        }
-    };
-    int t = next_tile(0);
-    if (t < ntile) fetch(t);
-    while (t < ntile) {
-        const int gy0 = (t / t64) * SWEEP_TILE, gx0 = (t % t64) * SWEEP_TILE;
-        __syncthreads();                                   // the previous region is no longer being read
-#pragma unroll
-        for (int u = 0; u < NPF; ++u) {
-            const int idx = tid + u * 256;
-            if (idx < nload) {
-                const int row = idx / rw4, c4 = (idx - row * rw4) * 4;
-                uint32_t* dst = region + row * LP + c4;
-                dst[0] = pf[u].x; dst[1] = pf[u].y; dst[2] = pf[u].z; dst[3] = pf[u].w;
-            }
-        }
-        __syncthreads();
-        const int tn = next_tile(t + 1);
-        if (tn < ntile) fetch(tn);                         // in flight while this tile is gathered
-#pragma unroll
-        for (int j = 0; j < TG; ++j) {
-            if (th0 + j >= lv.ntheta) break;
-            const int st = dir[((size_t)j * ntile + t) * 2], cn = dir[((size_t)j * ntile + t) * 2 + 1];
-            const int* __restrict__ cl = lv.cells + ((size_t)p * lv.ntheta + th0 + j) * lv.kmax + st;
-            for (int k = 0; k < cn; ++k) {
-                const unsigned pc = (unsigned)cl[k];
-                const int cb = ((int)(pc >> 16) - gy0) * LP + ((int)(pc & 0xffffu) - gx0);
-                unsigned v[R];
-#pragma unroll
-                for (int r = 0; r < R; ++r) v[r] = region[cb + poff[r]];
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const unsigned sum = lo[j][r] + v[r];
-                    hi[j][r] += sum < v[r] ? 1u : 0u;
-                    lo[j][r] = sum;
-                }
-            }
-        }
-        t = tn;
-    }
-    // epilogue per theta: scores, cube, per-wave partials (chunks = 4: one per wave)
-    const double inv = 1.0 / lv.cost_scale;
-    const double* __restrict__ pr = lv.prior + (size_t)p * 2 * npose;
-#pragma unroll
-    for (int j = 0; j < TG; ++j) {
-        const int it = th0 + j;
-        if (it >= lv.ntheta) break;
-        double* __restrict__ out = lv.cube + ((size_t)p * lv.ntheta + it) * npose;
-        double sc[R];
-        Best me{-INFINITY, INT_MAX, 0};
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int q = (wave * R + r) * WAVE + lane;
-            sc[r] = -INFINITY;
-            if (q < npose) {
-                const unsigned long long acc = ((unsigned long long)hi[j][r] << 32) | lo[j][r];
-                const double sum = -((double)acc * inv);
-                sc[r] = (sum + pr[q]) + pr[npose + q];                             // :131
-                out[q] = sc[r];
-                Best cand{sc[r], it * npose + q, isnan(sc[r]) ? 1 : 0};
-                if (better(cand, me)) me = cand;
-            }
-        }
-        me = wave_best(me);
-        double e = 0.0;
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-            if ((wave * R + r) * WAVE + lane < npose) e += exp(sc[r] - me.v);
-        e = wave_sum(e);
-        if (lane == 0) {
-            Slam2dPartial pt;
-            pt.max = me.v; pt.sumexp = e; pt.argmax = me.i; pt.has_nan = me.nan;
-            lv.partials[(size_t)p * lv.npartial + it * 4 + wave] = pt;
-        }
     }
 }
 
@@ -1116,35 +939,6 @@ __global__ void k_fill(uint32_t* cells, long long n, uint32_t value) {
 // ------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------
-template <int R, int TG>
-static int launch_sweep_lds(const Slam2dLevel& lv, int P, int LP, size_t lds_bytes, hipStream_t s) {
-    static bool attr_set = false;       // per instantiation: allow > 48 KiB of dynamic LDS
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_lds<R, TG>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    const int ngroups = cdiv(lv.ntheta, TG);
-    k_sweep_lds<R, TG><<<cdiv(P, 8) * 8 * ngroups, 256, lds_bytes, s>>>(lv, P, ngroups, LP);
-    return 0;
-}
-
-template <int TG>
-static int dispatch_sweep_lds(int R, const Slam2dLevel& lv, int P, int LP, size_t lds_bytes, hipStream_t s) {
-    switch (R) {
-        case 1: return launch_sweep_lds<1, TG>(lv, P, LP, lds_bytes, s);
-        case 2: return launch_sweep_lds<2, TG>(lv, P, LP, lds_bytes, s);
-        case 3: return launch_sweep_lds<3, TG>(lv, P, LP, lds_bytes, s);
-        case 4: return launch_sweep_lds<4, TG>(lv, P, LP, lds_bytes, s);
-        case 5: return launch_sweep_lds<5, TG>(lv, P, LP, lds_bytes, s);
-        case 6: return launch_sweep_lds<6, TG>(lv, P, LP, lds_bytes, s);
-        case 7: return launch_sweep_lds<7, TG>(lv, P, LP, lds_bytes, s);
-        case 8: return launch_sweep_lds<8, TG>(lv, P, LP, lds_bytes, s);
-        default: return SLAM2D_E_TOOLARGE;
-    }
-}
-
 template <int R>
 static void launch_sweep(const Slam2dLevel& lv, int P, int chunks, hipStream_t s) {
     const int waves = lv.ntheta * chunks;
@@ -1237,62 +1031,31 @@ int slam2d_sweep(const Slam2dLidar* lidar, const Slam2dLevel* level, int32_t P, 
         k_endpoints<<<dim3(lv.ntheta, P), 256, 0, s>>>(*lidar, lv, d_est, est_stride, d_ranges, d_flags);
     }
     k_priors<<<dim3(cdiv(npose, 256), P), 256, 0, s>>>(lv, est_moving_dist, lv.fine ? nullptr : d_psi_cs);
-    // Large cube planes (>= 8 waves of poses): the LDS-staged sweep, one block per (particle, TG
-    // thetas), every pose of the plane in the block (R = ceil(npose / 256) per thread, 4 chunks).
-    // Small planes (fine level): one wave per 64*R poses, field read through L1/L2.
+    // poses per lane R: the k loop costs ~(R + 1) issue slots per cell and wave (R gathers + the
+    // scalar cell load / loop), so minimise chunks * (R + 1); ties go to the larger R
     const int need = cdiv(npose, WAVE);
-    int TG = 0;
-    if (lv.tiledir != nullptr && lv.t64 * lv.t64 <= SWEEP_MAX_TILES && need >= 8 && cdiv(npose, 256) <= 8) TG = 3;
-    if (const char* ov = getenv("SLAM2D_SWEEP_TG")) {             // tuning knob: 0 = direct sweep
-        const int v = atoi(ov);
-        if (v == 0 || (TG != 0 && (v == 2 || v == 3 || v == 4))) TG = v;
+    int bestR = 1, bestCost = INT_MAX;
+    for (int R = 1; R <= 8; ++R) {
+        const int cost = cdiv(need, R) * (R + 1);
+        if (cost <= bestCost) { bestCost = cost; bestR = R; }
     }
-    int bestR, chunks;
-    if (TG) {
-        bestR = cdiv(npose, 256);
-        chunks = 4;
-    } else {
-        // poses per lane R: the k loop costs ~(R + 1) issue slots per cell and wave (R gathers + the
-        // scalar cell load / loop), so minimise chunks * (R + 1); ties go to the larger R
-        int bestCost = INT_MAX;
-        bestR = 1;
-        for (int R = 1; R <= 8; ++R) {
-            const int cost = cdiv(need, R) * (R + 1);
-            if (cost <= bestCost) { bestCost = cost; bestR = R; }
-        }
-        if (const char* ov = getenv("SLAM2D_SWEEP_R")) {          // tuning knob
-            const int R = atoi(ov);
-            if (R >= 1 && R <= 8) bestR = R;
-        }
-        chunks = cdiv(need, bestR);
+    if (const char* ov = getenv("SLAM2D_SWEEP_R")) {              // tuning knob
+        const int R = atoi(ov);
+        if (R >= 1 && R <= 8) bestR = R;
     }
+    const int chunks = cdiv(need, bestR);
     if (lv.ntheta * chunks > lv.npartial) return SLAM2D_E_BADARG;
     {
         StageScope prof(SLAM2D_STAGE_SWEEP, s);
-        if (TG) {
-            const int RH = SWEEP_TILE + 2 * lv.ncell;
-            int LP = ((RH + 3) & ~3) + 1;                          // >= the 16-byte-group padded row
-            while ((LP & 31) != (nx & 31)) ++LP;                   // LP == nx (mod 32): conflict-free row wrap
-            const size_t lds_bytes = (size_t)RH * LP * sizeof(uint32_t);
-            if (lds_bytes > 160 * 1024 - 256 || RH * ((RH + 3) / 4) > 12 * 256) return SLAM2D_E_TOOLARGE;
-            int rc2;
-            switch (TG) {
-                case 2: rc2 = dispatch_sweep_lds<2>(bestR, lv, P, LP, lds_bytes, s); break;
-                case 4: rc2 = dispatch_sweep_lds<4>(bestR, lv, P, LP, lds_bytes, s); break;
-                default: rc2 = dispatch_sweep_lds<3>(bestR, lv, P, LP, lds_bytes, s); break;
-            }
-            if (rc2) return rc2;
-        } else {
-            switch (bestR) {
-                case 1: launch_sweep<1>(lv, P, chunks, s); break;
-                case 2: launch_sweep<2>(lv, P, chunks, s); break;
-                case 3: launch_sweep<3>(lv, P, chunks, s); break;
-                case 4: launch_sweep<4>(lv, P, chunks, s); break;
-                case 5: launch_sweep<5>(lv, P, chunks, s); break;
-                case 6: launch_sweep<6>(lv, P, chunks, s); break;
-                case 7: launch_sweep<7>(lv, P, chunks, s); break;
-                default: launch_sweep<8>(lv, P, chunks, s); break;
-            }
+        switch (bestR) {
+            case 1: launch_sweep<1>(lv, P, chunks, s); break;
+            case 2: launch_sweep<2>(lv, P, chunks, s); break;
+            case 3: launch_sweep<3>(lv, P, chunks, s); break;
+            case 4: launch_sweep<4>(lv, P, chunks, s); break;
+            case 5: launch_sweep<5>(lv, P, chunks, s); break;
+            case 6: launch_sweep<6>(lv, P, chunks, s); break;
+            case 7: launch_sweep<7>(lv, P, chunks, s); break;
+            default: launch_sweep<8>(lv, P, chunks, s); break;
         }
     }
     {

@@ -354,7 +354,6 @@ class SearchLevel:
         npose = self.nx * self.nx
         self.npartial = self.ntheta * (-(-npose // 64))
         self.tmax = -(-self.fmax // 32)
-        self.t64 = -(-self.fmax // 64)
         i32, f64 = torch.int32, torch.float64
         t = self.t = dict(
             blur_w=_dev(self.taps, device),
@@ -377,8 +376,6 @@ class SearchLevel:
             tilemin=torch.zeros((P, self.tmax, self.tmax), dtype=f64, device=device),
             tilelist=torch.zeros((P, 2, self.tmax * self.tmax), dtype=i32, device=device),
             tilecount=torch.zeros((P, 2), dtype=i32, device=device),
-            tiledir=(torch.zeros((P, self.ntheta, self.t64 * self.t64, 2), dtype=i32, device=device)
-                     if self.t64 * self.t64 <= 1024 else None),
             # optional table-driven axis-0 pass; measured slower than the arithmetic on MI355X
             # (178 vs 164 us at config 2: the kernel is latency-, not ALU-bound), so off by default
             vtable=(_dev(column_pass_table(self.log_miss, self.taps, self.blur_radius), device)
@@ -395,8 +392,7 @@ class SearchLevel:
             cells=t["cells"].data_ptr(), kcount=t["kcount"].data_ptr(), prior=t["prior"].data_ptr(),
             cube=t["cube"].data_ptr(), partials=t["partials"].data_ptr(), npartial=self.npartial, tmax=self.tmax,
             tilemask=t["occ"].data_ptr() + P * self.fmax * self.fpitch, tilestate=t["tilestate"].data_ptr(),
-            tilemin=t["tilemin"].data_ptr(), tiledir=t["tiledir"].data_ptr() if t["tiledir"] is not None else None, t64=self.t64, _pad2=0,
-            tilelist=t["tilelist"].data_ptr(),
+            tilemin=t["tilemin"].data_ptr(), tilelist=t["tilelist"].data_ptr(),
             tilecount=t["tilecount"].data_ptr(), vtable=t["vtable"].data_ptr() if t["vtable"] is not None else None)
 
     # -- results --
@@ -428,8 +424,8 @@ class SearchLevel:
 
     def cells_of(self, p, it):
         k = int(self.t["kcount"][p, it].item())
-        packed = self.t["cells"][p, it, :k].cpu().numpy()
-        return (packed >> 16) + self.ncell, (packed & 0xFFFF) + self.ncell          # (cy, cx)
+        off = self.t["cells"][p, it, :k].cpu().numpy()
+        return off // self.fpitch + self.ncell, off % self.fpitch + self.ncell      # (cy, cx)
 
     def algorithmic_bytes(self, n_window_cells=None):
         """SURVEY.md 8(d) per particle-scan at this level: field build

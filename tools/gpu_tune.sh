@@ -4,9 +4,9 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -q --maxfail=60 -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
 echo "pytest rc=$?"; tail -n 5 gpurun_out/pytest_gpu.log
-for R in 0 2 3 4; do
-  export SLAM2D_SWEEP_TG=$R
-  echo "== SWEEP_TG=$R"
+for R in 0; do
+  if [ "$R" = "0" ]; then unset SLAM2D_SWEEP_R; else export SLAM2D_SWEEP_R=$R; fi
+  echo "== SWEEP_R=$R"
   timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json
 for line in sys.stdin:
@@ -14,7 +14,7 @@ for line in sys.stdin:
         d = json.loads(line); print('value', round(d['value']), 'ms/step', round(d['ms_per_step'],3), {k: v['avg_us'] for k, v in d['stages'].items()})
 "
 done
-unset SLAM2D_SWEEP_TG
+unset SLAM2D_SWEEP_R
 echo "== ref2level"
 timeout 300 python bench.py --workload ref2level --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json
