@@ -275,9 +275,11 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
     double lmin = INFINITY;
     // SciPy symmetric correlate1d order: out = a[c]*w[c]; for j=-r..-1: out += (a[c+j] + a[c-j]) * w[j]
     if constexpr (RAD > 0) {
-        {   // axis-0 pass: thread = (column lx, 8 consecutive rows)
-            const int lx = tid & 63, g = tid >> 6;
-            if (lx < ext) {
+        {   // axis-0 pass: thread = (column lx, 8 consecutive rows); the ext*4 threads that have work are
+            // packed into whole waves (ext = 48 -> 3 full waves, the 4th skips the phase)
+            constexpr int EXT_C = BLUR_TILE + 2 * RAD;
+            const int lx = tid % EXT_C, g = tid / EXT_C;
+            if (g < 4) {
                 if (lv.vtable != nullptr) {
                     // The axis-0 input is binary (free / occupied), so its result is a function of the
                     // (2r+1)-bit occupancy pattern of the column window: one lookup in a table that
@@ -612,7 +614,12 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-template <int R>
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// A "slot" is 4 consecutive dx of one dy row (the last slot of a row is partly padding); one lane
+// scores RQ slots, i.e. each gather is one 16-byte buffer load -- a quarter of the vector-memory
+// instructions of a dword-per-lane sweep for the same bytes.
+template <int RQ>
 __global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks, int bpp) {
     const int b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
@@ -624,68 +631,76 @@ __global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks
     if (w >= lv.ntheta * chunks) return;
     const int it = w / chunks, ch = w - it * chunks;
     const int nx = 2 * lv.ncell + 1, npose = nx * nx;
+    const int nq = (nx + 3) >> 2, nslot = nx * nq;
     const uint32_t* __restrict__ F = lv.field + (size_t)p * lv.fmax * lv.fpitch;
     const int* __restrict__ cl = lv.cells + ((size_t)p * lv.ntheta + it) * lv.kmax;
     const int K = lv.kcount[p * lv.ntheta + it];
-    const int q0 = ch * (WAVE * R) + lane;
+    const int u0 = ch * (WAVE * RQ) + lane;
     // Buffer addressing (SRSRC): address = field base + per-lane VGPR byte offset (constant
     // over k) + wave-uniform SGPR byte offset (the cell) -- no vector address arithmetic in
     // the loop, and out-of-range offsets read 0 instead of faulting.
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)F, (short)0, (int)((size_t)lv.fmax * lv.fpitch * sizeof(uint32_t)), 0x00020000);
-    int off[R];
-    unsigned lo[R], hi[R];               // exact 64-bit integer sum of fixed-point costs, as two
-#pragma unroll                           // 32-bit halves so every load lands in its own register
-    for (int r = 0; r < R; ++r) {
-        const int q = q0 + r * WAVE;
-        const int qq = q < npose ? q : 0;
-        const int iy = qq / nx;
-        off[r] = (iy * lv.fpitch + (qq - iy * nx)) * 4;
-        lo[r] = 0u; hi[r] = 0u;
+    int off[RQ], q0[RQ], nv[RQ];          // byte offset, first pose index, valid poses (0..4) of each slot
+    unsigned lo[RQ][4], hi[RQ][4];        // exact 64-bit integer sums as 32-bit halves
+#pragma unroll
+    for (int r = 0; r < RQ; ++r) {
+        const int u = u0 + r * WAVE;
+        const int uu = u < nslot ? u : 0;
+        const int iy = uu / nq, dx = (uu - iy * nq) * 4;
+        off[r] = (iy * lv.fpitch + dx) * 4;
+        q0[r] = iy * nx + dx;
+        nv[r] = u < nslot ? min(4, nx - dx) : 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lo[r][e] = 0u; hi[r][e] = 0u; }
     }
-#pragma unroll 4
+#pragma unroll 2
     for (int k = 0; k < K; ++k) {
         const int cell = cl[k] * 4;
-        unsigned v[R];
+        u32x4 v[RQ];
 #pragma unroll
-        for (int r = 0; r < R; ++r) v[r] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsrc, off[r], cell, 0);
+        for (int r = 0; r < RQ; ++r) v[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[r], cell, 0);
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const unsigned s = lo[r] + v[r];
-            hi[r] += s < v[r] ? 1u : 0u;
-            lo[r] = s;
-        }
+        for (int r = 0; r < RQ; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned s = lo[r][e] + v[r][e];
+                hi[r][e] += s < v[r][e] ? 1u : 0u;
+                lo[r][e] = s;
+            }
     }
-    unsigned long long acc[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = ((unsigned long long)hi[r] << 32) | lo[r];
     const double* __restrict__ pr = lv.prior + (size_t)p * 2 * npose;
     double* __restrict__ out = lv.cube + ((size_t)p * lv.ntheta + it) * npose;
     const double inv = 1.0 / lv.cost_scale;
-    double sc[R];
+    double sc[RQ][4];
     Best me{-INFINITY, INT_MAX, 0};
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int q = q0 + r * WAVE;
-        sc[r] = -INFINITY;
-        if (q < npose) {
-            const double sum = -((double)acc[r] * inv);                            // sum of probSP values
-            sc[r] = (sum + pr[q]) + pr[npose + q];                                 // :131
-            out[q] = sc[r];
-            Best cand{sc[r], it * npose + q, isnan(sc[r]) ? 1 : 0};
-            if (better(cand, me)) me = cand;
+    for (int r = 0; r < RQ; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sc[r][e] = -INFINITY;
+            if (e < nv[r]) {
+                const int q = q0[r] + e;
+                const unsigned long long acc = ((unsigned long long)hi[r][e] << 32) | lo[r][e];
+                const double sum = -((double)acc * inv);                           // sum of probSP values
+                sc[r][e] = (sum + pr[q]) + pr[npose + q];                          // :131
+                out[q] = sc[r][e];
+                Best cand{sc[r][e], it * npose + q, isnan(sc[r][e]) ? 1 : 0};
+                if (better(cand, me)) me = cand;
+            }
         }
-    }
     // per-wave reduction for k_select: max / argmax / sum exp(score - max)
     me = wave_best(me);
-    double e = 0.0;
+    double ex = 0.0;
 #pragma unroll
-    for (int r = 0; r < R; ++r)
-        if (q0 + r * WAVE < npose) e += exp(sc[r] - me.v);
-    e = wave_sum(e);
+    for (int r = 0; r < RQ; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e < nv[r]) ex += exp(sc[r][e] - me.v);
+    ex = wave_sum(ex);
     if (lane == 0) {
         Slam2dPartial pt;
-        pt.max = me.v; pt.sumexp = e; pt.argmax = me.i; pt.has_nan = me.nan;
+        pt.max = me.v; pt.sumexp = ex; pt.argmax = me.i; pt.has_nan = me.nan;
         lv.partials[(size_t)p * lv.npartial + w] = pt;
     }
 }
@@ -694,7 +709,7 @@ __global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks
 // K1d  arg-max / soft-max draw / confidence / matched pose   (Utils/ScanMatcher_OGBased.py:133-143)
 //      one wave per particle, working on the per-wave partials of the sweep
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_select(Slam2dLevel lv, int chunks, int R, const double* __restrict__ est,
+__global__ __launch_bounds__(64) void k_select(Slam2dLevel lv, int chunks, int RQ, const double* __restrict__ est,
                                                int estride, const double* __restrict__ uniform, Slam2dMatch* out) {
     const int p = blockIdx.x, lane = threadIdx.x;
     const int nx = 2 * lv.ncell + 1, npose = nx * nx;
@@ -735,16 +750,17 @@ __global__ __launch_bounds__(64) void k_select(Slam2dLevel lv, int chunks, int R
             if (run + t > target || w == s1 - 1) { wsel = w; break; }
             run += t;
         }
-        // inside chunk wsel: lane l owns entries [l*R, l*R+R) of its 64*R consecutive poses
+        // inside chunk wsel: it covers slots [ch*64*RQ, ...) = a contiguous pose range [qlo, qhi);
+        // lane l owns a contiguous run of `per2` poses of it
         const int it = wsel / chunks, ch = wsel - it * chunks;
-        const int qb = ch * WAVE * R + lane * R;
-        double ev[8];
+        const int nq = (nx + 3) >> 2, nslot = nx * nq;
+        const int s0c = min(nslot, ch * WAVE * RQ), s1c = min(nslot, (ch + 1) * WAVE * RQ);
+        const int qlo = (s0c / nq) * nx + min(nx, 4 * (s0c % nq));
+        const int qhi = (s1c / nq) * nx + min(nx, 4 * (s1c % nq));
+        const int per2 = (qhi - qlo + WAVE - 1) / WAVE;
+        const int a0 = qlo + lane * per2, a1 = min(qhi, a0 + per2);
         double lsum = 0.0;
-        for (int r = 0; r < 8; ++r) {
-            const int q = qb + r;
-            ev[r] = (r < R && q < npose) ? exp(c[(size_t)it * npose + q] - M) : 0.0;
-            lsum += ev[r];
-        }
+        for (int q = a0; q < a1; ++q) lsum += exp(c[(size_t)it * npose + q] - M);
         double linc = lsum;
 #pragma unroll
         for (int o = 1; o < WAVE; o <<= 1) {
@@ -752,19 +768,17 @@ __global__ __launch_bounds__(64) void k_select(Slam2dLevel lv, int chunks, int R
             if (lane >= o) linc += up;
         }
         const unsigned long long hit = __ballot(run + linc > target);
-        const int last_q = min(npose, (ch + 1) * WAVE * R) - 1;
-        pick = it * npose + last_q;                               // rounding fallback: chunk's last pose
+        pick = it * npose + max(qlo, qhi - 1);                    // rounding fallback: chunk's last pose
         if (hit) {
             const int l2 = __ffsll((long long)hit) - 1;
             double r2 = run + __shfl(linc - lsum, l2);
             int found = -1;
             if (lane == l2) {
-                for (int r = 0; r < 8; ++r) {
-                    if (r >= R) break;
-                    r2 += ev[r];
-                    if (r2 > target) { found = it * npose + qb + r; break; }
+                for (int q = a0; q < a1; ++q) {
+                    r2 += exp(c[(size_t)it * npose + q] - M);
+                    if (r2 > target) { found = it * npose + q; break; }
                 }
-                if (found < 0) found = it * npose + min(qb + R - 1, last_q);
+                if (found < 0) found = it * npose + max(a0, a1 - 1);
             }
             pick = __shfl(found, l2);
         }
@@ -1031,17 +1045,13 @@ int slam2d_sweep(const Slam2dLidar* lidar, const Slam2dLevel* level, int32_t P, 
         k_endpoints<<<dim3(lv.ntheta, P), 256, 0, s>>>(*lidar, lv, d_est, est_stride, d_ranges, d_flags);
     }
     k_priors<<<dim3(cdiv(npose, 256), P), 256, 0, s>>>(lv, est_moving_dist, lv.fine ? nullptr : d_psi_cs);
-    // poses per lane R: the k loop costs ~(R + 1) issue slots per cell and wave (R gathers + the
-    // scalar cell load / loop), so minimise chunks * (R + 1); ties go to the larger R
-    const int need = cdiv(npose, WAVE);
-    int bestR = 1, bestCost = INT_MAX;
-    for (int R = 1; R <= 8; ++R) {
-        const int cost = cdiv(need, R) * (R + 1);
-        if (cost <= bestCost) { bestCost = cost; bestR = R; }
-    }
+    // slots (4 consecutive dx) per lane RQ
+    const int nslot = nx * ((nx + 3) / 4);
+    const int need = cdiv(nslot, WAVE);
+    int bestR = 1;        // measured on MI355X (config 2): RQ = 1 124 us, RQ = 2..4 132-134 us
     if (const char* ov = getenv("SLAM2D_SWEEP_R")) {              // tuning knob
         const int R = atoi(ov);
-        if (R >= 1 && R <= 8) bestR = R;
+        if (R >= 1 && R <= 4) bestR = R;
     }
     const int chunks = cdiv(need, bestR);
     if (lv.ntheta * chunks > lv.npartial) return SLAM2D_E_BADARG;
@@ -1051,11 +1061,7 @@ int slam2d_sweep(const Slam2dLidar* lidar, const Slam2dLevel* level, int32_t P, 
             case 1: launch_sweep<1>(lv, P, chunks, s); break;
             case 2: launch_sweep<2>(lv, P, chunks, s); break;
             case 3: launch_sweep<3>(lv, P, chunks, s); break;
-            case 4: launch_sweep<4>(lv, P, chunks, s); break;
-            case 5: launch_sweep<5>(lv, P, chunks, s); break;
-            case 6: launch_sweep<6>(lv, P, chunks, s); break;
-            case 7: launch_sweep<7>(lv, P, chunks, s); break;
-            default: launch_sweep<8>(lv, P, chunks, s); break;
+            default: launch_sweep<4>(lv, P, chunks, s); break;
         }
     }
     {
