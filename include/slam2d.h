@@ -227,6 +227,27 @@ int slam2d_grid_update(const Slam2dLidar* lidar, const Slam2dMap* d_maps, int32_
                        int32_t* d_axis_scratch /* [P][2][lut_w] */, const int32_t* d_beam_shift,
                        uint32_t* d_flags, void* stream);
 
+/* Particle.updateEstimatedPose for P particles (Algorithm/FastSlam.py:77-106): the pose prior of the
+ * next scan from the previous matched poses and the raw odometry increment.
+ *   d_prev_pose[p*3 + 0..2]  previous matched pose (prevMatchedReading)
+ *   raw_theta, prev_raw_theta  currentRawReading['theta'], prevRawReading['theta'] (:78)
+ *   has_turn / raw_turn      rawMovingTheta - prevRawMovingTheta when both exist (:94), else has_turn = 0
+ *   d_heading[P]             prevMatchedMovingTheta per particle, NaN for None
+ * Writes d_est[p*3 + 0..2] (estimatedReading pose) and d_psi_cs[p*2 + 0..1] = (cos, sin) of
+ * estMovingTheta (NaN pair for None), the inputs of slam2d_field_build / slam2d_sweep. */
+int slam2d_prior(const double* d_prev_pose, double raw_theta, double prev_raw_theta, int32_t has_turn,
+                 double raw_turn, const double* d_heading, int32_t P, double* d_est, double* d_psi_cs,
+                 void* stream);
+
+/* The bookkeeping after a match (Algorithm/FastSlam.py:108-120,131-135): heading of the matched step
+ * (getMovingTheta), previous pose <- matched pose, log-weight += log coarse confidence.
+ *   d_fine / d_coarse        Slam2dMatch[P] of the fine / coarse level
+ *   d_prev_pose[P][3]        in: previous matched pose, out: this scan's matched pose
+ *   d_heading[P]             out: prevMatchedMovingTheta (NaN when the pose did not move)
+ *   d_logw[P]                in/out */
+int slam2d_post_match(const Slam2dMatch* d_fine, const Slam2dMatch* d_coarse, int32_t P, double* d_prev_pose,
+                      double* d_heading, double* d_logw, void* stream);
+
 /* Particle.update's `weight *= confidence` in the log domain followed by
  * ParticleFilter.normalizeWeights / weightUnbalanced (Algorithm/FastSlam.py:30-48,135).
  *   d_logw[N]    in/out: log-weights of ALL N particles (after an all-gather when sharded)

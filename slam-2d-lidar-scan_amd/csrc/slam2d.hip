@@ -934,6 +934,39 @@ __global__ __launch_bounds__(256) void k_weights(double* logw, const double* __r
 }
 
 // ------------------------------------------------------------------------------------
+// K5  odometry prior / post-match bookkeeping          (Algorithm/FastSlam.py:77-120,131-135)
+// ------------------------------------------------------------------------------------
+__global__ void k_prior(const double* __restrict__ prev, double raw_theta, double prev_raw_theta, int has_turn,
+                        double raw_turn, const double* __restrict__ heading, int P, double* est, double* psi_cs) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    est[3 * p + 0] = prev[3 * p + 0];                                               // :79
+    est[3 * p + 1] = prev[3 * p + 1];
+    est[3 * p + 2] = prev[3 * p + 2] + raw_theta - prev_raw_theta;                  // :78
+    double c = NAN, s = NAN;
+    const double h = heading[p];
+    if (has_turn && !isnan(h)) {                                                    // :89-95
+        const double psi = h + raw_turn;
+        c = cos(psi); s = sin(psi);
+    }
+    psi_cs[2 * p] = c; psi_cs[2 * p + 1] = s;
+}
+
+__global__ void k_post_match(const Slam2dMatch* __restrict__ fine, const Slam2dMatch* __restrict__ coarse, int P,
+                             double* prev, double* heading, double* logw) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const double x = fine[p].x, y = fine[p].y;
+    const double mx = x - prev[3 * p], my = y - prev[3 * p + 1];                    // :110-111
+    const double move = sqrt(mx * mx + my * my);
+    double h = NAN;
+    if (move != 0.0) h = my > 0.0 ? acos(mx / move) : -acos(mx / move);             // :113-117
+    heading[p] = h;
+    prev[3 * p] = x; prev[3 * p + 1] = y; prev[3 * p + 2] = fine[p].theta;          // :134
+    logw[p] += coarse[p].log_confidence;                                            // :135
+}
+
+// ------------------------------------------------------------------------------------
 // resample state movement / fill
 // ------------------------------------------------------------------------------------
 __global__ void k_gather_maps(const Slam2dMap* __restrict__ src, const Slam2dMap* __restrict__ dst,
@@ -1086,6 +1119,22 @@ int slam2d_grid_update(const Slam2dLidar* lidar, const Slam2dMap* d_maps, int32_
         k_grid_update<<<(unsigned)((long long)P * tiles_x * tiles_y), dim3(64, 4), 0, s>>>(
             *lidar, d_maps, P, d_pose, pose_stride, d_ranges, d_axis_scratch, d_beam_shift, d_flags, tiles_x);
     }
+    return launch_status();
+}
+
+int slam2d_prior(const double* d_prev_pose, double raw_theta, double prev_raw_theta, int32_t has_turn,
+                 double raw_turn, const double* d_heading, int32_t P, double* d_est, double* d_psi_cs,
+                 void* stream) {
+    if (!d_prev_pose || !d_heading || !d_est || !d_psi_cs || P <= 0) return SLAM2D_E_BADARG;
+    k_prior<<<cdiv(P, 64), 64, 0, (hipStream_t)stream>>>(d_prev_pose, raw_theta, prev_raw_theta, has_turn, raw_turn,
+                                                         d_heading, P, d_est, d_psi_cs);
+    return launch_status();
+}
+
+int slam2d_post_match(const Slam2dMatch* d_fine, const Slam2dMatch* d_coarse, int32_t P, double* d_prev_pose,
+                      double* d_heading, double* d_logw, void* stream) {
+    if (!d_fine || !d_coarse || !d_prev_pose || !d_heading || !d_logw || P <= 0) return SLAM2D_E_BADARG;
+    k_post_match<<<cdiv(P, 64), 64, 0, (hipStream_t)stream>>>(d_fine, d_coarse, P, d_prev_pose, d_heading, d_logw);
     return launch_status();
 }
 

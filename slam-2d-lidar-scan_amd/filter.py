@@ -109,6 +109,16 @@ class ParticleFilter:
                                 radius=cstep, fine=True, **common)                        # :66-73
         self.m_coarse = self.engine.match_buffer("coarse")
         self.m_fine = self.engine.match_buffer("fine")
+        self.d_pose = torch.zeros((P, 3), dtype=torch.float64, device=dev)     # prevMatchedReading poses
+        self.d_head = torch.full((P,), float("nan"), dtype=torch.float64, device=dev)   # prevMatchedMovingTheta
+        self.d_est = torch.zeros((P, 3), dtype=torch.float64, device=dev)
+        self.d_psi = torch.zeros((P, 2), dtype=torch.float64, device=dev)
+        self.d_uniform = torch.zeros(P, dtype=torch.float64, device=dev)
+        self.d_ranges = torch.zeros(beams, dtype=torch.float64, device=dev)
+        self._h_uniform = torch.zeros(P, dtype=torch.float64).pin_memory()
+        self._h_ranges = torch.zeros(beams, dtype=torch.float64).pin_memory()
+        self._h_report = torch.zeros((P, 5), dtype=torch.float64).pin_memory()
+        self.d_report = torch.zeros((P, 5), dtype=torch.float64, device=dev)   # x, y, theta, confidence, log-confidence
         self.d_logw = torch.zeros(P, dtype=torch.float64, device=dev)     # log of weight = 1 (:75)
         self.d_w = torch.full((P,), 1.0, dtype=torch.float64, device=dev)
         self.d_stats = torch.zeros(2, dtype=torch.float64, device=dev)
@@ -117,28 +127,34 @@ class ParticleFilter:
         self.prev_matched = None
         self.prev_raw = None
         self.prev_raw_heading = None
-        self.prev_matched_heading = [None] * P
         self.particles = [ParticleView(self, i) for i in range(P)]
         self.last_confidence = np.ones(P)
         self.last_variance = None
         self.step = 0
 
-    # ---- odometry prior, vectorised over particles (Algorithm/FastSlam.py:77-106) ----
-    def _prior(self, raw):
-        pm, pr = self.prev_matched, self.prev_raw
-        est = np.empty((self.numParticles, 3))
-        est[:, 0], est[:, 1] = pm[:, 0], pm[:, 1]
-        est[:, 2] = pm[:, 2] + raw['theta'] - pr['theta']
+    # ---- odometry prior (Algorithm/FastSlam.py:77-106) ----
+    def _raw_odometry(self, raw):
+        """The particle-independent part of updateEstimatedPose: distance and heading of the raw
+        odometry step (:81-104).  Returns (estMovingDist, rawMovingTheta, has_turn, raw_turn)."""
+        pr = self.prev_raw
         dx, dy = raw['x'] - pr['x'], raw['y'] - pr['y']
         dist = math.sqrt(dx ** 2 + dy ** 2)
-        psi = [None] * self.numParticles
-        raw_heading = None
+        raw_heading, has_turn, turn = None, 0, 0.0
         if dist > 0.3:
             raw_heading = _heading(dx, dy, dist)
             if self.prev_raw_heading is not None:
-                turn = raw_heading - self.prev_raw_heading
-                # (the reference raises TypeError if a particle's last matched move was exactly 0)
-                psi = [None if h is None else h + turn for h in self.prev_matched_heading]
+                has_turn, turn = 1, raw_heading - self.prev_raw_heading
+        return dist, raw_heading, has_turn, turn
+
+    def _prior(self, raw):
+        """Host mirror of the device prior (tests): (est [P,3], dist, psi list, raw heading)."""
+        dist, raw_heading, has_turn, turn = self._raw_odometry(raw)
+        pm = self.prev_matched
+        est = np.empty((self.numParticles, 3))
+        est[:, 0], est[:, 1] = pm[:, 0], pm[:, 1]
+        est[:, 2] = pm[:, 2] + raw['theta'] - self.prev_raw['theta']
+        # (the reference raises TypeError if a particle's last matched move was exactly 0)
+        psi = [None if (not has_turn or h is None) else h + turn for h in self.prev_matched_heading]
         return est, dist, psi, raw_heading
 
     def _draw_uniforms(self):
@@ -149,61 +165,64 @@ class ParticleFilter:
         u = src.random_sample(self.total_particles)
         return u[self.first_index:self.first_index + self.numParticles]
 
+    def _stage(self, host_buf, dev_buf, values):
+        host_buf.numpy()[...] = values
+        dev_buf.copy_(host_buf, non_blocking=True)
+
     # ---- Particle.update for all particles (Algorithm/FastSlam.py:25-27,122-135) ----
     def updateParticles(self, reading, count):
-        eng, P = self.engine, self.numParticles
-        ranges = np.asarray(reading['range'], dtype=np.float64)
-        d_rng = eng.to_device(ranges)
+        """One scan for every particle.  Everything between the uploads (ranges, uniforms) and the
+        single download at the end (poses, confidences) runs on the device without a host round
+        trip; the host only decides map growth from the poses it already has."""
+        eng, P, L = self.engine, self.numParticles, _lib.lib()
+        self._stage(self._h_ranges, self.d_ranges, np.asarray(reading['range'], dtype=np.float64))
         if count == 1:
             self.prev_raw_heading = None
-            self.prev_matched_heading = [None] * P
+            self.d_pose.copy_(torch.tensor([[reading['x'], reading['y'], reading['theta']]] * P, dtype=torch.float64))
+            self.d_head.fill_(float("nan"))
             matched = np.tile([reading['x'], reading['y'], reading['theta']], (P, 1)).astype(np.float64)
             conf = np.ones(P)
-            logconf = np.zeros(P)
-            d_pose, stride = eng.to_device(matched), 3
+            if self.growable:
+                self._grow_for_update(matched)
+            eng.grid_update(self.d_pose, 3, self.d_ranges)          # :133
+            eng.take_flags()
         else:
-            est, dist, psi, raw_heading = self._prior(reading)
-            matched, conf, logconf = self._match(est, dist, psi, d_rng)
+            dist, raw_heading, has_turn, turn = self._raw_odometry(reading)
+            est_xy = self.prev_matched                              # estimate = previous matched x, y (:79)
+            if self.growable:
+                self._grow_for_windows(est_xy[:, 0], est_xy[:, 1], self.coarse.reach)
+            self._stage(self._h_uniform, self.d_uniform, self._draw_uniforms())
+            _lib.check(L.slam2d_prior(_ptr(self.d_pose), float(reading['theta']), float(self.prev_raw['theta']),
+                                      has_turn, float(turn), _ptr(self.d_head), P, _ptr(self.d_est),
+                                      _ptr(self.d_psi), _stream()), "slam2d_prior")
+            eng.field_build(self.coarse, self.d_est, 3)
+            eng.sweep(self.coarse, self.d_est, 3, self.d_ranges, dist, self.d_psi, self.d_uniform, self.m_coarse)
+            if self.growable and not self._fine_window_cannot_grow(est_xy, (self.coarse.ncell + 1) * self.coarse.step):
+                eng.take_flags()
+                c = eng.read_matches(self.m_coarse)
+                self._grow_for_windows(c["x"], c["y"], self.fine.reach)
+            eng.field_build(self.fine, self.m_coarse, MATCH_DOUBLES)
+            eng.sweep(self.fine, self.m_coarse, MATCH_DOUBLES, self.d_ranges, dist, None, None, self.m_fine)
+            _lib.check(L.slam2d_post_match(_ptr(self.m_fine), _ptr(self.m_coarse), P, _ptr(self.d_pose),
+                                           _ptr(self.d_head), _ptr(self.d_logw), _stream()), "slam2d_post_match")
+            eng.grid_update(self.d_pose, 3, self.d_ranges)          # :133 (the update window lies inside the
+            #                                                         search window that was grown for)
+            self.d_report[:, 0:3] = self.d_pose
+            self.d_report[:, 3:5] = self.m_coarse[:, 3:5]           # confidence, log-confidence
+            self._h_report.copy_(self.d_report, non_blocking=True)
+            eng.take_flags()                                        # the one synchronisation of the scan
+            rep = self._h_report.numpy()
+            matched, conf = rep[:, 0:3].copy(), rep[:, 3].copy()
             self.prev_raw_heading = raw_heading
-            last = self.trajectory[-1]
-            heads = []
-            for i in range(P):                                     # getMovingTheta (:108-120)
-                mx, my = matched[i, 0] - last[i, 0], matched[i, 1] - last[i, 1]
-                move = math.sqrt(mx ** 2 + my ** 2)
-                heads.append(_heading(mx, my, move) if move != 0 else None)
-            self.prev_matched_heading = heads
-            d_pose, stride = self.m_fine, MATCH_DOUBLES
         self.trajectory.append(matched[:, :2].copy())
-        if self.growable:
-            self._grow_for_update(matched)
-        eng.grid_update(d_pose, stride, d_rng)                     # :133
         self.prev_matched, self.prev_raw = matched, reading
         self.last_confidence = conf
-        self.d_logw += eng.to_device(logconf)                      # weight *= confidence (:135)
-        eng.take_flags()
         self.step += 1
 
-    def _match(self, est, dist, psi, d_rng):
-        """matchScan(matchMax=False) for every particle (ScanMatcher_OGBased.py:47-79)."""
-        eng = self.engine
-        d_est = eng.to_device(est)
-        d_psi = eng.to_device(eng.psi_table(psi))
-        d_u = eng.to_device(self._draw_uniforms())
-        if self.growable:
-            self._grow_for_windows(est[:, 0], est[:, 1], self.coarse.reach)
-        eng.field_build(self.coarse, d_est, 3)
-        eng.sweep(self.coarse, d_est, 3, d_rng, dist, d_psi, d_u, self.m_coarse)
-        if self.growable and not self._fine_window_cannot_grow(est, (self.coarse.ncell + 1) * self.coarse.step):
-            eng.take_flags()
-            c = eng.read_matches(self.m_coarse)
-            self._grow_for_windows(c["x"], c["y"], self.fine.reach)
-        eng.field_build(self.fine, self.m_coarse, MATCH_DOUBLES)
-        eng.sweep(self.fine, self.m_coarse, MATCH_DOUBLES, d_rng, dist, None, None, self.m_fine)
-        eng.take_flags()
-        c = eng.read_matches(self.m_coarse)
-        f = eng.read_matches(self.m_fine)
-        matched = np.stack([f["x"], f["y"], f["theta"]], axis=1)
-        return matched, c["confidence"].copy(), c["log_confidence"].copy()
+    @property
+    def prev_matched_heading(self):
+        """prevMatchedMovingTheta per particle (None where the pose did not move), from the device."""
+        return [None if math.isnan(v) else float(v) for v in self.d_head.cpu().numpy()]
 
     def _grow_for_windows(self, xs, ys, reach):
         """checkAndExapndOG of every particle's search window (ScanMatcher_OGBased.py:27).  The
@@ -270,7 +289,9 @@ class ParticleFilter:
         self.engine.maps = [old[j].clone() for j in idx]            # deepcopy of the chosen particles (:61)
         self.engine.refresh_maps()
         self.prev_matched = self.prev_matched[idx].copy()
-        self.prev_matched_heading = [self.prev_matched_heading[j] for j in idx]
+        tidx = torch.as_tensor(np.asarray(idx, dtype=np.int64), device=self.device)
+        self.d_pose = self.d_pose[tidx].contiguous()
+        self.d_head = self.d_head[tidx].contiguous()
         self.trajectory = [t[idx].copy() for t in self.trajectory]
         self.weights = np.full(n := self.numParticles, 1 / n)                            # :62
         self.d_logw.fill_(math.log(1 / n))

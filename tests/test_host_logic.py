@@ -114,6 +114,8 @@ def test_psi_table():
 def test_batched_prior_equals_reference_prior(intel_readings):
     """ParticleFilter._prior vectorises Particle.updateEstimatedPose (FastSlam.py:77-106)."""
     class Dummy(flt.ParticleFilter):
+        prev_matched_heading = None      # plain attribute instead of the device-backed property
+
         def __init__(self):      # no device
             self.numParticles = 3
     pf = Dummy()
