@@ -83,7 +83,7 @@ typedef struct {
 } Slam2dMap;
 
 /* Lidar + polar spoke lookup table shared by all particles
- * (Utils/OccupancyGrid.py:22-57).  lut_bin / lut_r are the cell-major form of
+ * (Utils/OccupancyGrid.py:22-57).  lut_cell / lut_r are the cell-major form of
  * radByX/radByY/radByR: spoke bin and radius of every cell of the W x W window. */
 typedef struct {
     double unit;             /* unitGridSize */
@@ -94,8 +94,8 @@ typedef struct {
     int32_t num_spokes;      /* numSpokes */
     int32_t spoke_start;     /* spokesStartIdx */
     int32_t lut_w;           /* W = 2*int(max_range/unit)+1 */
-    const uint16_t* lut_bin; /* [W][W] */
-    const double*   lut_r;   /* [W][W] */
+    const uint32_t* lut_cell;/* [W][W] (spoke bin << 16) | floor(r / unit): 4 bytes decide most cells */
+    const double*   lut_r;   /* [W][W] exact radius, read only within ~2 cells of a beam's range thresholds */
     const double*   lut_xs;  /* [W]  linspace(-R, R, W) */
 } Slam2dLidar;
 
@@ -224,7 +224,7 @@ int slam2d_sweep(const Slam2dLidar* lidar, const Slam2dLevel* level, int32_t P,
  *                 (Utils/OccupancyGrid.py:144-147). */
 int slam2d_grid_update(const Slam2dLidar* lidar, const Slam2dMap* d_maps, int32_t P,
                        const double* d_pose, int32_t pose_stride, const double* d_ranges,
-                       int32_t* d_axis_scratch /* [P][2][lut_w] */, const int32_t* d_beam_shift,
+                       int32_t* d_axis_scratch /* [P*2*lut_w + beams] */, const int32_t* d_beam_shift,
                        uint32_t* d_flags, void* stream);
 
 /* Particle.updateEstimatedPose for P particles (Algorithm/FastSlam.py:77-106): the pose prior of the

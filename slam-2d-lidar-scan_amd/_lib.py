@@ -54,7 +54,7 @@ class Slam2dMap(C.Structure):
 class Slam2dLidar(C.Structure):
     _fields_ = [("unit", C.c_double), ("max_range", C.c_double), ("fov", C.c_double), ("wall_half", C.c_double),
                 ("beams", C.c_int32), ("num_spokes", C.c_int32), ("spoke_start", C.c_int32), ("lut_w", C.c_int32),
-                ("lut_bin", _vp), ("lut_r", _vp), ("lut_xs", _vp)]
+                ("lut_cell", _vp), ("lut_r", _vp), ("lut_xs", _vp)]
 
 
 class Slam2dFrame(C.Structure):

@@ -160,11 +160,16 @@ class LidarModel:
         """Device copies + the C struct (kept alive with the tensors)."""
         key = str(device)
         if key not in self._dev:
-            t = dict(bin=_dev(self.bin.view(np.int16), device), r=_dev(self.r, device), xs=_dev(self.xs, device))
+            # (bin << 16) | floor(r / unit): the integer radius lets the update kernel settle every cell
+            # that is not within a couple of cells of a range threshold without touching the fp64 radius
+            rq = np.floor(self.r / self.unit)
+            assert rq.max() < 65536
+            cell = (self.bin.astype(np.uint32) << np.uint32(16)) | rq.astype(np.uint32)
+            t = dict(cell=_dev(cell.view(np.int32), device), r=_dev(self.r, device), xs=_dev(self.xs, device))
             s = Slam2dLidar(unit=self.unit, max_range=self.max_range, fov=self.fov,
                             wall_half=self.wall_thickness / 2, beams=self.beams, num_spokes=self.num_spokes,
                             spoke_start=self.spoke_start, lut_w=self.width,
-                            lut_bin=t["bin"].data_ptr(), lut_r=t["r"].data_ptr(), lut_xs=t["xs"].data_ptr())
+                            lut_cell=t["cell"].data_ptr(), lut_r=t["r"].data_ptr(), lut_xs=t["xs"].data_ptr())
             self._dev[key] = (s, t)
         return self._dev[key][0]
 
@@ -452,7 +457,7 @@ class ParticleEngine:
         self.maps = list(maps)
         self.P = len(self.maps)
         self.flags = torch.zeros(self.P, dtype=torch.int32, device=self.device)
-        self.axis_scratch = torch.zeros((self.P, 2, lidar.width), dtype=torch.int32, device=self.device)
+        self.axis_scratch = torch.zeros(self.P * 2 * lidar.width + lidar.beams, dtype=torch.int32, device=self.device)
         self.match_buf = {}
         self.refresh_maps()
 
