@@ -77,19 +77,17 @@ __device__ __forceinline__ int reflect_index(int i, int n) {
 // ------------------------------------------------------------------------------------
 // K2a  frame geometry                      (Utils/ScanMatcher_OGBased.py:21-28)
 // ------------------------------------------------------------------------------------
-__global__ void k_frame_setup(Slam2dLidar lid, Slam2dLevel lv, const Slam2dMap* __restrict__ maps, int P,
-                              const double* __restrict__ centre, int cstride, uint32_t* flags) {
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
-    const Slam2dMap m = maps[p];
-    const double ex = centre[(size_t)p * cstride], ey = centre[(size_t)p * cstride + 1];
+// Frame geometry of one particle (every thread of k_frame_axis evaluates it redundantly: a few fp64
+// operations are cheaper than a kernel boundary).
+__device__ __forceinline__ Slam2dFrame make_frame(const Slam2dLidar& lid, const Slam2dLevel& lv, const Slam2dMap& m,
+                                                  const double ex, const double ey, uint32_t& f) {
     Slam2dFrame fr;
     fr.cx = ex; fr.cy = ey;
     fr.xlo = ex - lv.reach; fr.xhi = ex + lv.reach;            // :22-23
     fr.ylo = ey - lv.reach; fr.yhi = ey + lv.reach;
     int fw = (int)((fr.xhi - fr.xlo) / lv.step) + 1;            // :24-25
     int fh = (int)((fr.yhi - fr.ylo) / lv.step) + 1;
-    uint32_t f = 0;
+    f = 0;
     if (fw > lv.fmax) { fw = lv.fmax; f |= SLAM2D_F_FIELD_INDEX; }
     if (fh > lv.fmax) { fh = lv.fmax; f |= SLAM2D_F_FIELD_INDEX; }
     // checkMapToExpand (Utils/OccupancyGrid.py:108-118): the caller grows the map first
@@ -105,19 +103,24 @@ __global__ void k_frame_setup(Slam2dLidar lid, Slam2dLevel lv, const Slam2dMap* 
     fr.fh = fh; fr.fw = fw; fr.mx0 = mx0; fr.mx1 = mx1; fr.my0 = my0; fr.my1 = my1;
     fr.field_min = lv.floor_value; fr.redo = 0; fr._pad = 0;
     fr.min_bits = ~0ull;
-    lv.frames[p] = fr;
-    lv.tilecount[2 * p] = 0; lv.tilecount[2 * p + 1] = 0;
-    if (f) atomicOr(&flags[p], f);
+    return fr;
 }
 
 // ------------------------------------------------------------------------------------
-// K2b  field index of every window column / row   (Utils/ScanMatcher_OGBased.py:32-36,173-176)
+// K2a+b  frame geometry (:21-28) and the field index of every window column / row (:32-36,173-176)
 // ------------------------------------------------------------------------------------
-__global__ void k_axis_index(Slam2dLevel lv, const Slam2dMap* __restrict__ maps, uint32_t* flags) {
+__global__ void k_frame_axis(Slam2dLidar lid, Slam2dLevel lv, const Slam2dMap* __restrict__ maps,
+                             const double* __restrict__ centre, int cstride, uint32_t* flags) {
     const int p = blockIdx.y, axis = blockIdx.z;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const Slam2dFrame fr = lv.frames[p];
     const Slam2dMap m = maps[p];
+    uint32_t f;
+    const Slam2dFrame fr = make_frame(lid, lv, m, centre[(size_t)p * cstride], centre[(size_t)p * cstride + 1], f);
+    if (j == 0 && axis == 0) {
+        lv.frames[p] = fr;
+        lv.tilecount[2 * p] = 0; lv.tilecount[2 * p + 1] = 0;
+        if (f) atomicOr(&flags[p], f);
+    }
     const int n = axis == 0 ? fr.mx1 - fr.mx0 : fr.my1 - fr.my0;
     if (j >= n) return;
     const double coord = axis == 0 ? m.X[fr.mx0 + j] : m.Y[fr.my0 + j];
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(256) void k_refresh_bits(const Slam2dMap* __restric
 //      fp64, SciPy's symmetric correlate1d operation order, axis 0 then axis 1,
 //      'reflect' borders.  The clamp threshold is 0.5 * (field minimum); the minimum
 //      is known analytically (floor_value) whenever some cell has an all-free
-//      neighbourhood, which k_floor_check verifies from the measured minimum --
+//      neighbourhood, which k_blur_check_redo verifies from the measured minimum and
 //      mode 1 redoes the clamp with the measured minimum otherwise.
 // ------------------------------------------------------------------------------------
 #define BLUR_TILE 32
@@ -359,7 +362,7 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
         __syncthreads();
         if (tid == 0) {
             lmin = fmin(fmin(sm.red[0], sm.red[1]), fmin(sm.red[2], sm.red[3]));
-            lv.tilemin[((size_t)p * lv.tmax + tby) * lv.tmax + tbx] = lmin;   // reduced by k_floor_check
+            lv.tilemin[((size_t)p * lv.tmax + tby) * lv.tmax + tbx] = lmin;   // reduced by k_blur_check_redo
         }
     }
 }
@@ -430,37 +433,67 @@ __global__ __launch_bounds__(256) void k_blur_clamp(Slam2dLevel lv) {
     }
 }
 
-// Clamp redo with the measured minimum (rare: only when no cell of the field has an all-free
-// neighbourhood): one block per particle walks all tiles, and only if that particle needs it.
+// probMin (:43) = minimum over the per-tile minima; when it is not the analytic floor (rare: no cell
+// of the field has an all-free neighbourhood) the clamp is redone with it.  One block per particle.
 template <int RAD>
-__global__ __launch_bounds__(256) void k_blur_redo(Slam2dLevel lv) {
+__global__ __launch_bounds__(256) void k_blur_check_redo(Slam2dLevel lv, uint32_t* flags) {
     __shared__ BlurLds<RAD> sm;
-    const int p = blockIdx.z;
-    const Slam2dFrame fr = lv.frames[p];
-    if (!fr.redo) return;
+    __shared__ double min_s;
+    const int p = blockIdx.x, tid = threadIdx.x;
+    Slam2dFrame fr = lv.frames[p];
     const int nty = (fr.fh + 31) >> 5, ntx = (fr.fw + 31) >> 5;
+    const double* __restrict__ tm = lv.tilemin + (size_t)p * lv.tmax * lv.tmax;
+    double m = INFINITY;
+    for (int t = tid; t < nty * ntx; t += 256) m = fmin(m, tm[(t / ntx) * lv.tmax + (t % ntx)]);
+    for (int o = 32; o > 0; o >>= 1) m = fmin(m, __shfl_down(m, o));
+    if ((tid & 63) == 0) sm.red[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {
+        m = fmin(fmin(sm.red[0], sm.red[1]), fmin(sm.red[2], sm.red[3]));
+        min_s = m;
+        lv.frames[p].field_min = m;
+        if (m != lv.floor_value) { lv.frames[p].redo = 1; atomicOr(&flags[p], SLAM2D_F_FLOOR_REDO); }
+    }
+    __syncthreads();
+    if (min_s == lv.floor_value) return;
+    fr.field_min = min_s;
     for (int t = 0; t < nty * ntx; ++t) {
         blur_tile<RAD>(lv, sm, p, fr, t / ntx, t % ntx, 1, true);
         __syncthreads();
     }
 }
 
-// probMin (:43): minimum over the per-tile minima; one block per particle.
-__global__ __launch_bounds__(256) void k_floor_check(Slam2dLevel lv, int P, uint32_t* flags) {
-    __shared__ double red[4];
-    const int p = blockIdx.x, tid = threadIdx.x;
-    const Slam2dFrame fr = lv.frames[p];
-    const int nty = (fr.fh + 31) >> 5, ntx = (fr.fw + 31) >> 5;
-    const double* __restrict__ tm = lv.tilemin + (size_t)p * lv.tmax * lv.tmax;
-    double m = INFINITY;
-    for (int t = tid; t < nty * ntx; t += 256) m = fmin(m, tm[(t / ntx) * lv.tmax + (t % ntx)]);
-    for (int o = 32; o > 0; o >>= 1) m = fmin(m, __shfl_down(m, o));
-    if ((tid & 63) == 0) red[tid >> 6] = m;
-    __syncthreads();
-    if (tid == 0) {
-        m = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
-        lv.frames[p].field_min = m;
-        if (m != lv.floor_value) { lv.frames[p].redo = 1; atomicOr(&flags[p], SLAM2D_F_FLOOR_REDO); }
+// ------------------------------------------------------------------------------------
+// K1b  motion priors rv / thetaWeight              (Utils/ScanMatcher_OGBased.py:97-110)
+//      prior[p][0] = rv, prior[p][1] = thetaWeight, each [ny][nx]; computed by the theta-0 block of
+//      k_endpoints for its particle
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void write_priors(const Slam2dLevel& lv, const int p, const double est_dist,
+                                             const double* __restrict__ psi_cs) {
+    const int nx = 2 * lv.ncell + 1, np_ = nx * nx;
+    double* out = lv.prior + (size_t)p * 2 * np_;
+    const double cpsi = psi_cs ? psi_cs[2 * p] : NAN;
+    const double spsi = psi_cs ? psi_cs[2 * p + 1] : NAN;
+    for (int q = threadIdx.x; q < np_; q += blockDim.x) {
+        double rv = 0.0, tw = 0.0;
+        if (!lv.fine) {
+            const int iy = q / nx, ix = q - iy * nx;
+            const int xv = ix - lv.ncell, yv = iy - lv.ncell;
+            const double mx = (double)xv * lv.step, my = (double)yv * lv.step;
+            const double dist = sqrt(mx * mx + my * my);
+            const double dev = dist - est_dist;
+            rv = lv.rv_coef * (dev * dev);                                          // :101
+            if (fabs(dev) > lv.max_move_dev) rv = -100.0;                           // :102-103
+            if (!isnan(cpsi)) {                                                     // :104-108
+                double dv = sqrt((double)(xv * xv + yv * yv));
+                if (dv == 0.0) dv = 0.0001;
+                const double arg = ((double)xv * cpsi + (double)yv * spsi) / dv;
+                const double th = acos(arg);            // NaN when |arg| > 1, as np.arccos
+                tw = lv.tw_coef * (th * th);
+            }
+        }
+        out[q] = rv;
+        out[np_ + q] = tw;
     }
 }
 
@@ -471,7 +504,8 @@ __global__ __launch_bounds__(256) void k_floor_check(Slam2dLevel lv, int P, uint
 //      (cy - ncell) * fpitch + (cx - ncell).
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel lv, const double* __restrict__ est,
-                                                   int estride, const double* __restrict__ ranges, uint32_t* flags) {
+                                                   int estride, const double* __restrict__ ranges, uint32_t* flags,
+                                                   double est_dist, const double* __restrict__ psi_cs) {
     __shared__ int keys[SLAM2D_MAX_BEAMS];
     __shared__ int cnt_s[257];
     const int it = blockIdx.x, p = blockIdx.y, tid = threadIdx.x;
@@ -545,38 +579,7 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
         lv.kcount[p * lv.ntheta + it] = K;
     }
     if (bad) atomicOr(&flags[p], SLAM2D_F_ENDPOINT_OUTSIDE);
-}
-
-// ------------------------------------------------------------------------------------
-// K1b  motion priors rv / thetaWeight              (Utils/ScanMatcher_OGBased.py:97-110)
-//      prior[p][0] = rv, prior[p][1] = thetaWeight, each [ny][nx]
-// ------------------------------------------------------------------------------------
-__global__ void k_priors(Slam2dLevel lv, double est_dist, const double* __restrict__ psi_cs) {
-    const int p = blockIdx.y;
-    const int nx = 2 * lv.ncell + 1, np_ = nx * nx;
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= np_) return;
-    double rv = 0.0, tw = 0.0;
-    if (!lv.fine) {
-        const int iy = q / nx, ix = q - iy * nx;
-        const int xv = ix - lv.ncell, yv = iy - lv.ncell;
-        const double mx = (double)xv * lv.step, my = (double)yv * lv.step;
-        const double dist = sqrt(mx * mx + my * my);
-        const double dev = dist - est_dist;
-        rv = lv.rv_coef * (dev * dev);                                              // :101
-        if (fabs(dev) > lv.max_move_dev) rv = -100.0;                               // :102-103
-        const double cpsi = psi_cs ? psi_cs[2 * p] : NAN;
-        if (!isnan(cpsi)) {                                                         // :104-108
-            double dv = sqrt((double)(xv * xv + yv * yv));
-            if (dv == 0.0) dv = 0.0001;
-            const double arg = ((double)xv * cpsi + (double)yv * psi_cs[2 * p + 1]) / dv;
-            const double th = acos(arg);            // NaN when |arg| > 1, as np.arccos
-            tw = lv.tw_coef * (th * th);
-        }
-    }
-    double* out = lv.prior + (size_t)p * 2 * np_;
-    out[q] = rv;
-    out[np_ + q] = tw;
+    if (it == 0) write_priors(lv, p, est_dist, psi_cs);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1059,8 +1062,7 @@ int slam2d_field_build(const Slam2dLidar* lidar, const Slam2dLevel* level, const
     if (!d_maps || !d_centre || !d_flags || centre_stride < 2) return SLAM2D_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     const Slam2dLevel& lv = *level;
-    k_frame_setup<<<cdiv(P, 64), 64, 0, s>>>(*lidar, lv, d_maps, P, d_centre, centre_stride, d_flags);
-    k_axis_index<<<dim3(cdiv(lv.wmax, 256), P, 2), 256, 0, s>>>(lv, d_maps, d_flags);
+    k_frame_axis<<<dim3(cdiv(lv.wmax, 256), P, 2), 256, 0, s>>>(*lidar, lv, d_maps, d_centre, centre_stride, d_flags);
     if (lv.tilemask != lv.occ + (size_t)P * lv.fmax * lv.fpitch || !lv.tilestate || !lv.tilemin || !lv.tilelist || !lv.tilecount)
         return SLAM2D_E_BADARG;
     hipError_t e = hipMemsetAsync(lv.occ, 0, (size_t)P * lv.fmax * lv.fpitch + (size_t)P * lv.tmax * lv.tmax, s);
@@ -1081,11 +1083,10 @@ int slam2d_field_build(const Slam2dLidar* lidar, const Slam2dLevel* level, const
             default: k_blur_clamp<0><<<bgrid, 256, 0, s>>>(lv); break;
         }
     }
-    k_floor_check<<<P, 256, 0, s>>>(lv, P, d_flags);
     switch (lv.blur_radius) {
-        case 2: k_blur_redo<2><<<dim3(1, 1, P), 256, 0, s>>>(lv); break;
-        case 8: k_blur_redo<8><<<dim3(1, 1, P), 256, 0, s>>>(lv); break;
-        default: k_blur_redo<0><<<dim3(1, 1, P), 256, 0, s>>>(lv); break;
+        case 2: k_blur_check_redo<2><<<P, 256, 0, s>>>(lv, d_flags); break;
+        case 8: k_blur_check_redo<8><<<P, 256, 0, s>>>(lv, d_flags); break;
+        default: k_blur_check_redo<0><<<P, 256, 0, s>>>(lv, d_flags); break;
     }
     return launch_status();
 }
@@ -1102,9 +1103,9 @@ int slam2d_sweep(const Slam2dLidar* lidar, const Slam2dLevel* level, int32_t P, 
     const int nx = 2 * lv.ncell + 1, npose = nx * nx;
     {
         StageScope prof(SLAM2D_STAGE_ENDPOINTS, s);
-        k_endpoints<<<dim3(lv.ntheta, P), 256, 0, s>>>(*lidar, lv, d_est, est_stride, d_ranges, d_flags);
+        k_endpoints<<<dim3(lv.ntheta, P), 256, 0, s>>>(*lidar, lv, d_est, est_stride, d_ranges, d_flags,
+                                                       est_moving_dist, lv.fine ? nullptr : d_psi_cs);
     }
-    k_priors<<<dim3(cdiv(npose, 256), P), 256, 0, s>>>(lv, est_moving_dist, lv.fine ? nullptr : d_psi_cs);
     // slots (4 consecutive dx) per lane RQ
     const int nslot = nx * ((nx + 3) / 4);
     const int need = cdiv(nslot, WAVE);
