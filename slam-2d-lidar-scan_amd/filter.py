@@ -13,7 +13,7 @@ import math
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, parallel
 from .engine import MATCH_DOUBLES, LidarModel, MapState, ParticleEngine, SearchLevel, require_gpu, _ptr, _stream
 
 
@@ -87,7 +87,7 @@ class ParticleFilter:
     ``rng`` defaults to the legacy global NumPy stream like the reference."""
 
     def __init__(self, numParticles, ogParameters, smParameters, device=None, growable=True, rng=None,
-                 total_particles=None, first_index=0):
+                 total_particles=None, first_index=0, group=None):
         (mapX, mapY, initXY, unit, fov, max_range, beams, wall) = ogParameters            # :66
         (sr, half_rad, sigma, move_sigma, max_dev, turn_sigma, miss, cf) = smParameters   # :67-68
         self.device = require_gpu(device or "cuda:0")
@@ -96,6 +96,15 @@ class ParticleFilter:
         self.first_index = first_index
         self.growable = growable
         self.rng = rng
+        self.group = group
+        self.sharded = self.total_particles != numParticles
+        if self.sharded:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                raise _lib.Slam2dError("a sharded ParticleFilter needs torch.distributed to be initialised")
+            self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+            if parallel.shard_range(self.total_particles, self.world, self.rank) != (first_index, numParticles):
+                raise ValueError("first_index / numParticles do not match parallel.shard_range for this rank")
         self.lidar = LidarModel.get(unit, max_range, fov, beams, wall)
         maps = [MapState.create(mapX, mapY, initXY, unit, self.device) for _ in range(numParticles)]
         self.engine = ParticleEngine(self.lidar, maps, self.device)
@@ -262,38 +271,79 @@ class ParticleFilter:
 
     # ---- weights (Algorithm/FastSlam.py:30-48) ----
     def normalizeWeights(self):
-        L = _lib.lib()
-        _lib.check(L.slam2d_weights_normalize(_ptr(self.d_logw), None, self.numParticles, _ptr(self.d_w),
-                                              _ptr(self.d_stats), _stream()), "slam2d_weights_normalize")
-        self.weights = self.d_w.cpu().numpy()
+        """weights <- weights / sum (:43-48) in the log domain.  Sharded: all-reduce(MAX) + all-reduce(SUM)
+        of the normaliser (parallel.normalize_sharded), then an all-gather of the N weights so that
+        every rank evaluates the degeneracy test on identical numbers.  ``self.weights`` holds this
+        rank's particles, ``self.all_weights`` all N."""
+        n = self.total_particles
+        if self.sharded:
+            w, logw, _ = parallel.normalize_sharded(self.d_logw, n, self.group)
+            self.d_logw.copy_(logw)
+            self.d_w.copy_(w)
+            self.all_weights = parallel.gather_weights(w, n, self.world, self.group).cpu().numpy()
+            self.weights = self.all_weights[self.first_index:self.first_index + self.numParticles].copy()
+        else:
+            L = _lib.lib()
+            _lib.check(L.slam2d_weights_normalize(_ptr(self.d_logw), None, self.numParticles, _ptr(self.d_w),
+                                                  _ptr(self.d_stats), _stream()), "slam2d_weights_normalize")
+            self.weights = self.d_w.cpu().numpy()
+            self.all_weights = self.weights
         # sum (w_i - 1/N)^2 in the reference's sequential order (:32-35): its resample trigger sits at
         # total degeneracy, where the outcome is decided by the rounding of this very sum
-        n = self.numParticles
-        self.last_variance = float(np.cumsum((self.weights - 1 / n) ** 2)[-1])
+        self.last_variance = float(np.cumsum((self.all_weights - 1 / n) ** 2)[-1])
 
     def weightUnbalanced(self):
         self.normalizeWeights()
-        n = self.numParticles
+        n = self.total_particles
         return self.last_variance > ((n - 1) / n) ** 2 + (n - 1.000000000000001) * (1 / n) ** 2     # :37
 
     # ---- resample (Algorithm/FastSlam.py:50-62) ----
     def resample(self):
-        n = self.numParticles
+        """np.random.choice(N, N, p=weights) (:59) on every rank from the shared seeded stream, then the
+        state movement: local clones, and -- sharded -- point-to-point transfers of the maps that change
+        rank (parallel.migrate)."""
+        n = self.total_particles
         src = self.rng if self.rng is not None else np.random
-        idx = src.choice(np.arange(n), n, p=self.weights)                                # :59
+        idx = src.choice(np.arange(n), n, p=self.all_weights)                            # :59
         self.apply_resample(idx)
         return idx
 
     def apply_resample(self, idx):
-        old = self.engine.maps
-        self.engine.maps = [old[j].clone() for j in idx]            # deepcopy of the chosen particles (:61)
+        n, P, first = self.total_particles, self.numParticles, self.first_index
+        maps = self.engine.maps
+        if not self.sharded:
+            self.engine.maps = [maps[j].clone() for j in idx]       # deepcopy of the chosen particles (:61)
+            local = np.asarray(idx)
+            tidx = torch.as_tensor(local.astype(np.int64), device=self.device)
+            self.d_pose = self.d_pose[tidx].contiguous()
+            self.d_head = self.d_head[tidx].contiguous()
+            self.prev_matched = self.prev_matched[local].copy()
+            self.trajectory = [t[local].copy() for t in self.trajectory]
+        else:
+            shape = (maps[0].rows, maps[0].cols)
+            if any((m.rows, m.cols) != shape or m.lim_x != maps[0].lim_x or m.lim_y != maps[0].lim_y for m in maps):
+                raise _lib.Slam2dError("sharded resample needs maps of one extent on a rank (pre-size the maps)")
+            T = len(self.trajectory)
+            # one record per particle: pose, heading, trajectory; and its map
+            rec = torch.zeros((P, 4 + 2 * T), dtype=torch.float64, device=self.device)
+            rec[:, 0:3] = self.d_pose
+            rec[:, 3] = self.d_head
+            if T:
+                rec[:, 4:] = torch.as_tensor(np.stack(self.trajectory, axis=1).reshape(P, 2 * T), device=self.device)
+            recs = parallel.migrate([rec[i] for i in range(P)], idx, n, self.world, self.rank, self.group)
+            cells = parallel.migrate([m.cells for m in maps], idx, n, self.world, self.rank, self.group)
+            rec = torch.stack(recs)
+            self.d_pose = rec[:, 0:3].contiguous()
+            self.d_head = rec[:, 3].contiguous()
+            host = rec.cpu().numpy()
+            self.prev_matched = host[:, 0:3].copy()
+            self.trajectory = [host[:, 4 + 2 * t:6 + 2 * t].copy() for t in range(T)]
+            for m, c in zip(maps, cells):
+                m.cells = c
+                m.bits_valid = False
         self.engine.refresh_maps()
-        self.prev_matched = self.prev_matched[idx].copy()
-        tidx = torch.as_tensor(np.asarray(idx, dtype=np.int64), device=self.device)
-        self.d_pose = self.d_pose[tidx].contiguous()
-        self.d_head = self.d_head[tidx].contiguous()
-        self.trajectory = [t[idx].copy() for t in self.trajectory]
-        self.weights = np.full(n := self.numParticles, 1 / n)                            # :62
+        self.weights = np.full(P, 1 / n)                                                 # :62
+        self.all_weights = np.full(n, 1 / n)
         self.d_logw.fill_(math.log(1 / n))
         self.d_w.fill_(1 / n)
 

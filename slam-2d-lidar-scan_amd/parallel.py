@@ -20,6 +20,14 @@ import torch
 import torch.distributed as dist
 
 
+def _stage(t, group=None):
+    """gloo has no device-tensor point-to-point (and only some device collectives): with that backend
+    (CPU tests, or two ranks sharing one GPU) device tensors make the hop through host memory."""
+    if t.is_cuda and dist.is_initialized() and dist.get_backend(group) == "gloo":
+        return t.cpu()
+    return t
+
+
 def shard_range(total, world, rank):
     """Contiguous slice [first, first + count) of ``total`` particles owned by ``rank``."""
     base, extra = divmod(total, world)
@@ -41,13 +49,18 @@ def normalize_sharded(logw_local, total, group=None):
     Returns (w_local, logw_local_normalised, variance) where variance is
     sum_i (w_i - 1/N)^2 over ALL N particles (Algorithm/FastSlam.py:32-35), computed as
     sum w^2 - 1/N.  Two tiny all-reduces; no gather of the weights themselves."""
+    dev = logw_local.device
     m = logw_local.max().reshape(1) if logw_local.numel() else logw_local.new_full((1,), -math.inf)
     if dist.is_initialized():
+        m = _stage(m, group)
         dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
+        m = m.to(dev)
     e = torch.exp(logw_local - m)
     sums = torch.stack((e.sum(), (e * e).sum()))
     if dist.is_initialized():
+        sums = _stage(sums, group)
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        sums = sums.to(dev)
     w = e / sums[0]
     variance = sums[1] / (sums[0] * sums[0]) - 1.0 / total
     logw = logw_local - (m + torch.log(sums[0]))
@@ -62,9 +75,10 @@ def gather_weights(w_local, total, world, group=None):
     cap = max(counts)
     pad = w_local.new_zeros(cap)
     pad[:w_local.numel()] = w_local
-    parts = [w_local.new_zeros(cap) for _ in range(world)]
+    pad = _stage(pad, group)
+    parts = [pad.new_zeros(cap) for _ in range(world)]
     dist.all_gather(parts, pad, group=group)
-    return torch.cat([p[:c] for p, c in zip(parts, counts)])
+    return torch.cat([p[:c] for p, c in zip(parts, counts)]).to(w_local.device)
 
 
 def resample_plan(indices, total, world, rank):
@@ -95,16 +109,17 @@ def migrate(tensors, indices, total, world, rank, group=None):
     for d, s in local:
         new[d] = tensors[s].clone()
     ops, landing = [], []
+    dev = tensors[0].device
     for dst_rank, s, tag in sends:
-        ops.append(dist.P2POp(dist.isend, tensors[s].contiguous(), dst_rank, group=group, tag=tag))
+        ops.append(dist.P2POp(dist.isend, _stage(tensors[s].contiguous(), group), dst_rank, group=group, tag=tag))
     for src_rank, d, tag in recvs:
-        buf = torch.empty_like(tensors[0])
+        buf = _stage(torch.empty_like(tensors[0]), group)
         landing.append((d, buf))
         ops.append(dist.P2POp(dist.irecv, buf, src_rank, group=group, tag=tag))
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     for d, buf in landing:
-        new[d] = buf
+        new[d] = buf.to(dev)
     assert all(t is not None for t in new)
     return new
