@@ -168,18 +168,22 @@ __global__ __launch_bounds__(256) void k_occ_scatter(Slam2dLevel lv, const Slam2
 }
 
 __global__ __launch_bounds__(256) void k_refresh_bits(const Slam2dMap* __restrict__ maps, const int32_t* __restrict__ index) {
+    // one wave = 64 consecutive cells of a row: coalesced 256-byte read, one ballot, two words out
     const Slam2dMap m = maps[index ? index[blockIdx.y] : blockIdx.y];
-    const long long nwords = (long long)m.rows * m.bits_pitch;
-    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < nwords; t += (long long)gridDim.x * 256) {
-        const int row = (int)(t / m.bits_pitch), w = (int)(t - (long long)row * m.bits_pitch);
-        uint32_t word = 0;
-        const uint32_t* c = m.cells + (size_t)row * m.pitch + (w << 5);
-        const int n = min(32, m.cols - (w << 5));
-        for (int b = 0; b < n; ++b) {
-            const uint32_t v = c[b];
-            if (2u * (v >> 16) > (v & 0xffffu)) word |= 1u << b;                   // :29-31
+    const int lane = threadIdx.x & 63;
+    const int groups_per_row = (m.cols + 63) >> 6;
+    const long long ngroups = (long long)m.rows * groups_per_row;
+    for (long long g = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); g < ngroups; g += (long long)gridDim.x * 4) {
+        const int row = (int)(g / groups_per_row), c0 = (int)(g - (long long)row * groups_per_row) << 6;
+        const int col = c0 + lane;
+        bool occ = false;
+        if (col < m.cols) {
+            const uint32_t v = m.cells[(size_t)row * m.pitch + col];
+            occ = 2u * (v >> 16) > (v & 0xffffu);                                  // :29-31
         }
-        m.occ_bits[t] = word;
+        const unsigned long long mask = __ballot(occ);
+        if (lane < 2 && (c0 >> 5) + lane < m.bits_pitch)
+            m.occ_bits[(size_t)row * m.bits_pitch + (c0 >> 5) + lane] = (uint32_t)(mask >> (32 * lane));
     }
 }
 
@@ -1183,7 +1187,7 @@ int slam2d_gather_maps(const Slam2dMap* d_src, const Slam2dMap* d_dst, const int
 
 int slam2d_map_refresh_bits(const Slam2dMap* d_maps, const int32_t* d_index, int32_t n, void* stream) {
     if (!d_maps || n <= 0) return SLAM2D_E_BADARG;
-    k_refresh_bits<<<dim3(256, n), 256, 0, (hipStream_t)stream>>>(d_maps, d_index);
+    k_refresh_bits<<<dim3(1024, n), 256, 0, (hipStream_t)stream>>>(d_maps, d_index);
     return launch_status();
 }
 
