@@ -251,10 +251,10 @@ int slam2d_post_match(const Slam2dMatch* d_fine, const Slam2dMatch* d_coarse, in
 /* Particle.update's `weight *= confidence` in the log domain followed by
  * ParticleFilter.normalizeWeights / weightUnbalanced (Algorithm/FastSlam.py:30-48,135).
  *   d_logw[N]    in/out: log-weights of ALL N particles (after an all-gather when sharded)
- *   d_logconf[N] log-confidences to add first (NULL: none)
+ *   d_logconf    log-confidences to add first, element i at d_logconf[i*logconf_stride] (NULL: none)
  *   d_w[N]       out: normalised weights
  *   d_stats[2]   out: [variance = sum (w - 1/N)^2, log of the pre-normalisation weight sum] */
-int slam2d_weights_normalize(double* d_logw, const double* d_logconf, int32_t N,
+int slam2d_weights_normalize(double* d_logw, const double* d_logconf, int32_t logconf_stride, int32_t N,
                              double* d_w, double* d_stats, void* stream);
 
 /* ParticleFilter.resample's state movement (Algorithm/FastSlam.py:56-61) for maps of

@@ -930,13 +930,13 @@ __global__ __launch_bounds__(256) void k_grid_update(Slam2dLidar lid, const Slam
 // ------------------------------------------------------------------------------------
 // K4  weights                                        (Algorithm/FastSlam.py:30-48,135)
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_weights(double* logw, const double* __restrict__ logconf, int N, double* w,
-                                                 double* stats) {
+__global__ __launch_bounds__(256) void k_weights(double* logw, const double* __restrict__ logconf, int cstride, int N,
+                                                 double* w, double* stats) {
     __shared__ double red[256];
     const int tid = threadIdx.x;
     double mx = -INFINITY;
     for (int i = tid; i < N; i += 256) {
-        double v = logw[i] + (logconf ? logconf[i] : 0.0);
+        double v = logw[i] + (logconf ? logconf[(size_t)i * cstride] : 0.0);
         logw[i] = v;
         mx = fmax(mx, v);
     }
@@ -1170,10 +1170,10 @@ int slam2d_post_match(const Slam2dMatch* d_fine, const Slam2dMatch* d_coarse, in
     return launch_status();
 }
 
-int slam2d_weights_normalize(double* d_logw, const double* d_logconf, int32_t N, double* d_w, double* d_stats,
-                             void* stream) {
-    if (!d_logw || !d_w || !d_stats || N <= 0) return SLAM2D_E_BADARG;
-    k_weights<<<1, 256, 0, (hipStream_t)stream>>>(d_logw, d_logconf, N, d_w, d_stats);
+int slam2d_weights_normalize(double* d_logw, const double* d_logconf, int32_t logconf_stride, int32_t N, double* d_w,
+                             double* d_stats, void* stream) {
+    if (!d_logw || !d_w || !d_stats || N <= 0 || (d_logconf && logconf_stride < 1)) return SLAM2D_E_BADARG;
+    k_weights<<<1, 256, 0, (hipStream_t)stream>>>(d_logw, d_logconf, logconf_stride, N, d_w, d_stats);
     return launch_status();
 }
 

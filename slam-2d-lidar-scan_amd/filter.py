@@ -284,7 +284,7 @@ class ParticleFilter:
             self.weights = self.all_weights[self.first_index:self.first_index + self.numParticles].copy()
         else:
             L = _lib.lib()
-            _lib.check(L.slam2d_weights_normalize(_ptr(self.d_logw), None, self.numParticles, _ptr(self.d_w),
+            _lib.check(L.slam2d_weights_normalize(_ptr(self.d_logw), None, 1, self.numParticles, _ptr(self.d_w),
                                                   _ptr(self.d_stats), _stream()), "slam2d_weights_normalize")
             self.weights = self.d_w.cpu().numpy()
             self.all_weights = self.weights

@@ -61,7 +61,7 @@ def test_device_count_never_raises(L):
 
 def test_argument_errors_without_gpu(L):
     assert L.slam2d_map_fill(None, 0, 0, None) == -1
-    assert L.slam2d_weights_normalize(None, None, 0, None, None, None) == -1
+    assert L.slam2d_weights_normalize(None, None, 1, 0, None, None, None) == -1
 
 
 def test_product_path_fails_loudly_without_gpu():

@@ -317,7 +317,7 @@ def test_weights_kernel(pkg):
         d_w = torch.zeros(n, dtype=torch.float64, device="cuda")
         d_s = torch.zeros(2, dtype=torch.float64, device="cuda")
         L = flt._lib.lib()
-        flt._lib.check(L.slam2d_weights_normalize(flt._ptr(d_lw), flt._ptr(d_lc), n, flt._ptr(d_w), flt._ptr(d_s),
+        flt._lib.check(L.slam2d_weights_normalize(flt._ptr(d_lw), flt._ptr(d_lc), 1, n, flt._ptr(d_w), flt._ptr(d_s),
                                                    flt._stream()), "weights")
         s = logw + logc
         w = np.exp(s - s.max()); w /= w.sum()
