@@ -45,7 +45,13 @@ WORKLOADS = {
                       half_rad=0.25, sigma_cells=2, miss=0.15, coarse_factor=5, levels=2, wall=0.1,
                       move_sigma=0.1, max_dev=0.25, turn_sigma=0.3,
                       note="reference defaults: coarse 249^2/30x27x27 + fine 1241^2/30x11x11, 180 beams, map update"),
+    # BASELINE.json configs[4] (per-GPU slice): 2000x2000 @ 0.05 m map, 1081-beam 270-degree scans, 128 particles/GPU
+    "config5": dict(unit=0.05, max_range=30.0, fov=1.5 * math.pi, beams=1081, map_m=100.0, search_radius=2.05,
+                    half_rad=0.30, sigma_cells=2, miss=0.15, coarse_factor=2, levels=2, wall=0.25,
+                    move_sigma=0.1, max_dev=0.25, turn_sigma=0.3,
+                    note="2000x2000@0.05m map, 1081 beams over 1.5 pi, coarse 702^2/139x41x41 + fine 1403^2/139x5x5"),
 }
+WORKLOAD_PARTICLES = {"config5": 128}
 
 
 def parse():
@@ -54,7 +60,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
-    ap.add_argument("--particles", type=int, default=64, help="particles per GPU")
+    ap.add_argument("--particles", type=int, default=None, help="particles per GPU (default 64; config5: 128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample")
     return ap.parse_args()
@@ -230,7 +236,7 @@ def main():
     lib = E._lib.lib()
 
     cfg = WORKLOADS[args.workload]
-    P, K, W = args.particles, args.steps, args.warmup
+    P, K, W = args.particles or WORKLOAD_PARTICLES.get(args.workload, 64), args.steps, args.warmup
     scen = Scenario(cfg, P, K + W, seed=0, rank=rank)
     hot = HotPath(cfg, P, scen, device)
 
@@ -297,7 +303,7 @@ def main():
             # 2*FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950
             traffic = (json.load(open(tpath)).get(f"{args.workload}:{dom}") or {}).get("hbm_bytes_corrected")
         out = {
-            "metric": "scans/sec (180-beam) x particles at fixed search volume",
+            "metric": f"scans/sec ({cfg['beams']}-beam) x particles at fixed search volume",
             "value": total_units / elapsed, "unit": "particle-scans/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -510,23 +510,35 @@ __device__ __forceinline__ void write_priors(const Slam2dLevel& lv, const int p,
 __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel lv, const double* __restrict__ est,
                                                    int estride, const double* __restrict__ ranges, uint32_t* flags,
                                                    double est_dist, const double* __restrict__ psi_cs) {
-    __shared__ int keys[SLAM2D_MAX_BEAMS];
-    __shared__ int cnt_s[257];
+    // np.unique (:120) through an LDS hash set: every beam inserts its cell; of the beams that hit one
+    // cell the lowest beam index owns it (atomicMin), so the list keeps beam order -- which is spatially
+    // coherent (neighbouring beams hit neighbouring cells) and deterministic.  Scores are exact
+    // integer sums, so the order of the list cannot change a result.
+    extern __shared__ __attribute__((aligned(16))) int ep_lds[];     // [2n] keys, [2n] owners, [8] wave counts
     const int it = blockIdx.x, p = blockIdx.y, tid = threadIdx.x;
     const Slam2dFrame fr = lv.frames[p];
     const double ex = est[(size_t)p * estride], ey = est[(size_t)p * estride + 1], eth = est[(size_t)p * estride + 2];
     const int B = lid.beams;
     int n = 256;
     while (n < B) n <<= 1;
+    const int hsize = 2 * n, hmask = hsize - 1;
+    int* hkey = ep_lds;
+    int* hown = ep_lds + hsize;
+    int* cnt_s = ep_lds + 2 * hsize;
+    for (int i = tid; i < hsize; i += 256) { hkey[i] = INT_MAX; hown[i] = INT_MAX; }
     // np.linspace(theta - fov/2, theta + fov/2, num=B)  (:82-83)
     const double a0 = eth - lid.fov / 2, a1 = eth + lid.fov / 2;
     const double astep = (a1 - a0) / (double)(B - 1);
     const double c = lv.theta_cos[it], s = lv.theta_sin[it];
     const int nc = lv.ncell;
+    const int per = n / 256;                               // beams per thread, contiguous: [tid*per, tid*per + per)
+    int key[SLAM2D_MAX_BEAMS / 256], slot[SLAM2D_MAX_BEAMS / 256];
     bool bad = false;
-    for (int b = tid; b < n; b += 256) {
-        int key = INT_MAX;
-        if (b < B) {
+#pragma unroll
+    for (int q = 0; q < SLAM2D_MAX_BEAMS / 256; ++q) {
+        key[q] = INT_MAX; slot[q] = 0;
+        const int b = tid * per + q;
+        if (q < per && b < B) {
             const double rg = ranges[b];
             if (rg < lid.max_range) {                                               // :84
                 const double a = (b == B - 1) ? a1 : (double)b * astep + a0;
@@ -538,47 +550,46 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
                 const int cy = (int)((qy - fr.ylo) / lv.step);                      // :175
                 const int x0 = cx - nc, y0 = cy - nc;
                 if (x0 < 0 || y0 < 0 || cx + nc >= fr.fw || cy + nc >= fr.fh) bad = true;
-                else key = y0 * lv.fpitch + x0;
+                else key[q] = y0 * lv.fpitch + x0;
             }
         }
-        keys[b] = key;
     }
     __syncthreads();
-    for (int k = 2; k <= n; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < n; i += 256) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const bool up = (i & k) == 0;
-                    const int a = keys[i], b = keys[ixj];
-                    if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
-                }
-            }
-            __syncthreads();
+#pragma unroll
+    for (int q = 0; q < SLAM2D_MAX_BEAMS / 256; ++q) {
+        if (key[q] == INT_MAX) continue;
+        int h = (int)(((unsigned)key[q] * 2654435761u) >> 7) & hmask;
+        for (;;) {
+            const int prev = atomicCAS(&hkey[h], INT_MAX, key[q]);
+            if (prev == INT_MAX || prev == key[q]) break;
+            h = (h + 1) & hmask;
         }
+        slot[q] = h;
+        atomicMin(&hown[h], tid * per + q);
     }
-    // np.unique(axis=0) (:120): keep the first of every run; contiguous chunk per thread
-    const int chunk = n / 256;
-    int mine = 0;
-    for (int q = 0; q < chunk; ++q) {
-        const int i = tid * chunk + q;
-        const int k = keys[i];
-        if (k != INT_MAX && (i == 0 || k != keys[i - 1])) ++mine;
+    __syncthreads();
+    int keep = 0, mine = 0;
+#pragma unroll
+    for (int q = 0; q < SLAM2D_MAX_BEAMS / 256; ++q)
+        if (key[q] != INT_MAX && hown[slot[q]] == tid * per + q) { keep |= 1 << q; ++mine; }
+    int incl = mine;                                       // inclusive scan inside the wave ...
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if ((tid & 63) >= o) incl += up;
     }
-    cnt_s[tid + 1] = mine;
+    if ((tid & 63) == 63) cnt_s[(tid >> 6) + 1] = incl;
     if (tid == 0) cnt_s[0] = 0;
     __syncthreads();
-    if (tid == 0) for (int t = 1; t <= 256; ++t) cnt_s[t] += cnt_s[t - 1];
-    __syncthreads();
-    int pos = cnt_s[tid];
+    const int wv = tid >> 6;
+    int pos = incl - mine;                                 // ... plus the waves before
+    for (int w2 = 1; w2 <= wv; ++w2) pos += cnt_s[w2];
     int* out = lv.cells + ((size_t)p * lv.ntheta + it) * lv.kmax;
-    for (int q = 0; q < chunk; ++q) {
-        const int i = tid * chunk + q;
-        const int k = keys[i];
-        if (k != INT_MAX && (i == 0 || k != keys[i - 1])) { if (pos < lv.kmax) out[pos] = k; ++pos; }
-    }
-    if (tid == 0) {
-        int K = cnt_s[256];
+#pragma unroll
+    for (int q = 0; q < SLAM2D_MAX_BEAMS / 256; ++q)
+        if ((keep >> q) & 1) { if (pos < lv.kmax) out[pos] = key[q]; ++pos; }
+    if (tid == 255) {
+        int K = pos;                                       // the last thread ends at the total
         if (K > lv.kmax) { K = lv.kmax; bad = true; }
         lv.kcount[p * lv.ntheta + it] = K;
     }
@@ -1107,8 +1118,11 @@ int slam2d_sweep(const Slam2dLidar* lidar, const Slam2dLevel* level, int32_t P, 
     const int nx = 2 * lv.ncell + 1, npose = nx * nx;
     {
         StageScope prof(SLAM2D_STAGE_ENDPOINTS, s);
-        k_endpoints<<<dim3(lv.ntheta, P), 256, 0, s>>>(*lidar, lv, d_est, est_stride, d_ranges, d_flags,
-                                                       est_moving_dist, lv.fine ? nullptr : d_psi_cs);
+        int n = 256;
+        while (n < lidar->beams) n <<= 1;
+        const size_t ep_lds = (size_t)(4 * n + 8) * sizeof(int);
+        k_endpoints<<<dim3(lv.ntheta, P), 256, ep_lds, s>>>(*lidar, lv, d_est, est_stride, d_ranges, d_flags,
+                                                            est_moving_dist, lv.fine ? nullptr : d_psi_cs);
     }
     // slots (4 consecutive dx) per lane RQ
     const int nslot = nx * ((nx + 3) / 4);

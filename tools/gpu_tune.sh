@@ -26,3 +26,10 @@ echo "== forced dist (nccl, 1 rank)"
 SLAM2D_FORCE_DIST=1 timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -n 2 | cut -c1-400
 echo "== torchrun 1 rank"
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 1 --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -n 2 | cut -c1-300
+echo "== config5"
+timeout 300 python bench.py --workload config5 --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+import sys, json
+for line in sys.stdin:
+    if line.startswith('{'):
+        d = json.loads(line); print('value', round(d['value']), 'ms/step', round(d['ms_per_step'],3), {k: v['avg_us'] for k, v in d['stages_warmup'].items()})
+"
