@@ -151,7 +151,7 @@ typedef struct {
     Slam2dFrame* frames;     /* [P] */
     int32_t* axis_x;         /* [P][wmax] field column of every window map column */
     int32_t* axis_y;         /* [P][wmax] */
-    uint8_t* occ;            /* [P][fmax][fpitch] occupied field cells; then [P][tmax][tmax] tile flags */
+    uint8_t* occ;            /* [P][fmax][fpitch] occupied field cells; then [P][tmax][tmax] tile flags (16x16 cells) */
     uint32_t* field;         /* [P][fmax][fpitch]  fixed-point cost of probSP (see above) */
     int32_t* cells;          /* [P][ntheta][kmax] unique endpoint cells (patch-corner offsets) */
     int32_t* kcount;         /* [P][ntheta] */
@@ -159,7 +159,7 @@ typedef struct {
     double*  cube;           /* [P][ntheta][ny][nx] convTotal */
     Slam2dPartial* partials; /* [P][npartial] per-wave reductions of the cube (sweep -> select) */
     int32_t npartial;        /* capacity per particle: ntheta * ceil(ny*nx / 64) */
-    int32_t tmax;            /* ceil(fmax / 32): 32x32-cell tiles per field edge */
+    int32_t tmax;            /* ceil(fmax / 16): 16x16-cell tiles per field edge */
     uint8_t* tilemask;       /* [P][tmax][tmax] 1 = tile holds an occupied field cell (must follow occ
                                 contiguously: both are cleared by one memset) */
     uint8_t* tilestate;      /* [P][tmax][tmax] PERSISTENT across calls: 0 = the field tile already holds

@@ -19,6 +19,8 @@
 #include "slam2d.h"
 
 #define WAVE 64
+#define BLUR_TILE 16                 // field tile edge of the blur (power of two: BLUR_SHIFT)
+#define BLUR_SHIFT 4
 
 // ------------------------------------------------------------------------------------
 // stage profiling (bench.py): optional HIP-event pairs around selected kernels
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256) void k_occ_scatter(Slam2dLevel lv, const Slam2
         const int fx = ax[col_base + bit - fr.mx0];
         if (fx >= 0 && fy >= 0) {                                                  // :36-37
             occ[(size_t)fy * lv.fpitch + fx] = 1;
-            tiles[(fy >> 5) * lv.tmax + (fx >> 5)] = 1;
+            tiles[(fy >> BLUR_SHIFT) * lv.tmax + (fx >> BLUR_SHIFT)] = 1;
         }
     }
 }
@@ -195,10 +197,10 @@ __global__ __launch_bounds__(256) void k_refresh_bits(const Slam2dMap* __restric
 //      neighbourhood, which k_blur_check_redo verifies from the measured minimum and
 //      mode 1 redoes the clamp with the measured minimum otherwise.
 // ------------------------------------------------------------------------------------
-#define BLUR_TILE 32
-#define SLAM2D_BLUR_BLOCKS_PER_PARTICLE 96
+#define BLUR_THREADS 64              // one wave per tile: no cross-wave barriers
+#define SLAM2D_BLUR_BLOCKS_PER_PARTICLE 256
 #define BLUR_EXT (BLUR_TILE + 2 * SLAM2D_MAX_BLUR_RADIUS)
-// RAD > 0: radius known at compile time (register sliding windows, fully unrolled, LDS sized
+// RAD > 0: radius known at compile time, RAD <= 8 (register sliding windows, fully unrolled, LDS sized
 // for it); RAD == 0: any radius up to SLAM2D_MAX_BLUR_RADIUS (loops over LDS).
 //
 // Work avoidance (all bit-exact):
@@ -207,12 +209,15 @@ __global__ __launch_bounds__(256) void k_refresh_bits(const Slam2dMap* __restric
 //  * lv.tilestate remembers, across scans, which tiles of the (reused) field buffer already
 //    hold that constant: a tile that was free at the previous build and is free now is not
 //    touched at all -- the field build then costs HBM traffic only where walls are.
+// Tiles are 16x16: walls are thin, so small tiles keep the blurred area close to the area that
+// actually differs from the constant (work ~ (T + 2r + 1) * (2 + 2r/T) per unit wall length has its
+// minimum near T = 2r).
 template <int RAD>
 struct BlurLds {
     static constexpr int EXT = RAD > 0 ? BLUR_TILE + 2 * RAD : BLUR_EXT;
     uint8_t occ[EXT][EXT + 4];
-    double mid[BLUR_TILE][EXT + 1];
-    double red[4];
+    double mid[BLUR_TILE][EXT + 5];        // pitch 37 doubles at RAD = 8: conflict-free b64 row reads
+    double red;
 };
 
 template <int RAD>
@@ -226,12 +231,12 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
     const int tid = threadIdx.x;
     const uint8_t* occ = lv.occ + (size_t)p * lv.fmax * lv.fpitch;
     uint8_t* state = lv.tilestate + ((size_t)p * lv.tmax + tby) * lv.tmax + tbx;
-    // activity: an occupied cell within the halo (r <= 16 < 32) lies in one of the 3x3 tiles around
+    // activity: an occupied cell within the halo (r <= 16 = tile edge) lies in one of the 3x3 tiles around
     int any = 1;
     if (use_flags) {
         any = 0;
         const uint8_t* tiles = lv.tilemask + (size_t)p * lv.tmax * lv.tmax;
-        const int nty = (fh + 31) >> 5, ntx = (fw + 31) >> 5;
+        const int nty = (fh + BLUR_TILE - 1) >> BLUR_SHIFT, ntx = (fw + BLUR_TILE - 1) >> BLUR_SHIFT;
         if (tid < 9) {
             const int yy = tby + tid / 3 - 1, xx = tbx + tid % 3 - 1;
             if (yy >= 0 && yy < nty && xx >= 0 && xx < ntx) any = tiles[yy * lv.tmax + xx];
@@ -244,14 +249,14 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
         int exact = 0;                 // the tile flags are conservative: re-test on the halo itself
         if ((r & 3) == 0 && interior) {
             const int wpr = ext >> 2;
-            for (int idx = tid; idx < ext * wpr; idx += 256) {
+            for (int idx = tid; idx < ext * wpr; idx += BLUR_THREADS) {
                 const int ly = idx / wpr, lw = idx - ly * wpr;
                 const uint32_t v = *reinterpret_cast<const uint32_t*>(occ + (size_t)(ty0 - r + ly) * lv.fpitch + (tx0 - r) + 4 * lw);
                 *reinterpret_cast<uint32_t*>(&sm.occ[ly][4 * lw]) = v;
                 exact |= (v != 0u);
             }
         } else {
-            for (int idx = tid; idx < ext * ext; idx += 256) {
+            for (int idx = tid; idx < ext * ext; idx += BLUR_THREADS) {
                 const int ly = idx / ext, lx = idx - ly * ext;
                 const int gy = reflect_index(ty0 - r + ly, fh), gx = reflect_index(tx0 - r + lx, fw);
                 const uint8_t o = occ[(size_t)gy * lv.fpitch + gx];
@@ -271,7 +276,7 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
         if (mode == 0 && tid == 0) lv.tilemin[((size_t)p * lv.tmax + tby) * lv.tmax + tbx] = v;
         if (mode == 0 && *state == 0) return;          // already holds the constant: nothing to write
         const uint32_t c = v > thr ? 0u : (uint32_t)rint(-v * lv.cost_scale);
-        for (int idx = tid; idx < BLUR_TILE * BLUR_TILE; idx += 256) {
+        for (int idx = tid; idx < BLUR_TILE * BLUR_TILE; idx += BLUR_THREADS) {
             const int y = idx / BLUR_TILE, x = idx - y * BLUR_TILE;
             if (tx0 + x < lv.fpitch && ty0 + y < lv.fmax) field[(size_t)(ty0 + y) * lv.fpitch + tx0 + x] = c;
         }
@@ -282,46 +287,26 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
     double lmin = INFINITY;
     // SciPy symmetric correlate1d order: out = a[c]*w[c]; for j=-r..-1: out += (a[c+j] + a[c-j]) * w[j]
     if constexpr (RAD > 0) {
-        {   // axis-0 pass: thread = (column lx, 8 consecutive rows); the ext*4 threads that have work are
-            // packed into whole waves (ext = 48 -> 3 full waves, the 4th skips the phase)
+        {   // axis-0 pass: lane = (column lx, half of the tile's rows: 8 consecutive outputs)
             constexpr int EXT_C = BLUR_TILE + 2 * RAD;
+            static_assert(2 * EXT_C <= BLUR_THREADS, "one wave covers the axis-0 pass only for RAD <= 8");
             const int lx = tid % EXT_C, g = tid / EXT_C;
-            if (g < 4) {
-                if (lv.vtable != nullptr) {
-                    // The axis-0 input is binary (free / occupied), so its result is a function of the
-                    // (2r+1)-bit occupancy pattern of the column window: one lookup in a table that
-                    // was filled with the same operation order (bit k = occupied at window row k).
-                    unsigned pat = 0;
+            if (g < 2) {
+                double f[8 + 2 * RAD];
 #pragma unroll
-                    for (int k = 0; k < 2 * RAD + 1; ++k) pat |= (sm.occ[g * 8 + k][lx] ? 1u : 0u) << k;
-                    unsigned pats[8];
+                for (int k = 0; k < 8 + 2 * RAD; ++k) f[k] = sm.occ[g * 8 + k][lx] ? 0.0 : L;
 #pragma unroll
-                    for (int o = 0; o < 8; ++o) {
-                        pats[o] = pat;
-                        if (o < 7) pat = (pat >> 1) | ((sm.occ[g * 8 + o + 2 * RAD + 1][lx] ? 1u : 0u) << (2 * RAD));
-                    }
-                    double v[8];
+                for (int o = 0; o < 8; ++o) {
+                    double acc = f[o + RAD] * w[RAD];
 #pragma unroll
-                    for (int o = 0; o < 8; ++o) v[o] = lv.vtable[pats[o]];
-#pragma unroll
-                    for (int o = 0; o < 8; ++o) sm.mid[g * 8 + o][lx] = v[o];
-                } else {
-                    double f[8 + 2 * RAD];
-#pragma unroll
-                    for (int k = 0; k < 8 + 2 * RAD; ++k) f[k] = sm.occ[g * 8 + k][lx] ? 0.0 : L;
-#pragma unroll
-                    for (int o = 0; o < 8; ++o) {
-                        double acc = f[o + RAD] * w[RAD];
-#pragma unroll
-                        for (int j = -RAD; j < 0; ++j) acc = acc + (f[o + RAD + j] + f[o + RAD - j]) * w[RAD + j];
-                        sm.mid[g * 8 + o][lx] = acc;
-                    }
+                    for (int j = -RAD; j < 0; ++j) acc = acc + (f[o + RAD + j] + f[o + RAD - j]) * w[RAD + j];
+                    sm.mid[g * 8 + o][lx] = acc;
                 }
             }
         }
         __syncthreads();
-        {   // axis-1 pass: thread = (row y, 4 consecutive columns)
-            const int y = tid >> 3, x0 = (tid & 7) * 4;
+        {   // axis-1 pass: lane = (row y, 4 consecutive columns)
+            const int y = tid >> 2, x0 = (tid & 3) * 4;
             double mrow[4 + 2 * RAD];
 #pragma unroll
             for (int k = 0; k < 4 + 2 * RAD; ++k) mrow[k] = sm.mid[y][x0 + k];
@@ -338,7 +323,7 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
             }
         }
     } else {
-        for (int idx = tid; idx < BLUR_TILE * ext; idx += 256) {
+        for (int idx = tid; idx < BLUR_TILE * ext; idx += BLUR_THREADS) {
             const int y = idx / ext, lx = idx - y * ext;
             double acc = (sm.occ[y + r][lx] ? 0.0 : L) * w[r];
             for (int j = -r; j < 0; ++j) {
@@ -349,7 +334,7 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
             sm.mid[y][lx] = acc;
         }
         __syncthreads();
-        for (int idx = tid; idx < BLUR_TILE * BLUR_TILE; idx += 256) {
+        for (int idx = tid; idx < BLUR_TILE * BLUR_TILE; idx += BLUR_THREADS) {
             const int y = idx / BLUR_TILE, x = idx - y * BLUR_TILE;
             double acc = sm.mid[y][x + r] * w[r];
             for (int j = -r; j < 0; ++j) acc = acc + (sm.mid[y][x + r + j] + sm.mid[y][x + r - j]) * w[r + j];
@@ -362,16 +347,12 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
     }
     if (mode == 0) {
         for (int o = 32; o > 0; o >>= 1) lmin = fmin(lmin, __shfl_down(lmin, o));
-        if ((tid & 63) == 0) sm.red[tid >> 6] = lmin;
-        __syncthreads();
-        if (tid == 0) {
-            lmin = fmin(fmin(sm.red[0], sm.red[1]), fmin(sm.red[2], sm.red[3]));
-            lv.tilemin[((size_t)p * lv.tmax + tby) * lv.tmax + tbx] = lmin;   // reduced by k_blur_check_redo
-        }
+        if (tid == 0) lv.tilemin[((size_t)p * lv.tmax + tby) * lv.tmax + tbx] = lmin;   // reduced by k_blur_check_redo
     }
+    __syncthreads();                                   // LDS is reused by the block's next tile
 }
 
-// Tile triage, one thread per 32x32 field tile: tiles with an occupied cell in their 3x3 tile
+// Tile triage, one thread per 16x16 field tile: tiles with an occupied cell in their 3x3 tile
 // neighbourhood go to the blur work list; free tiles get their minimum recorded and, if the
 // field buffer does not already hold the free-space constant there, go to the fill list.
 // (Per-wave aggregated atomics: a wave's tiles belong to one particle.)
@@ -379,7 +360,7 @@ __global__ __launch_bounds__(256) void k_tile_classify(Slam2dLevel lv) {
     const int p = blockIdx.y;
     const int t = blockIdx.x * 256 + threadIdx.x;
     const Slam2dFrame fr = lv.frames[p];
-    const int nty = (fr.fh + 31) >> 5, ntx = (fr.fw + 31) >> 5;
+    const int nty = (fr.fh + BLUR_TILE - 1) >> BLUR_SHIFT, ntx = (fr.fw + BLUR_TILE - 1) >> BLUR_SHIFT;
     const int ty = t / lv.tmax, tx = t - ty * lv.tmax;
     if (ty >= nty || tx >= ntx) return;
     const uint8_t* tiles = lv.tilemask + (size_t)p * lv.tmax * lv.tmax;
@@ -402,7 +383,7 @@ __global__ __launch_bounds__(256) void k_tile_classify(Slam2dLevel lv) {
     }
 }
 
-// Free tiles whose buffer content is stale: store the free-space constant (whole 32x32 tile, also
+// Free tiles whose buffer content is stale: store the free-space constant (whole tile, also
 // beyond the current frame, so that the tile stays valid when the frame grows by its +-1 jitter).
 __global__ __launch_bounds__(256) void k_tile_fill(Slam2dLevel lv) {
     const int p = blockIdx.y, tid = threadIdx.x;
@@ -411,20 +392,20 @@ __global__ __launch_bounds__(256) void k_tile_fill(Slam2dLevel lv) {
     const double v = lv.floor_value;
     const uint32_t c = v > 0.5 * v ? 0u : (uint32_t)rint(-v * lv.cost_scale);
     uint32_t* field = lv.field + (size_t)p * lv.fmax * lv.fpitch;
-    for (int b = blockIdx.x; b < n; b += gridDim.x) {
+    // one wave per tile: 64 lanes x 16 bytes = the tile's 256 cells
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int b = blockIdx.x * 4 + wave; b < n; b += gridDim.x * 4) {
         const int t = list[b];
         const int ty0 = (t / lv.tmax) * BLUR_TILE, tx0 = (t % lv.tmax) * BLUR_TILE;
-        for (int idx = tid; idx < BLUR_TILE * BLUR_TILE / 4; idx += 256) {
-            const int y = idx / (BLUR_TILE / 4), x = (idx - y * (BLUR_TILE / 4)) * 4;
-            if (ty0 + y < lv.fmax && tx0 + x + 3 < lv.fpitch)
-                *reinterpret_cast<uint4*>(field + (size_t)(ty0 + y) * lv.fpitch + tx0 + x) = make_uint4(c, c, c, c);
-        }
+        const int y = lane >> 2, x = (lane & 3) * 4;
+        if (ty0 + y < lv.fmax && tx0 + x + 3 < lv.fpitch)
+            *reinterpret_cast<uint4*>(field + (size_t)(ty0 + y) * lv.fpitch + tx0 + x) = make_uint4(c, c, c, c);
     }
 }
 
-// Blur of the work list: gridDim.x blocks per particle walk that particle's active tiles.
+// Blur of the work list: gridDim.x one-wave blocks per particle walk that particle's active tiles.
 template <int RAD>
-__global__ __launch_bounds__(256) void k_blur_clamp(Slam2dLevel lv) {
+__global__ __launch_bounds__(BLUR_THREADS) void k_blur_clamp(Slam2dLevel lv) {
     __shared__ BlurLds<RAD> sm;
     const int p = blockIdx.y;
     const int n = lv.tilecount[2 * p];
@@ -438,33 +419,24 @@ __global__ __launch_bounds__(256) void k_blur_clamp(Slam2dLevel lv) {
 }
 
 // probMin (:43) = minimum over the per-tile minima; when it is not the analytic floor (rare: no cell
-// of the field has an all-free neighbourhood) the clamp is redone with it.  One block per particle.
+// of the field has an all-free neighbourhood) the clamp is redone with it.  One wave per particle.
 template <int RAD>
-__global__ __launch_bounds__(256) void k_blur_check_redo(Slam2dLevel lv, uint32_t* flags) {
+__global__ __launch_bounds__(BLUR_THREADS) void k_blur_check_redo(Slam2dLevel lv, uint32_t* flags) {
     __shared__ BlurLds<RAD> sm;
-    __shared__ double min_s;
     const int p = blockIdx.x, tid = threadIdx.x;
     Slam2dFrame fr = lv.frames[p];
-    const int nty = (fr.fh + 31) >> 5, ntx = (fr.fw + 31) >> 5;
+    const int nty = (fr.fh + BLUR_TILE - 1) >> BLUR_SHIFT, ntx = (fr.fw + BLUR_TILE - 1) >> BLUR_SHIFT;
     const double* __restrict__ tm = lv.tilemin + (size_t)p * lv.tmax * lv.tmax;
     double m = INFINITY;
-    for (int t = tid; t < nty * ntx; t += 256) m = fmin(m, tm[(t / ntx) * lv.tmax + (t % ntx)]);
-    for (int o = 32; o > 0; o >>= 1) m = fmin(m, __shfl_down(m, o));
-    if ((tid & 63) == 0) sm.red[tid >> 6] = m;
-    __syncthreads();
+    for (int t = tid; t < nty * ntx; t += BLUR_THREADS) m = fmin(m, tm[(t / ntx) * lv.tmax + (t % ntx)]);
+    for (int o = 1; o < WAVE; o <<= 1) m = fmin(m, __shfl_xor(m, o));
     if (tid == 0) {
-        m = fmin(fmin(sm.red[0], sm.red[1]), fmin(sm.red[2], sm.red[3]));
-        min_s = m;
         lv.frames[p].field_min = m;
         if (m != lv.floor_value) { lv.frames[p].redo = 1; atomicOr(&flags[p], SLAM2D_F_FLOOR_REDO); }
     }
-    __syncthreads();
-    if (min_s == lv.floor_value) return;
-    fr.field_min = min_s;
-    for (int t = 0; t < nty * ntx; ++t) {
-        blur_tile<RAD>(lv, sm, p, fr, t / ntx, t % ntx, 1, true);
-        __syncthreads();
-    }
+    if (m == lv.floor_value) return;
+    fr.field_min = m;
+    for (int t = 0; t < nty * ntx; ++t) blur_tile<RAD>(lv, sm, p, fr, t / ntx, t % ntx, 1, true);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1088,20 +1060,20 @@ int slam2d_field_build(const Slam2dLidar* lidar, const Slam2dLevel* level, const
     }
     const int ntile = lv.tmax * lv.tmax;
     k_tile_classify<<<dim3(cdiv(ntile, 256), P), 256, 0, s>>>(lv);
-    k_tile_fill<<<dim3(min(ntile, 32), P), 256, 0, s>>>(lv);
+    k_tile_fill<<<dim3(min(cdiv(ntile, 4), 64), P), 256, 0, s>>>(lv);
     {
         StageScope prof(SLAM2D_STAGE_BLUR, s);
         const dim3 bgrid(min(ntile, SLAM2D_BLUR_BLOCKS_PER_PARTICLE), P);
         switch (lv.blur_radius) {
-            case 2: k_blur_clamp<2><<<bgrid, 256, 0, s>>>(lv); break;
-            case 8: k_blur_clamp<8><<<bgrid, 256, 0, s>>>(lv); break;
-            default: k_blur_clamp<0><<<bgrid, 256, 0, s>>>(lv); break;
+            case 2: k_blur_clamp<2><<<bgrid, BLUR_THREADS, 0, s>>>(lv); break;
+            case 8: k_blur_clamp<8><<<bgrid, BLUR_THREADS, 0, s>>>(lv); break;
+            default: k_blur_clamp<0><<<bgrid, BLUR_THREADS, 0, s>>>(lv); break;
         }
     }
     switch (lv.blur_radius) {
-        case 2: k_blur_check_redo<2><<<P, 256, 0, s>>>(lv, d_flags); break;
-        case 8: k_blur_check_redo<8><<<P, 256, 0, s>>>(lv, d_flags); break;
-        default: k_blur_check_redo<0><<<P, 256, 0, s>>>(lv, d_flags); break;
+        case 2: k_blur_check_redo<2><<<P, BLUR_THREADS, 0, s>>>(lv, d_flags); break;
+        case 8: k_blur_check_redo<8><<<P, BLUR_THREADS, 0, s>>>(lv, d_flags); break;
+        default: k_blur_check_redo<0><<<P, BLUR_THREADS, 0, s>>>(lv, d_flags); break;
     }
     return launch_status();
 }

@@ -358,7 +358,7 @@ class SearchLevel:
         self.max_move_dev = max_move_dev
         npose = self.nx * self.nx
         self.npartial = self.ntheta * (-(-npose // 64))
-        self.tmax = -(-self.fmax // 32)
+        self.tmax = -(-self.fmax // 16)             # 16x16-cell tiles of the blur
         i32, f64 = torch.int32, torch.float64
         t = self.t = dict(
             blur_w=_dev(self.taps, device),
