@@ -141,30 +141,58 @@ __global__ void k_frame_axis(Slam2dLidar lid, Slam2dLevel lv, const Slam2dMap* _
 // The occupied / free state of every map cell is kept as one bit (Slam2dMap.occ_bits, maintained by
 // the update kernel), so the field build reads 1/32 of the bytes the count map holds.
 // One thread = one 32-cell word of the map window.
+#define SCATTER_ROWS 32
 __global__ __launch_bounds__(256) void k_occ_scatter(Slam2dLevel lv, const Slam2dMap* __restrict__ maps) {
+    // wave = threadIdx.y walks 8 rows of the map window; lane = one 32-cell word of the row.  The bits
+    // of a non-zero word are handled by 32 lanes at once (two words per step), so a horizontal wall --
+    // words with up to 32 bits set -- costs one step, not 32 serial iterations of one lane.
     const int p = blockIdx.z;
     const Slam2dFrame fr = lv.frames[p];
-    const int w0 = fr.mx0 >> 5;
-    const int w = w0 + blockIdx.x * 64 + threadIdx.x;
-    const int i = blockIdx.y * 4 + threadIdx.y;
-    if (w > ((fr.mx1 - 1) >> 5) || i >= fr.my1 - fr.my0 || fr.mx1 <= fr.mx0) return;
+    const int nrow = fr.my1 - fr.my0;
+    if (fr.mx1 <= fr.mx0 || nrow <= 0) return;
+    const int lane = threadIdx.x, wave = threadIdx.y;
+    const int w0 = (fr.mx0 >> 5) + blockIdx.x * 64, wlast = (fr.mx1 - 1) >> 5;
+    if (w0 > wlast) return;
+    const int w = w0 + lane;
     const Slam2dMap m = maps[p];
-    uint32_t word = m.occ_bits[(size_t)(fr.my0 + i) * m.bits_pitch + w];
-    if (!word) return;
+    constexpr int NR = SCATTER_ROWS / 4;
+    const int i0 = blockIdx.y * SCATTER_ROWS + wave;
+    uint32_t words[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int i = i0 + 4 * k;
+        words[k] = (i < nrow && w <= wlast) ? m.occ_bits[(size_t)(fr.my0 + i) * m.bits_pitch + w] : 0u;
+    }
     const int col_base = w << 5;
-    if (col_base < fr.mx0) word &= ~0u << (fr.mx0 - col_base);                    // window edges
-    if (col_base + 32 > fr.mx1) word &= ~0u >> (col_base + 32 - fr.mx1);
+    uint32_t edge = ~0u;
+    if (col_base < fr.mx0) edge &= ~0u << (fr.mx0 - col_base);                    // window edges
+    if (col_base + 32 > fr.mx1) edge &= ~0u >> (col_base + 32 - fr.mx1);
     uint8_t* occ = lv.occ + (size_t)p * lv.fmax * lv.fpitch;
     uint8_t* tiles = lv.tilemask + (size_t)p * lv.tmax * lv.tmax;
     const int32_t* __restrict__ ax = lv.axis_x + (size_t)p * lv.wmax;
-    const int fy = lv.axis_y[(size_t)p * lv.wmax + i];
-    while (word) {
-        const int bit = __ffs(word) - 1;
-        word &= word - 1;
-        const int fx = ax[col_base + bit - fr.mx0];
-        if (fx >= 0 && fy >= 0) {                                                  // :36-37
-            occ[(size_t)fy * lv.fpitch + fx] = 1;
-            tiles[(fy >> BLUR_SHIFT) * lv.tmax + (fx >> BLUR_SHIFT)] = 1;
+    const int half = lane >> 5, bit = lane & 31;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const uint32_t word = words[k] & edge;
+        unsigned long long nz = __ballot(word != 0u);
+        if (!nz) continue;
+        const int fy = lv.axis_y[(size_t)p * lv.wmax + i0 + 4 * k];
+        while (nz) {
+            const int sa = __ffsll((long long)nz) - 1;
+            nz &= nz - 1;
+            int sb = -1;
+            if (nz) { sb = __ffsll((long long)nz) - 1; nz &= nz - 1; }
+            const uint32_t wa = __shfl(word, sa), wb = sb >= 0 ? __shfl(word, sb) : 0u;
+            const uint32_t wsel = half ? wb : wa;
+            const int src = half ? sb : sa;
+            if ((wsel >> bit) & 1u) {
+                const int col = ((w0 + src) << 5) + bit;
+                const int fx = ax[col - fr.mx0];
+                if (fx >= 0 && fy >= 0) {                                          // :36-37
+                    occ[(size_t)fy * lv.fpitch + fx] = 1;
+                    tiles[(fy >> BLUR_SHIFT) * lv.tmax + (fx >> BLUR_SHIFT)] = 1;
+                }
+            }
         }
     }
 }
@@ -362,7 +390,7 @@ __global__ __launch_bounds__(256) void k_tile_classify(Slam2dLevel lv) {
     const Slam2dFrame fr = lv.frames[p];
     const int nty = (fr.fh + BLUR_TILE - 1) >> BLUR_SHIFT, ntx = (fr.fw + BLUR_TILE - 1) >> BLUR_SHIFT;
     const int ty = t / lv.tmax, tx = t - ty * lv.tmax;
-    if (ty >= nty || tx >= ntx) return;
+    if (ty >= nty || tx >= ntx) return;             // (exited lanes simply do not vote below)
     const uint8_t* tiles = lv.tilemask + (size_t)p * lv.tmax * lv.tmax;
     int any = 0;
 #pragma unroll
@@ -374,12 +402,23 @@ __global__ __launch_bounds__(256) void k_tile_classify(Slam2dLevel lv) {
         }
     int* count = lv.tilecount + 2 * p;
     int* list = lv.tilelist + (size_t)p * 2 * lv.tmax * lv.tmax;
-    if (any) {
-        list[atomicAdd(&count[0], 1)] = t;
-    } else {
-        lv.tilemin[(size_t)p * lv.tmax * lv.tmax + t] = lv.floor_value;
-        uint8_t* state = lv.tilestate + (size_t)p * lv.tmax * lv.tmax + t;
-        if (*state) { *state = 0; list[lv.tmax * lv.tmax + atomicAdd(&count[1], 1)] = t; }
+    uint8_t* state = lv.tilestate + (size_t)p * lv.tmax * lv.tmax + t;
+    if (!any) lv.tilemin[(size_t)p * lv.tmax * lv.tmax + t] = lv.floor_value;
+    const bool to_fill = !any && *state != 0;
+    if (to_fill) *state = 0;
+    // one atomic per wave and list (all tiles of a wave belong to particle p)
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        const bool mine = which == 0 ? any != 0 : to_fill;
+        const unsigned long long mask = __ballot(mine);
+        if (!mask) continue;
+        const int leader = __ffsll((long long)mask) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&count[which], __popcll(mask));
+        base = __shfl(base, leader);
+        if (mine) list[which * lv.tmax * lv.tmax + base + __popcll(mask & below)] = t;
     }
 }
 
@@ -421,20 +460,24 @@ __global__ __launch_bounds__(BLUR_THREADS) void k_blur_clamp(Slam2dLevel lv) {
 // probMin (:43) = minimum over the per-tile minima; when it is not the analytic floor (rare: no cell
 // of the field has an all-free neighbourhood) the clamp is redone with it.  One wave per particle.
 template <int RAD>
-__global__ __launch_bounds__(BLUR_THREADS) void k_blur_check_redo(Slam2dLevel lv, uint32_t* flags) {
+__global__ __launch_bounds__(256) void k_blur_check_redo(Slam2dLevel lv, uint32_t* flags) {
     __shared__ BlurLds<RAD> sm;
+    __shared__ double red_s[4];
     const int p = blockIdx.x, tid = threadIdx.x;
     Slam2dFrame fr = lv.frames[p];
     const int nty = (fr.fh + BLUR_TILE - 1) >> BLUR_SHIFT, ntx = (fr.fw + BLUR_TILE - 1) >> BLUR_SHIFT;
     const double* __restrict__ tm = lv.tilemin + (size_t)p * lv.tmax * lv.tmax;
     double m = INFINITY;
-    for (int t = tid; t < nty * ntx; t += BLUR_THREADS) m = fmin(m, tm[(t / ntx) * lv.tmax + (t % ntx)]);
+    for (int t = tid; t < nty * ntx; t += 256) m = fmin(m, tm[(t / ntx) * lv.tmax + (t % ntx)]);
     for (int o = 1; o < WAVE; o <<= 1) m = fmin(m, __shfl_xor(m, o));
+    if ((tid & 63) == 0) red_s[tid >> 6] = m;
+    __syncthreads();
+    m = fmin(fmin(red_s[0], red_s[1]), fmin(red_s[2], red_s[3]));
     if (tid == 0) {
         lv.frames[p].field_min = m;
         if (m != lv.floor_value) { lv.frames[p].redo = 1; atomicOr(&flags[p], SLAM2D_F_FLOOR_REDO); }
     }
-    if (m == lv.floor_value) return;
+    if (m == lv.floor_value || tid >= BLUR_THREADS) return;     // the redo itself is one wave's work
     fr.field_min = m;
     for (int t = 0; t < nty * ntx; ++t) blur_tile<RAD>(lv, sm, p, fr, t / ntx, t % ntx, 1, true);
 }
@@ -1056,7 +1099,7 @@ int slam2d_field_build(const Slam2dLidar* lidar, const Slam2dLevel* level, const
     if (e != hipSuccess) return (int)e;
     {
         StageScope prof(SLAM2D_STAGE_SCATTER, s);
-        k_occ_scatter<<<dim3(cdiv(cdiv(lv.wmax, 32) + 1, 64), cdiv(lv.wmax, 4), P), dim3(64, 4), 0, s>>>(lv, d_maps);
+        k_occ_scatter<<<dim3(cdiv(cdiv(lv.wmax, 32) + 1, 64), cdiv(lv.wmax, SCATTER_ROWS), P), dim3(64, 4), 0, s>>>(lv, d_maps);
     }
     const int ntile = lv.tmax * lv.tmax;
     k_tile_classify<<<dim3(cdiv(ntile, 256), P), 256, 0, s>>>(lv);
@@ -1071,9 +1114,9 @@ int slam2d_field_build(const Slam2dLidar* lidar, const Slam2dLevel* level, const
         }
     }
     switch (lv.blur_radius) {
-        case 2: k_blur_check_redo<2><<<P, BLUR_THREADS, 0, s>>>(lv, d_flags); break;
-        case 8: k_blur_check_redo<8><<<P, BLUR_THREADS, 0, s>>>(lv, d_flags); break;
-        default: k_blur_check_redo<0><<<P, BLUR_THREADS, 0, s>>>(lv, d_flags); break;
+        case 2: k_blur_check_redo<2><<<P, 256, 0, s>>>(lv, d_flags); break;
+        case 8: k_blur_check_redo<8><<<P, 256, 0, s>>>(lv, d_flags); break;
+        default: k_blur_check_redo<0><<<P, 256, 0, s>>>(lv, d_flags); break;
     }
     return launch_status();
 }
