@@ -155,6 +155,7 @@ typedef struct {
     uint32_t* field;         /* [P][fmax][fpitch]  fixed-point cost of probSP (see above) */
     int32_t* cells;          /* [P][ntheta][kmax] unique endpoint cells (patch-corner offsets) */
     int32_t* kcount;         /* [P][ntheta] */
+    double*  beam_xy;        /* [P][kmax][2] beam endpoints of the estimate pose (x = NaN: out of range) */
     double*  prior;          /* [P][2][ny][nx]  rv plane, thetaWeight plane */
     double*  cube;           /* [P][ntheta][ny][nx] convTotal */
     Slam2dPartial* partials; /* [P][npartial] per-wave reductions of the cube (sweep -> select) */

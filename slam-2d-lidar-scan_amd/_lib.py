@@ -78,7 +78,7 @@ class Slam2dLevel(C.Structure):
                 ("thetas", _vp), ("theta_cos", _vp), ("theta_sin", _vp),
                 ("rv_coef", C.c_double), ("tw_coef", C.c_double), ("max_move_dev", C.c_double),
                 ("frames", _vp), ("axis_x", _vp), ("axis_y", _vp), ("occ", _vp), ("field", _vp),
-                ("cells", _vp), ("kcount", _vp), ("prior", _vp), ("cube", _vp),
+                ("cells", _vp), ("kcount", _vp), ("beam_xy", _vp), ("prior", _vp), ("cube", _vp),
                 ("partials", _vp), ("npartial", C.c_int32), ("tmax", C.c_int32), ("tilemask", _vp),
                 ("tilestate", _vp), ("tilemin", _vp),
                 ("tilelist", _vp), ("tilecount", _vp), ("vtable", _vp)]

@@ -517,6 +517,29 @@ __device__ __forceinline__ void write_priors(const Slam2dLevel& lv, const int p,
 }
 
 // ------------------------------------------------------------------------------------
+// K1a0  beam endpoints of the estimate pose, once per particle   (Utils/ScanMatcher_OGBased.py:81-89)
+//       (the theta loop only rotates them; px = NaN marks a beam that is out of range, :84)
+// ------------------------------------------------------------------------------------
+__global__ void k_beam_points(Slam2dLidar lid, Slam2dLevel lv, const double* __restrict__ est, int estride,
+                              const double* __restrict__ ranges) {
+    const int p = blockIdx.y, b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int B = lid.beams;
+    if (b >= B) return;
+    const double ex = est[(size_t)p * estride], ey = est[(size_t)p * estride + 1], eth = est[(size_t)p * estride + 2];
+    // np.linspace(theta - fov/2, theta + fov/2, num=B)  (:82-83)
+    const double a0 = eth - lid.fov / 2, a1 = eth + lid.fov / 2;
+    const double astep = (a1 - a0) / (double)(B - 1);
+    const double rg = ranges[b];
+    double px = NAN, py = NAN;
+    if (rg < lid.max_range) {                                                       // :84
+        const double a = (b == B - 1) ? a1 : (double)b * astep + a0;
+        px = ex + cos(a) * rg; py = ey + sin(a) * rg;                               // :87-88
+    }
+    lv.beam_xy[((size_t)p * lv.kmax + b) * 2] = px;
+    lv.beam_xy[((size_t)p * lv.kmax + b) * 2 + 1] = py;
+}
+
+// ------------------------------------------------------------------------------------
 // K1a  beam endpoints -> unique field cells per theta   (Utils/ScanMatcher_OGBased.py:81-89,
 //      117-121,162-176).  One block per (theta, particle); bitonic sort + compaction in LDS.
 //      A cell is stored as the offset of the corner of its (2*ncell+1)^2 patch:
@@ -532,7 +555,7 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
     extern __shared__ __attribute__((aligned(16))) int ep_lds[];     // [2n] keys, [2n] owners, [8] wave counts
     const int it = blockIdx.x, p = blockIdx.y, tid = threadIdx.x;
     const Slam2dFrame fr = lv.frames[p];
-    const double ex = est[(size_t)p * estride], ey = est[(size_t)p * estride + 1], eth = est[(size_t)p * estride + 2];
+    const double ex = est[(size_t)p * estride], ey = est[(size_t)p * estride + 1];
     const int B = lid.beams;
     int n = 256;
     while (n < B) n <<= 1;
@@ -541,12 +564,10 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
     int* hown = ep_lds + hsize;
     int* cnt_s = ep_lds + 2 * hsize;
     for (int i = tid; i < hsize; i += 256) { hkey[i] = INT_MAX; hown[i] = INT_MAX; }
-    // np.linspace(theta - fov/2, theta + fov/2, num=B)  (:82-83)
-    const double a0 = eth - lid.fov / 2, a1 = eth + lid.fov / 2;
-    const double astep = (a1 - a0) / (double)(B - 1);
     const double c = lv.theta_cos[it], s = lv.theta_sin[it];
     const int nc = lv.ncell;
     const int per = n / 256;                               // beams per thread, contiguous: [tid*per, tid*per + per)
+    const double* __restrict__ bxy = lv.beam_xy + (size_t)p * lv.kmax * 2;
     int key[SLAM2D_MAX_BEAMS / 256], slot[SLAM2D_MAX_BEAMS / 256];
     bool bad = false;
 #pragma unroll
@@ -554,10 +575,8 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
         key[q] = INT_MAX; slot[q] = 0;
         const int b = tid * per + q;
         if (q < per && b < B) {
-            const double rg = ranges[b];
-            if (rg < lid.max_range) {                                               // :84
-                const double a = (b == B - 1) ? a1 : (double)b * astep + a0;
-                const double px = ex + cos(a) * rg, py = ey + sin(a) * rg;          // :87-88
+            const double px = bxy[2 * b], py = bxy[2 * b + 1];
+            if (!isnan(px)) {
                 const double dx = px - ex, dy = py - ey;
                 const double qx = ex + c * dx - s * dy;                             // :169
                 const double qy = ey + s * dx + c * dy;                             // :170
@@ -1128,11 +1147,12 @@ int slam2d_sweep(const Slam2dLidar* lidar, const Slam2dLevel* level, int32_t P, 
     if (rc) return rc;
     if (!d_est || !d_ranges || !d_out || !d_flags || est_stride < 3) return SLAM2D_E_BADARG;
     const Slam2dLevel& lv = *level;
-    if (lv.kmax < lidar->beams || !lv.partials) return SLAM2D_E_BADARG;
+    if (lv.kmax < lidar->beams || !lv.partials || !lv.beam_xy) return SLAM2D_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     const int nx = 2 * lv.ncell + 1, npose = nx * nx;
     {
         StageScope prof(SLAM2D_STAGE_ENDPOINTS, s);
+        k_beam_points<<<dim3(cdiv(lidar->beams, 256), P), 256, 0, s>>>(*lidar, lv, d_est, est_stride, d_ranges);
         int n = 256;
         while (n < lidar->beams) n <<= 1;
         const size_t ep_lds = (size_t)(4 * n + 8) * sizeof(int);

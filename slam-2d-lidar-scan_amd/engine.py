@@ -374,6 +374,7 @@ class SearchLevel:
             field=torch.zeros((P, self.fmax, self.fpitch), dtype=i32, device=device),     # uint32 costs
             cells=torch.zeros((P, self.ntheta, self.kmax), dtype=i32, device=device),
             kcount=torch.zeros((P, self.ntheta), dtype=i32, device=device),
+            beam_xy=torch.zeros((P, self.kmax, 2), dtype=f64, device=device),
             prior=torch.zeros((P, 2, npose), dtype=f64, device=device),
             cube=torch.zeros((P, self.ntheta, npose), dtype=f64, device=device),
             partials=torch.zeros((P, self.npartial, C.sizeof(Slam2dPartial)), dtype=torch.uint8, device=device),
@@ -394,7 +395,7 @@ class SearchLevel:
             theta_sin=t["sin"].data_ptr(), rv_coef=self.rv_coef, tw_coef=self.tw_coef,
             max_move_dev=max_move_dev, frames=t["frames"].data_ptr(), axis_x=t["axis_x"].data_ptr(),
             axis_y=t["axis_y"].data_ptr(), occ=t["occ"].data_ptr(), field=t["field"].data_ptr(),
-            cells=t["cells"].data_ptr(), kcount=t["kcount"].data_ptr(), prior=t["prior"].data_ptr(),
+            cells=t["cells"].data_ptr(), kcount=t["kcount"].data_ptr(), beam_xy=t["beam_xy"].data_ptr(), prior=t["prior"].data_ptr(),
             cube=t["cube"].data_ptr(), partials=t["partials"].data_ptr(), npartial=self.npartial, tmax=self.tmax,
             tilemask=t["occ"].data_ptr() + P * self.fmax * self.fpitch, tilestate=t["tilestate"].data_ptr(),
             tilemin=t["tilemin"].data_ptr(), tilelist=t["tilelist"].data_ptr(),
