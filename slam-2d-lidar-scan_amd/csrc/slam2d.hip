@@ -384,42 +384,56 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
 // neighbourhood go to the blur work list; free tiles get their minimum recorded and, if the
 // field buffer does not already hold the free-space constant there, go to the fill list.
 // (Per-wave aggregated atomics: a wave's tiles belong to one particle.)
-__global__ __launch_bounds__(256) void k_tile_classify(Slam2dLevel lv) {
+__global__ __launch_bounds__(1024) void k_tile_classify(Slam2dLevel lv) {
+    // 1024 tiles per block; list positions = (one global atomic per block and list) + rank inside the
+    // block, so a particle's two counters see a handful of atomics instead of one per wave.
+    __shared__ int wave_cnt[2][16];
+    __shared__ int block_base[2];
     const int p = blockIdx.y;
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int t = blockIdx.x * 1024 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const Slam2dFrame fr = lv.frames[p];
     const int nty = (fr.fh + BLUR_TILE - 1) >> BLUR_SHIFT, ntx = (fr.fw + BLUR_TILE - 1) >> BLUR_SHIFT;
     const int ty = t / lv.tmax, tx = t - ty * lv.tmax;
-    if (ty >= nty || tx >= ntx) return;             // (exited lanes simply do not vote below)
+    const bool live = ty < nty && tx < ntx;
     const uint8_t* tiles = lv.tilemask + (size_t)p * lv.tmax * lv.tmax;
     int any = 0;
+    bool to_fill = false;
+    if (live) {
 #pragma unroll
-    for (int dy = -1; dy <= 1; ++dy)
+        for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) {
-            const int yy = ty + dy, xx = tx + dx;
-            if (yy >= 0 && yy < nty && xx >= 0 && xx < ntx) any |= tiles[yy * lv.tmax + xx];
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int yy = ty + dy, xx = tx + dx;
+                if (yy >= 0 && yy < nty && xx >= 0 && xx < ntx) any |= tiles[yy * lv.tmax + xx];
+            }
+        uint8_t* state = lv.tilestate + (size_t)p * lv.tmax * lv.tmax + t;
+        if (!any) {
+            lv.tilemin[(size_t)p * lv.tmax * lv.tmax + t] = lv.floor_value;
+            to_fill = *state != 0;
+            if (to_fill) *state = 0;
         }
-    int* count = lv.tilecount + 2 * p;
-    int* list = lv.tilelist + (size_t)p * 2 * lv.tmax * lv.tmax;
-    uint8_t* state = lv.tilestate + (size_t)p * lv.tmax * lv.tmax + t;
-    if (!any) lv.tilemin[(size_t)p * lv.tmax * lv.tmax + t] = lv.floor_value;
-    const bool to_fill = !any && *state != 0;
-    if (to_fill) *state = 0;
-    // one atomic per wave and list (all tiles of a wave belong to particle p)
-    const int lane = threadIdx.x & 63;
+    }
     const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const bool mine[2] = {live && any != 0, to_fill};
+    int rank[2];
 #pragma unroll
     for (int which = 0; which < 2; ++which) {
-        const bool mine = which == 0 ? any != 0 : to_fill;
-        const unsigned long long mask = __ballot(mine);
-        if (!mask) continue;
-        const int leader = __ffsll((long long)mask) - 1;
-        int base = 0;
-        if (lane == leader) base = atomicAdd(&count[which], __popcll(mask));
-        base = __shfl(base, leader);
-        if (mine) list[which * lv.tmax * lv.tmax + base + __popcll(mask & below)] = t;
+        const unsigned long long mask = __ballot(mine[which]);
+        rank[which] = __popcll(mask & below);
+        if (lane == 0) wave_cnt[which][wave] = __popcll(mask);
     }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        int tot = 0;
+        for (int w2 = 0; w2 < 16; ++w2) { const int c = wave_cnt[threadIdx.x][w2]; wave_cnt[threadIdx.x][w2] = tot; tot += c; }
+        block_base[threadIdx.x] = tot ? atomicAdd(&lv.tilecount[2 * p + threadIdx.x], tot) : 0;
+    }
+    __syncthreads();
+    int* list = lv.tilelist + (size_t)p * 2 * lv.tmax * lv.tmax;
+#pragma unroll
+    for (int which = 0; which < 2; ++which)
+        if (mine[which]) list[which * lv.tmax * lv.tmax + block_base[which] + wave_cnt[which][wave] + rank[which]] = t;
 }
 
 // Free tiles whose buffer content is stale: store the free-space constant (whole tile, also
@@ -1121,7 +1135,7 @@ int slam2d_field_build(const Slam2dLidar* lidar, const Slam2dLevel* level, const
         k_occ_scatter<<<dim3(cdiv(cdiv(lv.wmax, 32) + 1, 64), cdiv(lv.wmax, SCATTER_ROWS), P), dim3(64, 4), 0, s>>>(lv, d_maps);
     }
     const int ntile = lv.tmax * lv.tmax;
-    k_tile_classify<<<dim3(cdiv(ntile, 256), P), 256, 0, s>>>(lv);
+    k_tile_classify<<<dim3(cdiv(ntile, 1024), P), 1024, 0, s>>>(lv);
     k_tile_fill<<<dim3(min(cdiv(ntile, 4), 64), P), 256, 0, s>>>(lv);
     {
         StageScope prof(SLAM2D_STAGE_BLUR, s);
