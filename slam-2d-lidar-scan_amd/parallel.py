@@ -4,9 +4,9 @@ the tests).
 
 Particles are independent during a scan (Algorithm/FastSlam.py:25-27), so the data
 path has no collective.  The only exchange is the weight normaliser
-(``normalizeWeights`` / ``weightUnbalanced``, Algorithm/FastSlam.py:30-48): an
-all-reduce(MAX) of the local log-weight maximum followed by one all-reduce(SUM) of
-the vector [sum w, sum w^2] -- 8 + 16 bytes per scan, latency-bound.  Resampling
+(``normalizeWeights`` / ``weightUnbalanced``, Algorithm/FastSlam.py:30-48): one
+all-gather of [max log-weight, sum w, sum w^2] per rank (24 bytes), merged in rank order
+on every rank -- latency-bound, one collective per scan.  Resampling
 (rare, Algorithm/FastSlam.py:50-62) all-gathers the N weights, draws the indices
 from the shared seeded stream on every rank, and moves the surviving particles' maps
 point-to-point.
@@ -48,22 +48,29 @@ def normalize_sharded(logw_local, total, group=None):
 
     Returns (w_local, logw_local_normalised, variance) where variance is
     sum_i (w_i - 1/N)^2 over ALL N particles (Algorithm/FastSlam.py:32-35), computed as
-    sum w^2 - 1/N.  Two tiny all-reduces; no gather of the weights themselves."""
+    sum w^2 - 1/N.  ONE collective per scan: an all-gather of each rank's
+    [max log-weight, sum exp(lw - max), sum exp(2 (lw - max))] (24 bytes per rank), merged
+    identically on every rank in rank order -- so the result does not depend on the
+    reduction order of the network, and the per-scan cost is one xGMI latency."""
     dev = logw_local.device
-    m = logw_local.max().reshape(1) if logw_local.numel() else logw_local.new_full((1,), -math.inf)
-    if dist.is_initialized():
-        m = _stage(m, group)
-        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
-        m = m.to(dev)
+    m = logw_local.max() if logw_local.numel() else logw_local.new_tensor(-math.inf)
     e = torch.exp(logw_local - m)
-    sums = torch.stack((e.sum(), (e * e).sum()))
-    if dist.is_initialized():
-        sums = _stage(sums, group)
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
-        sums = sums.to(dev)
-    w = e / sums[0]
-    variance = sums[1] / (sums[0] * sums[0]) - 1.0 / total
-    logw = logw_local - (m + torch.log(sums[0]))
+    mine = torch.stack((m, e.sum(), (e * e).sum()))
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        world = dist.get_world_size(group)
+        mine = _stage(mine, group)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        allp = torch.stack(parts).to(dev)                       # [world, 3]
+        gm = allp[:, 0].max()
+        scale = torch.exp(allp[:, 0] - gm)                      # rescale every rank's sums to the global max
+        s1 = (allp[:, 1] * scale).sum()
+        s2 = (allp[:, 2] * scale * scale).sum()
+    else:
+        gm, s1, s2 = m, mine[1].to(dev), mine[2].to(dev)
+    w = torch.exp(logw_local - gm) / s1
+    variance = s2 / (s1 * s1) - 1.0 / total
+    logw = logw_local - (gm + torch.log(s1))
     return w, logw, variance
 
 
