@@ -6,7 +6,7 @@
 A "step" is one lidar scan processed for every particle of the rank: search-field build
 from each particle's own map, pose-cube sweep with soft-max pose draw and confidence,
 occupancy-grid update at the matched pose, weight update + normalisation (sharded runs:
-the RCCL all-reduce of the normaliser).  All inputs of all steps (ranges, pose estimates,
+one RCCL all-gather of the normaliser).  All inputs of all steps (ranges, pose estimates,
 uniforms) are resident in HBM before the timed region; nothing is copied or synchronised
 inside it.
 
@@ -311,7 +311,7 @@ def main():
             "config": {"workload": f"{args.workload}: {cfg['note']}", "particles_per_gpu": P,
                        "total_particles": P * world, "pose_hypotheses_per_particle_scan":
                        hot.coarse.ntheta * hot.coarse.nx ** 2 + (hot.fine.ntheta * hot.fine.nx ** 2 if hot.fine else 0),
-                       "parallelism": f"particles sharded x{world}, all-reduce of the weight normaliser"
+                       "parallelism": f"particles sharded x{world}, one 24-byte-per-rank RCCL all-gather of the weight normaliser per scan"
                        if world > 1 else "single GPU"},
             "scans_per_sec": K / elapsed,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
