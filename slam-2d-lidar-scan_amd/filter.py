@@ -233,16 +233,31 @@ class ParticleFilter:
         """prevMatchedMovingTheta per particle (None where the pose did not move), from the device."""
         return [None if math.isnan(v) else float(v) for v in self.d_head.cpu().numpy()]
 
+    def _limits(self):
+        """[P, 4] array (x0, x1, y0, y1) of the particles' map limits, rebuilt only after a growth or a
+        resample (the engine's map list is replaced then)."""
+        maps = self.engine.maps
+        key = (id(maps), sum(len(m.growth_log) for m in maps))
+        if getattr(self, "_lims_key", None) != key:
+            self._lims = np.array([[m.lim_x[0], m.lim_x[1], m.lim_y[0], m.lim_y[1]] for m in maps])
+            self._lims_key = key
+        return self._lims
+
+    def _outside(self, xs, ys, reach):
+        """Indices of the particles whose window [x +- reach] x [y +- reach] leaves their map."""
+        L = self._limits()
+        xs, ys = np.asarray(xs), np.asarray(ys)
+        bad = (xs - reach < L[:, 0]) | (xs + reach > L[:, 1]) | (ys - reach < L[:, 2]) | (ys + reach > L[:, 3])
+        return np.flatnonzero(bad)
+
     def _grow_for_windows(self, xs, ys, reach):
         """checkAndExapndOG of every particle's search window (ScanMatcher_OGBased.py:27).  The
-        common case (window inside the map) is decided with four float compares per particle."""
+        common case (every window inside its map) is one vectorised comparison."""
         grew = False
-        for m, x, y in zip(self.engine.maps, xs, ys):
-            lx, ly = m.lim_x, m.lim_y
-            if x - reach >= lx[0] and x + reach <= lx[1] and y - reach >= ly[0] and y + reach <= ly[1]:
-                continue
+        for i in self._outside(xs, ys, reach):
+            m = self.engine.maps[i]
             n = len(m.growth_log)
-            m.ensure_contains([x - reach, x + reach], [y - reach, y + reach], self.lidar.unit)
+            m.ensure_contains([xs[i] - reach, xs[i] + reach], [ys[i] - reach, ys[i] + reach], self.lidar.unit)
             grew |= len(m.growth_log) != n
         if grew:
             self.engine.refresh_maps()
@@ -252,22 +267,15 @@ class ParticleFilter:
         """True when every particle's coarse window, widened by `margin` (the largest coarse
         displacement), lies inside its map: the fine window then needs no growth whatever the
         coarse result is, and the mid-scan synchronisation can be skipped."""
-        reach = self.coarse.reach + margin
-        for m, (x, y, _) in zip(self.engine.maps, est):
-            lx, ly = m.lim_x, m.lim_y
-            if not (x - reach >= lx[0] and x + reach <= lx[1] and y - reach >= ly[0] and y + reach <= ly[1]):
-                return False
-        return True
+        return self._outside(est[:, 0], est[:, 1], self.coarse.reach + margin).size == 0
 
     def _grow_for_update(self, matched):
         """The update window (pose +/- R) lies inside the search window that was grown for
         (estimate +/- (1.1 R + searchRadius)), except on the first scan of a small map."""
-        R = self.lidar.max_range
-        for m, (x, y, _) in zip(self.engine.maps, matched):
-            if x - R < m.lim_x[0] or x + R > m.lim_x[1] or y - R < m.lim_y[0] or y + R > m.lim_y[1]:
-                raise _lib.Slam2dError("the first scan's lidar window leaves the initial map: pre-size the map "
-                                       "(the per-beam growth of Utils/OccupancyGrid.py:147 is only reproduced by "
-                                       "the single-particle OccupancyGrid class)")
+        if self._outside(matched[:, 0], matched[:, 1], self.lidar.max_range).size:
+            raise _lib.Slam2dError("the first scan's lidar window leaves the initial map: pre-size the map "
+                                   "(the per-beam growth of Utils/OccupancyGrid.py:147 is only reproduced by "
+                                   "the single-particle OccupancyGrid class)")
 
     # ---- weights (Algorithm/FastSlam.py:30-48) ----
     def normalizeWeights(self):
