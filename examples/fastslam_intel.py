@@ -27,9 +27,8 @@ def main():
     ap.add_argument("--png", default=None)
     args = ap.parse_args()
     pkg = importlib.import_module("slam-2d-lidar-scan_amd")
-    z = np.load(os.path.join(REPO, "tests", "golden", "intel_gfs.npz"))
-    rng = z["range_cm"].astype(np.float64) / 100.0
-    readings = [{"x": float(p[0]), "y": float(p[1]), "theta": float(p[2]), "range": r} for p, r in zip(z["pose"], rng)]
+    dataio = importlib.import_module("slam-2d-lidar-scan_amd.dataio")
+    readings = dataio.read_npz(os.path.join(REPO, "tests", "golden", "intel_gfs.npz"))
     u = 0.02
     ogP = [args.map_m, args.map_m, readings[0], u, np.pi, 10, 180, 5 * u]          # FastSlam.py:204 order
     smP = [1.4, 0.25, 2, 0.1, 0.25, 0.3, 0.15, 5]                                   # FastSlam.py:198-199
@@ -50,7 +49,8 @@ def main():
     best = int(np.argmax(pf.weights))
     traj = np.array([t[best] for t in pf.trajectory])
     length = np.hypot(*np.diff(traj, axis=0).T).sum()
-    raw_len = np.hypot(*np.diff(z["pose"][:n, :2], axis=0).T).sum()
+    raw_xy = np.array([[r["x"], r["y"]] for r in readings[:n]])
+    raw_len = np.hypot(*np.diff(raw_xy, axis=0).T).sum()
     print(f"{n} scans x {args.particles} particles in {el:.1f} s = {n / el:.1f} scans/s = "
           f"{n * args.particles / el:.0f} particle-scans/s")
     print(f"resamples at {resamples}; best particle {best}; weights min/max {pf.weights.min():.3e}/{pf.weights.max():.3e}")
