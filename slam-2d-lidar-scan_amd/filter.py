@@ -316,11 +316,37 @@ class ParticleFilter:
         self.apply_resample(idx)
         return idx
 
+    def _gather_maps(self, maps, idx):
+        """new[i] = copy of maps[idx[i]].  Maps of one extent are copied by a single gather kernel
+        (slam2d_gather_maps); ragged extents fall back to per-map device copies."""
+        ref = maps[0]
+        same = all((m.rows, m.cols, m.pitch) == (ref.rows, ref.cols, ref.pitch) for m in maps)
+        if not same:
+            return [maps[j].clone() for j in idx]
+        new = []
+        for j in idx:
+            src = maps[j]
+            m = MapState.__new__(MapState)
+            m.device, m.X, m.Y = src.device, src.X.copy(), src.Y.copy()
+            m.rows, m.cols, m.pitch = src.rows, src.cols, src.pitch
+            m.cells = torch.empty_like(src.cells)
+            m._alloc_bits()
+            m._sync_coords()
+            m.growth_log = list(src.growth_log)
+            new.append(m)
+        from .engine import upload_map_descs
+        d_src, d_dst = upload_map_descs(maps, self.device), upload_map_descs(new, self.device)
+        d_idx = torch.as_tensor(np.asarray(idx, dtype=np.int32), device=self.device)
+        _lib.check(_lib.lib().slam2d_gather_maps(_ptr(d_src), _ptr(d_dst), _ptr(d_idx), len(new),
+                                                 ref.rows * ref.pitch, _stream()), "slam2d_gather_maps")
+        torch.cuda.current_stream().synchronize()      # the descriptor uploads must outlive the kernel
+        return new
+
     def apply_resample(self, idx):
         n, P, first = self.total_particles, self.numParticles, self.first_index
         maps = self.engine.maps
         if not self.sharded:
-            self.engine.maps = [maps[j].clone() for j in idx]       # deepcopy of the chosen particles (:61)
+            self.engine.maps = self._gather_maps(maps, idx)         # deepcopy of the chosen particles (:61)
             local = np.asarray(idx)
             tidx = torch.as_tensor(local.astype(np.int64), device=self.device)
             self.d_pose = self.d_pose[tidx].contiguous()

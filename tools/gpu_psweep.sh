@@ -1,0 +1,8 @@
+for P in 8 16 32 64 128 256 512; do
+ timeout 300 python bench.py --particles $P --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
+import sys, json
+for line in sys.stdin:
+    if line.startswith('{'):
+        d = json.loads(line); print('P', d['config']['particles_per_gpu'], 'value', round(d['value']), 'ms/step', round(d['ms_per_step'],3))
+"
+done
