@@ -258,6 +258,17 @@ int slam2d_post_match(const Slam2dMatch* d_fine, const Slam2dMatch* d_coarse, in
 int slam2d_weights_normalize(double* d_logw, const double* d_logconf, int32_t logconf_stride, int32_t N,
                              double* d_w, double* d_stats, void* stream);
 
+/* The same normaliser for particles sharded over several processes (one per GPU).  Rank-local
+ * half: d_logw[i] += d_logconf[i * logconf_stride], then d_part[3] = [max log w, sum exp(lw - max),
+ * sum exp(2 (lw - max))] of this rank's N particles.  The caller all-gathers the 24 bytes of every
+ * rank (the only collective of a scan) and hands the [world][3] array to slam2d_weights_merge,
+ * which folds it in rank order, writes this rank's normalised weights / log-weights and
+ * d_stats[2] = [sum over ALL particles of (w - 1/total)^2, log of the pre-normalisation sum]. */
+int slam2d_weights_local(double* d_logw, const double* d_logconf, int32_t logconf_stride, int32_t N,
+                         double* d_part, void* stream);
+int slam2d_weights_merge(double* d_logw, int32_t N, const double* d_parts, int32_t world,
+                         int64_t total_particles, double* d_w, double* d_stats, void* stream);
+
 /* ParticleFilter.resample's state movement (Algorithm/FastSlam.py:56-61) for maps of
  * identical shape: dst[p] = src[d_index[p]].  Ragged maps are copied by the host with
  * plain device-to-device copies instead. */

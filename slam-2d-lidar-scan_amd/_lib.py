@@ -106,6 +106,8 @@ SIGNATURES = {
     "slam2d_prior": (C.c_int, [_vp, C.c_double, C.c_double, C.c_int32, C.c_double, _vp, C.c_int32, _vp, _vp, _vp]),
     "slam2d_post_match": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, _vp, _vp]),
     "slam2d_weights_normalize": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
+    "slam2d_weights_local": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _vp, _vp]),
+    "slam2d_weights_merge": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, C.c_int64, _vp, _vp, _vp]),
     "slam2d_gather_maps": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int64, _vp]),
     "slam2d_map_fill": (C.c_int, [_vp, C.c_int64, C.c_uint32, _vp]),
     "slam2d_map_refresh_bits": (C.c_int, [_vp, _vp, C.c_int32, _vp]),

@@ -1047,6 +1047,63 @@ __global__ __launch_bounds__(256) void k_weights(double* logw, const double* __r
     if (tid == 0) { stats[0] = red[0]; stats[1] = lse; }
 }
 
+// Sharded normaliser, rank-local half: log-weights += log-confidence, then this rank's
+// [max log w, sum exp(lw - max), sum exp(2 (lw - max))].  The three doubles of every rank are
+// exchanged by ONE all-gather (24 bytes per rank) and merged by k_weights_merge.
+__global__ __launch_bounds__(256) void k_weights_local(double* logw, const double* __restrict__ logconf, int cstride,
+                                                       int N, double* part) {
+    __shared__ double red[256];
+    __shared__ double red2[256];
+    const int tid = threadIdx.x;
+    double mx = -INFINITY;
+    for (int i = tid; i < N; i += 256) {
+        double v = logw[i] + (logconf ? logconf[(size_t)i * cstride] : 0.0);
+        logw[i] = v;
+        mx = fmax(mx, v);
+    }
+    red[tid] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] = fmax(red[tid], red[tid + o]); __syncthreads(); }
+    mx = red[0];
+    __syncthreads();
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = tid; i < N; i += 256) {
+        const double e = exp(logw[i] - mx);
+        s1 += e;
+        s2 += e * e;
+    }
+    red[tid] = s1;
+    red2[tid] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { red[tid] += red[tid + o]; red2[tid] += red2[tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) { part[0] = mx; part[1] = red[0]; part[2] = red2[0]; }
+}
+
+// Sharded normaliser, merge half: every rank folds the gathered [world][3] partials in rank order
+// (so the result does not depend on the network's reduction order), normalises its own particles
+// and evaluates sum (w - 1/N)^2 = sum w^2 - 1/N over ALL N particles (Algorithm/FastSlam.py:32-35).
+__global__ __launch_bounds__(256) void k_weights_merge(double* logw, int N, const double* __restrict__ parts, int world,
+                                                       double total_particles, double* w, double* stats) {
+    double gm = -INFINITY;
+    for (int r = 0; r < world; ++r) gm = fmax(gm, parts[3 * r]);
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < world; ++r) {
+        const double sc = exp(parts[3 * r] - gm);
+        s1 += parts[3 * r + 1] * sc;
+        s2 += parts[3 * r + 2] * sc * sc;
+    }
+    const double lse = gm + log(s1);
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const double lw = logw[i];
+        w[i] = exp(lw - gm) / s1;
+        logw[i] = lw - lse;
+    }
+    if (threadIdx.x == 0) { stats[0] = s2 / (s1 * s1) - 1.0 / total_particles; stats[1] = lse; }
+}
+
 // ------------------------------------------------------------------------------------
 // K5  odometry prior / post-match bookkeeping          (Algorithm/FastSlam.py:77-120,131-135)
 // ------------------------------------------------------------------------------------
@@ -1256,6 +1313,20 @@ int slam2d_weights_normalize(double* d_logw, const double* d_logconf, int32_t lo
                              double* d_stats, void* stream) {
     if (!d_logw || !d_w || !d_stats || N <= 0 || (d_logconf && logconf_stride < 1)) return SLAM2D_E_BADARG;
     k_weights<<<1, 256, 0, (hipStream_t)stream>>>(d_logw, d_logconf, logconf_stride, N, d_w, d_stats);
+    return launch_status();
+}
+
+int slam2d_weights_local(double* d_logw, const double* d_logconf, int32_t logconf_stride, int32_t N, double* d_part,
+                         void* stream) {
+    if (!d_logw || !d_part || N <= 0 || (d_logconf && logconf_stride < 1)) return SLAM2D_E_BADARG;
+    k_weights_local<<<1, 256, 0, (hipStream_t)stream>>>(d_logw, d_logconf, logconf_stride, N, d_part);
+    return launch_status();
+}
+
+int slam2d_weights_merge(double* d_logw, int32_t N, const double* d_parts, int32_t world, int64_t total_particles,
+                         double* d_w, double* d_stats, void* stream) {
+    if (!d_logw || !d_parts || !d_w || !d_stats || N <= 0 || world <= 0 || total_particles < N) return SLAM2D_E_BADARG;
+    k_weights_merge<<<1, 256, 0, (hipStream_t)stream>>>(d_logw, N, d_parts, world, (double)total_particles, d_w, d_stats);
     return launch_status();
 }
 

@@ -139,6 +139,7 @@ class ParticleFilter:
         self.particles = [ParticleView(self, i) for i in range(P)]
         self.last_confidence = np.ones(P)
         self.last_variance = None
+        self._normalizer = None
         self.step = 0
 
     # ---- odometry prior (Algorithm/FastSlam.py:77-106) ----
@@ -279,16 +280,16 @@ class ParticleFilter:
 
     # ---- weights (Algorithm/FastSlam.py:30-48) ----
     def normalizeWeights(self):
-        """weights <- weights / sum (:43-48) in the log domain.  Sharded: all-reduce(MAX) + all-reduce(SUM)
-        of the normaliser (parallel.normalize_sharded), then an all-gather of the N weights so that
+        """weights <- weights / sum (:43-48) in the log domain.  Sharded: one all-gather of every rank's
+        three partial sums (parallel.ShardedNormalizer), then an all-gather of the N weights so that
         every rank evaluates the degeneracy test on identical numbers.  ``self.weights`` holds this
         rank's particles, ``self.all_weights`` all N."""
         n = self.total_particles
         if self.sharded:
-            w, logw, _ = parallel.normalize_sharded(self.d_logw, n, self.group)
-            self.d_logw.copy_(logw)
-            self.d_w.copy_(w)
-            self.all_weights = parallel.gather_weights(w, n, self.world, self.group).cpu().numpy()
+            if self._normalizer is None:
+                self._normalizer = parallel.ShardedNormalizer(_lib.lib(), _lib.check, self.device, n, self.group)
+            self._normalizer(self.d_logw, None, 1, self.d_w, self.d_stats)
+            self.all_weights = parallel.gather_weights(self.d_w, n, self.world, self.group).cpu().numpy()
             self.weights = self.all_weights[self.first_index:self.first_index + self.numParticles].copy()
         else:
             L = _lib.lib()

@@ -74,6 +74,40 @@ def normalize_sharded(logw_local, total, group=None):
     return w, logw, variance
 
 
+class ShardedNormalizer:
+    """``normalize_sharded`` for device-resident particles as two HIP launches around the one
+    collective: ``slam2d_weights_local`` (log-weights += log-confidence, this rank's three partials),
+    an all-gather of the 24 bytes of every rank, ``slam2d_weights_merge`` (fold in rank order,
+    normalise this rank's particles, variance over all N).  The torch-op version above costs a dozen
+    small launches per scan (measured 77 us on one MI355X -- a quarter of a config-2 step)."""
+
+    def __init__(self, lib, check, device, total, group=None):
+        self.lib, self.check, self.total, self.group = lib, check, int(total), group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.part = torch.zeros(3, dtype=torch.float64, device=device)
+        self.parts = torch.zeros(3 * self.world, dtype=torch.float64, device=device)
+        self.via_host = dist.is_initialized() and dist.get_backend(group) == "gloo"
+
+    def __call__(self, logw, logconf_ptr, logconf_stride, w, stats):
+        """In place on ``logw`` (this rank's log-weights); writes ``w`` and ``stats`` =
+        [sum over all particles of (w - 1/N)^2, log of the pre-normalisation sum]."""
+        stream = torch.cuda.current_stream(logw.device).cuda_stream
+        n = logw.numel()
+        self.check(self.lib.slam2d_weights_local(logw.data_ptr(), logconf_ptr, logconf_stride, n,
+                                                 self.part.data_ptr(), stream), "slam2d_weights_local")
+        if not dist.is_initialized():
+            self.parts.copy_(self.part)
+        elif self.via_host:                                   # gloo: the 24 bytes hop through host memory
+            mine = self.part.cpu()
+            got = [torch.empty_like(mine) for _ in range(self.world)]
+            dist.all_gather(got, mine, group=self.group)
+            self.parts.copy_(torch.cat(got))
+        else:
+            dist.all_gather_into_tensor(self.parts, self.part, group=self.group)
+        self.check(self.lib.slam2d_weights_merge(logw.data_ptr(), n, self.parts.data_ptr(), self.world, self.total,
+                                                 w.data_ptr(), stats.data_ptr(), stream), "slam2d_weights_merge")
+
+
 def gather_weights(w_local, total, world, group=None):
     """All N normalised weights on every rank, in particle order (ragged shards allowed)."""
     if not dist.is_initialized() or world == 1:

@@ -326,6 +326,51 @@ def test_weights_kernel(pkg):
         np.testing.assert_allclose(np.exp(d_lw.cpu().numpy()), w, rtol=1e-10)
 
 
+def test_sharded_weights_kernels(pkg):
+    """slam2d_weights_local + slam2d_weights_merge over emulated ranks (ragged shards) give the
+    weights, log-weights and variance of the single-process normaliser over all particles, and
+    agree with the torch-op restatement parallel.normalize_sharded."""
+    import torch
+    from importlib import import_module
+    flt = import_module("slam-2d-lidar-scan_amd.filter")
+    par = import_module("slam-2d-lidar-scan_amd.parallel")
+    L = flt._lib.lib()
+    rs = np.random.RandomState(11)
+    for n, world in ((7, 1), (64, 2), (130, 3), (1000, 8)):
+        logw = rs.uniform(-300, -5, n)
+        logc = rs.uniform(-200, 1, (n, 3))                          # strided log-confidences
+        shards = [par.shard_range(n, world, r) for r in range(world)]
+        d_lw = [torch.from_numpy(logw[f:f + c].copy()).cuda() for f, c in shards]
+        d_lc = [torch.from_numpy(logc[f:f + c].copy()).cuda() for f, c in shards]
+        parts = torch.zeros(3 * world, dtype=torch.float64, device="cuda")
+        for r in range(world):
+            flt._lib.check(L.slam2d_weights_local(flt._ptr(d_lw[r]), d_lc[r].data_ptr() + 8, 3, shards[r][1],
+                                                  parts.data_ptr() + 24 * r, flt._stream()), "local")
+        s = logw + logc[:, 1]
+        w = np.exp(s - s.max()); w /= w.sum()
+        for r, (f, c) in enumerate(shards):
+            d_w = torch.zeros(c, dtype=torch.float64, device="cuda")
+            d_s = torch.zeros(2, dtype=torch.float64, device="cuda")
+            flt._lib.check(L.slam2d_weights_merge(flt._ptr(d_lw[r]), c, flt._ptr(parts), world, n, flt._ptr(d_w),
+                                                  flt._ptr(d_s), flt._stream()), "merge")
+            np.testing.assert_allclose(d_w.cpu().numpy(), w[f:f + c], rtol=1e-12)
+            np.testing.assert_allclose(np.exp(d_lw[r].cpu().numpy()), w[f:f + c], rtol=1e-10)
+            np.testing.assert_allclose(d_s[0].item(), ((w - 1 / n) ** 2).sum(), rtol=1e-9, atol=1e-15)
+            np.testing.assert_allclose(d_s[1].item(), s.max() + np.log(np.exp(s - s.max()).sum()), rtol=1e-13)
+    # the host-side wrapper without a process group == the torch-op version
+    norm = par.ShardedNormalizer(L, flt._lib.check, "cuda", 64)
+    lw = torch.from_numpy(rs.uniform(-50, 0, 64)).cuda()
+    tw, tlw, tvar = par.normalize_sharded(lw.clone(), 64)
+    d_w = torch.zeros(64, dtype=torch.float64, device="cuda")
+    d_s = torch.zeros(2, dtype=torch.float64, device="cuda")
+    norm(lw, None, 1, d_w, d_s)
+    np.testing.assert_allclose(d_w.cpu().numpy(), tw.cpu().numpy(), rtol=1e-12)
+    np.testing.assert_allclose(lw.cpu().numpy(), tlw.cpu().numpy(), rtol=1e-12)
+    np.testing.assert_allclose(d_s[0].item(), tvar.item(), rtol=1e-9, atol=1e-15)
+    assert L.slam2d_weights_local(None, None, 1, 4, None, None) < 0
+    assert L.slam2d_weights_merge(flt._ptr(lw), 64, flt._ptr(d_s), 1, 8, flt._ptr(d_w), flt._ptr(d_s), None) < 0
+
+
 def test_large_synthetic_properties(pkg):
     """Size-independent properties at BASELINE config-2 size with 8 particles: identical
     particles give identical results (batch determinism), the update kernel touches each
