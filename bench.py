@@ -138,6 +138,7 @@ class HotPath:
         self.stream = torch.cuda.Stream(device=device) if total and total != P else None
         self.done = torch.cuda.Event()
         self.normalizer = None
+        self.lazy = os.environ.get("SLAM2D_BENCH_FULL_FIELD", "0") != "1"   # slam2d_match vs field_build + sweep
         self.side = None
         if os.environ.get("SLAM2D_BENCH_OVERLAP_WEIGHTS", "0") == "1" and self.stream is None:
             self.side = torch.cuda.Stream(device=device)
@@ -148,10 +149,12 @@ class HotPath:
         """Field build, sweep (both levels) and map update of this group's particles for scan s."""
         e, E = self.eng, self.E
         est, rng = self.d_est[s], self.d_ranges[s]
-        e.field_build(self.coarse, est, 3)
+        if not self.lazy:
+            e.field_build(self.coarse, est, 3)
         if self.side is not None:
             torch.cuda.current_stream().wait_event(self.side_done)     # last scan's normaliser has read m_coarse
-        e.sweep(self.coarse, est, 3, rng, float(self.dist[s]), self.d_psi[s], self.d_uniform[s], self.m_coarse)
+        (e.match if self.lazy else e.sweep)(self.coarse, est, 3, rng, float(self.dist[s]), self.d_psi[s],
+                                            self.d_uniform[s], self.m_coarse)
         if self.side is not None:
             # the weights need only the coarse confidence (the reference returns the COARSE confidence,
             # Utils/ScanMatcher_OGBased.py:74-79): normalise -- local sums, the all-gather, merge -- on a
@@ -163,8 +166,10 @@ class HotPath:
                 self.side_done.record()
         final = self.m_coarse
         if self.fine is not None:
-            e.field_build(self.fine, self.m_coarse, E.MATCH_DOUBLES)
-            e.sweep(self.fine, self.m_coarse, E.MATCH_DOUBLES, rng, float(self.dist[s]), None, None, self.m_fine)
+            if not self.lazy:
+                e.field_build(self.fine, self.m_coarse, E.MATCH_DOUBLES)
+            (e.match if self.lazy else e.sweep)(self.fine, self.m_coarse, E.MATCH_DOUBLES, rng, float(self.dist[s]),
+                                                None, None, self.m_fine)
             final = self.m_fine
         e.grid_update(final, E.MATCH_DOUBLES, rng)
 

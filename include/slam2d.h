@@ -173,6 +173,8 @@ typedef struct {
     const double* vtable;    /* NULL, or [2^(2*blur_radius+1)] axis-0 blur result of every binary column
                                 window (bit k set = window row k occupied), filled with the kernel's
                                 operation order; used when blur_radius is 2 or 8 */
+    uint32_t* tileneed;      /* [P][ceil(tmax*tmax/32)] scratch of slam2d_match: bit t set = the sweep reads
+                                field tile t (may be NULL when only slam2d_field_build is used) */
 } Slam2dLevel;
 
 /* Result of one level for one particle. */
@@ -213,6 +215,20 @@ int slam2d_field_build(const Slam2dLidar* lidar, const Slam2dLevel* level, const
  *                                (matchMax=False, :136-139); NULL selects argmax (matchMax=True)
  * Writes level->cube[p] (convTotal), level->partials[p] and d_out[p]. */
 int slam2d_sweep(const Slam2dLidar* lidar, const Slam2dLevel* level, int32_t P,
+                 const double* d_est, int32_t est_stride, const double* d_ranges,
+                 double est_moving_dist, const double* d_psi_cs, const double* d_uniform,
+                 Slam2dMatch* d_out, uint32_t* d_flags, void* stream);
+
+/* matchScan's work at ONE level for P particles: frameSearchSpace + generateProbSearchSpace +
+ * searchToMatch (Utils/ScanMatcher_OGBased.py:20-45,91-151) in one call, arguments as for the two
+ * calls above (the field is centred on d_est[p][0..1]).  Results (d_out, level->cube,
+ * level->partials) are identical to slam2d_field_build followed by slam2d_sweep; the difference is
+ * that only the 16x16 field tiles the sweep reads -- those within the search radius of a beam
+ * endpoint at some theta -- are blurred (typically 15-30 % of the tiles that hold a wall), so
+ * level->field is left incomplete: tiles outside that set keep stale content.  Falls back to the
+ * full build for a frame without a single free tile (the field minimum, :43, is then not known
+ * without computing everything). */
+int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2dMap* d_maps, int32_t P,
                  const double* d_est, int32_t est_stride, const double* d_ranges,
                  double est_moving_dist, const double* d_psi_cs, const double* d_uniform,
                  Slam2dMatch* d_out, uint32_t* d_flags, void* stream);

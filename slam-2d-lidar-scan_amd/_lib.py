@@ -81,7 +81,7 @@ class Slam2dLevel(C.Structure):
                 ("cells", _vp), ("kcount", _vp), ("beam_xy", _vp), ("prior", _vp), ("cube", _vp),
                 ("partials", _vp), ("npartial", C.c_int32), ("tmax", C.c_int32), ("tilemask", _vp),
                 ("tilestate", _vp), ("tilemin", _vp),
-                ("tilelist", _vp), ("tilecount", _vp), ("vtable", _vp)]
+                ("tilelist", _vp), ("tilecount", _vp), ("vtable", _vp), ("tileneed", _vp)]
 
 
 class Slam2dMatch(C.Structure):
@@ -101,6 +101,8 @@ SIGNATURES = {
     "slam2d_field_build": (C.c_int, [C.POINTER(Slam2dLidar), C.POINTER(Slam2dLevel), _vp, C.c_int32, _vp, C.c_int32,
                                      _vp, _vp]),
     "slam2d_sweep": (C.c_int, [C.POINTER(Slam2dLidar), C.POINTER(Slam2dLevel), C.c_int32, _vp, C.c_int32, _vp,
+                               C.c_double, _vp, _vp, _vp, _vp, _vp]),
+    "slam2d_match": (C.c_int, [C.POINTER(Slam2dLidar), C.POINTER(Slam2dLevel), _vp, C.c_int32, _vp, C.c_int32, _vp,
                                C.c_double, _vp, _vp, _vp, _vp, _vp]),
     "slam2d_grid_update": (C.c_int, [C.POINTER(Slam2dLidar), _vp, C.c_int32, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "slam2d_prior": (C.c_int, [_vp, C.c_double, C.c_double, C.c_int32, C.c_double, _vp, C.c_int32, _vp, _vp, _vp]),

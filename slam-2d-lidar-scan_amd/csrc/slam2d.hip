@@ -112,9 +112,13 @@ __device__ __forceinline__ Slam2dFrame make_frame(const Slam2dLidar& lid, const 
 // K2a+b  frame geometry (:21-28) and the field index of every window column / row (:32-36,173-176)
 // ------------------------------------------------------------------------------------
 __global__ void k_frame_axis(Slam2dLidar lid, Slam2dLevel lv, const Slam2dMap* __restrict__ maps,
-                             const double* __restrict__ centre, int cstride, uint32_t* flags) {
+                             const double* __restrict__ centre, int cstride, uint32_t* flags, int clear_need) {
     const int p = blockIdx.y, axis = blockIdx.z;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (clear_need && axis == 1) {                     // the needed-tile bitmap of slam2d_match
+        const int nneed = (lv.tmax * lv.tmax + 31) >> 5;
+        for (int w = j; w < nneed; w += gridDim.x * blockDim.x) lv.tileneed[(size_t)p * nneed + w] = 0u;
+    }
     const Slam2dMap m = maps[p];
     uint32_t f;
     const Slam2dFrame fr = make_frame(lid, lv, m, centre[(size_t)p * cstride], centre[(size_t)p * cstride + 1], f);
@@ -380,75 +384,90 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
     __syncthreads();                                   // LDS is reused by the block's next tile
 }
 
-// Tile triage, one thread per 16x16 field tile: tiles with an occupied cell in their 3x3 tile
-// neighbourhood go to the blur work list; free tiles get their minimum recorded and, if the
-// field buffer does not already hold the free-space constant there, go to the fill list.
-// (Per-wave aggregated atomics: a wave's tiles belong to one particle.)
-__global__ __launch_bounds__(1024) void k_tile_classify(Slam2dLevel lv) {
-    // 1024 tiles per block; list positions = (one global atomic per block and list) + rank inside the
-    // block, so a particle's two counters see a handful of atomics instead of one per wave.
-    __shared__ int wave_cnt[2][16];
-    __shared__ int block_base[2];
-    const int p = blockIdx.y;
-    const int t = blockIdx.x * 1024 + threadIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// Tile triage, one 1024-thread block per particle looping over its 16x16 field tiles:
+//  * tiles with an occupied cell in their 3x3 tile neighbourhood go to the blur work list;
+//  * free tiles get their minimum recorded and, if the field buffer does not already hold the
+//    free-space constant there, are filled with it by this same block (no separate launch).
+// lazy != 0 (slam2d_match): only tiles the sweep will read (lv.tileneed, marked by k_endpoints) are
+// blurred or filled; the others keep their stale content and their tilestate.  This needs the field
+// minimum (:43) to be known without computing the whole field: it is the analytic floor as soon as
+// ONE tile of the frame is free (every cell of such a tile equals the floor and no blurred value is
+// below it).  A frame without any free tile falls back to the full build.
+#define TRIAGE_THREADS 1024
+__global__ __launch_bounds__(TRIAGE_THREADS) void k_tile_triage(Slam2dLevel lv, int lazy) {
+    __shared__ int wave_cnt[2][2][16];
+    __shared__ int base[2];
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const Slam2dFrame fr = lv.frames[p];
     const int nty = (fr.fh + BLUR_TILE - 1) >> BLUR_SHIFT, ntx = (fr.fw + BLUR_TILE - 1) >> BLUR_SHIFT;
-    const int ty = t / lv.tmax, tx = t - ty * lv.tmax;
-    const bool live = ty < nty && tx < ntx;
-    const uint8_t* tiles = lv.tilemask + (size_t)p * lv.tmax * lv.tmax;
-    int any = 0;
-    bool to_fill = false;
-    if (live) {
+    const int ntile = lv.tmax * lv.tmax;
+    const int iters = (ntile + TRIAGE_THREADS - 1) / TRIAGE_THREADS;          // <= 32 (checked by the host)
+    const uint8_t* tiles = lv.tilemask + (size_t)p * ntile;
+    uint32_t liveb = 0u, anyb = 0u;
+    int has_free = 0;
+    for (int it = 0; it < iters; ++it) {
+        const int t = it * TRIAGE_THREADS + tid;
+        const int ty = t / lv.tmax, tx = t - ty * lv.tmax;
+        if (t < ntile && ty < nty && tx < ntx) {
+            int any = 0;
 #pragma unroll
-        for (int dy = -1; dy <= 1; ++dy)
+            for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int yy = ty + dy, xx = tx + dx;
-                if (yy >= 0 && yy < nty && xx >= 0 && xx < ntx) any |= tiles[yy * lv.tmax + xx];
-            }
-        uint8_t* state = lv.tilestate + (size_t)p * lv.tmax * lv.tmax + t;
-        if (!any) {
-            lv.tilemin[(size_t)p * lv.tmax * lv.tmax + t] = lv.floor_value;
-            to_fill = *state != 0;
-            if (to_fill) *state = 0;
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int yy = ty + dy, xx = tx + dx;
+                    if (yy >= 0 && yy < nty && xx >= 0 && xx < ntx) any |= tiles[yy * lv.tmax + xx];
+                }
+            liveb |= 1u << it;
+            if (any) anyb |= 1u << it; else has_free = 1;
         }
     }
+    if (tid < 2) base[tid] = 0;
+    has_free = __syncthreads_or(has_free);
+    const bool everything = !lazy || !has_free;
+    const int nneed = (ntile + 31) >> 5;
+    const uint32_t* __restrict__ need = lv.tileneed + (size_t)p * nneed;
+    uint8_t* state = lv.tilestate + (size_t)p * ntile;
+    int* list = lv.tilelist + (size_t)p * 2 * ntile;
     const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
-    const bool mine[2] = {live && any != 0, to_fill};
-    int rank[2];
+    for (int it = 0; it < iters; ++it) {
+        const int t = it * TRIAGE_THREADS + tid;
+        const bool live = (liveb >> it) & 1u, any = (anyb >> it) & 1u;
+        const bool wanted = live && (everything || ((need[t >> 5] >> (t & 31)) & 1u));
+        bool to_fill = false;
+        if (live && !any) {
+            lv.tilemin[(size_t)p * ntile + t] = lv.floor_value;
+            if (wanted && state[t] != 0) { to_fill = true; state[t] = 0; }
+        }
+        const bool mine[2] = {wanted && any, to_fill};
+        int rank[2];
 #pragma unroll
-    for (int which = 0; which < 2; ++which) {
-        const unsigned long long mask = __ballot(mine[which]);
-        rank[which] = __popcll(mask & below);
-        if (lane == 0) wave_cnt[which][wave] = __popcll(mask);
+        for (int which = 0; which < 2; ++which) {
+            const unsigned long long mask = __ballot(mine[which]);
+            rank[which] = __popcll(mask & below);
+            if (lane == 0) wave_cnt[it & 1][which][wave] = __popcll(mask);
+        }
+        __syncthreads();
+        if (tid < 2) {
+            int tot = base[tid];
+            for (int w2 = 0; w2 < 16; ++w2) { const int c = wave_cnt[it & 1][tid][w2]; wave_cnt[it & 1][tid][w2] = tot; tot += c; }
+            base[tid] = tot;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int which = 0; which < 2; ++which)
+            if (mine[which]) list[which * ntile + wave_cnt[it & 1][which][wave] + rank[which]] = t;
     }
     __syncthreads();
-    if (threadIdx.x < 2) {
-        int tot = 0;
-        for (int w2 = 0; w2 < 16; ++w2) { const int c = wave_cnt[threadIdx.x][w2]; wave_cnt[threadIdx.x][w2] = tot; tot += c; }
-        block_base[threadIdx.x] = tot ? atomicAdd(&lv.tilecount[2 * p + threadIdx.x], tot) : 0;
-    }
-    __syncthreads();
-    int* list = lv.tilelist + (size_t)p * 2 * lv.tmax * lv.tmax;
-#pragma unroll
-    for (int which = 0; which < 2; ++which)
-        if (mine[which]) list[which * lv.tmax * lv.tmax + block_base[which] + wave_cnt[which][wave] + rank[which]] = t;
-}
-
-// Free tiles whose buffer content is stale: store the free-space constant (whole tile, also
-// beyond the current frame, so that the tile stays valid when the frame grows by its +-1 jitter).
-__global__ __launch_bounds__(256) void k_tile_fill(Slam2dLevel lv) {
-    const int p = blockIdx.y, tid = threadIdx.x;
-    const int n = lv.tilecount[2 * p + 1];
-    const int* list = lv.tilelist + (size_t)p * 2 * lv.tmax * lv.tmax + lv.tmax * lv.tmax;
+    if (tid < 2) lv.tilecount[2 * p + tid] = base[tid];
+    // fill: one wave per tile, 64 lanes x 16 bytes = the tile's 256 cells (the whole tile, also beyond the
+    // current frame, so that the tile stays valid when the frame grows by its +-1 jitter)
+    const int nfill = base[1];
     const double v = lv.floor_value;
     const uint32_t c = v > 0.5 * v ? 0u : (uint32_t)rint(-v * lv.cost_scale);
     uint32_t* field = lv.field + (size_t)p * lv.fmax * lv.fpitch;
-    // one wave per tile: 64 lanes x 16 bytes = the tile's 256 cells
-    const int wave = tid >> 6, lane = tid & 63;
-    for (int b = blockIdx.x * 4 + wave; b < n; b += gridDim.x * 4) {
-        const int t = list[b];
+    for (int b = wave; b < nfill; b += TRIAGE_THREADS / 64) {
+        const int t = list[ntile + b];
         const int ty0 = (t / lv.tmax) * BLUR_TILE, tx0 = (t % lv.tmax) * BLUR_TILE;
         const int y = lane >> 2, x = (lane & 3) * 4;
         if (ty0 + y < lv.fmax && tx0 + x + 3 < lv.fpitch)
@@ -561,12 +580,14 @@ __global__ void k_beam_points(Slam2dLidar lid, Slam2dLevel lv, const double* __r
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel lv, const double* __restrict__ est,
                                                    int estride, const double* __restrict__ ranges, uint32_t* flags,
-                                                   double est_dist, const double* __restrict__ psi_cs) {
+                                                   double est_dist, const double* __restrict__ psi_cs, int mark) {
     // np.unique (:120) through an LDS hash set: every beam inserts its cell; of the beams that hit one
     // cell the lowest beam index owns it (atomicMin), so the list keeps beam order -- which is spatially
     // coherent (neighbouring beams hit neighbouring cells) and deterministic.  Scores are exact
     // integer sums, so the order of the list cannot change a result.
-    extern __shared__ __attribute__((aligned(16))) int ep_lds[];     // [2n] keys, [2n] owners, [8] wave counts
+    // mark != 0 (slam2d_match): the block also ORs the 16x16 field tiles its patches touch into
+    // lv.tileneed, through an LDS bitmap, so that the field build can skip every other tile.
+    extern __shared__ __attribute__((aligned(16))) int ep_lds[];     // [2n] keys, [2n] owners, [8] wave counts, [nneed] tiles
     const int it = blockIdx.x, p = blockIdx.y, tid = threadIdx.x;
     const Slam2dFrame fr = lv.frames[p];
     const double ex = est[(size_t)p * estride], ey = est[(size_t)p * estride + 1];
@@ -578,6 +599,9 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
     int* hown = ep_lds + hsize;
     int* cnt_s = ep_lds + 2 * hsize;
     for (int i = tid; i < hsize; i += 256) { hkey[i] = INT_MAX; hown[i] = INT_MAX; }
+    uint32_t* need_s = reinterpret_cast<uint32_t*>(ep_lds + 2 * hsize + 8);
+    const int nneed = (lv.tmax * lv.tmax + 31) >> 5;
+    if (mark) for (int i = tid; i < nneed; i += 256) need_s[i] = 0u;
     const double c = lv.theta_cos[it], s = lv.theta_sin[it];
     const int nc = lv.ncell;
     const int per = n / 256;                               // beams per thread, contiguous: [tid*per, tid*per + per)
@@ -614,8 +638,25 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
         }
         slot[q] = h;
         atomicMin(&hown[h], tid * per + q);
+        if (mark) {                                        // tiles of the (2 nc + 1)^2 patch at (x0, y0)
+            const int y0 = key[q] / lv.fpitch, x0 = key[q] - y0 * lv.fpitch;
+            const int tx0 = x0 >> BLUR_SHIFT, tx1 = (x0 + 2 * nc) >> BLUR_SHIFT;
+            for (int ty = y0 >> BLUR_SHIFT; ty <= (y0 + 2 * nc) >> BLUR_SHIFT; ++ty)
+                for (int tx = tx0; tx <= tx1;) {           // runs of bits inside one 32-bit word
+                    const int bit = ty * lv.tmax + tx;
+                    const int len = min(tx1 - tx + 1, 32 - (bit & 31));
+                    atomicOr(&need_s[bit >> 5], (len == 32 ? ~0u : ((1u << len) - 1u)) << (bit & 31));
+                    tx += len;
+                }
+        }
     }
     __syncthreads();
+    if (mark)
+        for (int i = tid; i < nneed; i += 256) {
+            const uint32_t v = need_s[i];
+            uint32_t* g = lv.tileneed + (size_t)p * nneed + i;
+            if (v && (__hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & v) != v) atomicOr(g, v);
+        }
     int keep = 0, mine = 0;
 #pragma unroll
     for (int q = 0; q < SLAM2D_MAX_BEAMS / 256; ++q)
@@ -1194,25 +1235,30 @@ static int check_level(const Slam2dLidar* lidar, const Slam2dLevel* lv, int P) {
     return 0;
 }
 
-int slam2d_field_build(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2dMap* d_maps, int32_t P,
-                       const double* d_centre, int32_t centre_stride, uint32_t* d_flags, void* stream) {
-    int rc = check_level(lidar, level, P);
-    if (rc) return rc;
-    if (!d_maps || !d_centre || !d_flags || centre_stride < 2) return SLAM2D_E_BADARG;
-    hipStream_t s = (hipStream_t)stream;
-    const Slam2dLevel& lv = *level;
-    k_frame_axis<<<dim3(cdiv(lv.wmax, 256), P, 2), 256, 0, s>>>(*lidar, lv, d_maps, d_centre, centre_stride, d_flags);
+// ---- launch sequences shared by slam2d_field_build / slam2d_sweep / slam2d_match ----
+static int check_field_args(const Slam2dLevel& lv, int P, bool lazy) {
     if (lv.tilemask != lv.occ + (size_t)P * lv.fmax * lv.fpitch || !lv.tilestate || !lv.tilemin || !lv.tilelist || !lv.tilecount)
         return SLAM2D_E_BADARG;
-    hipError_t e = hipMemsetAsync(lv.occ, 0, (size_t)P * lv.fmax * lv.fpitch + (size_t)P * lv.tmax * lv.tmax, s);
-    if (e != hipSuccess) return (int)e;
+    if (lazy && !lv.tileneed) return SLAM2D_E_BADARG;
+    if (cdiv(lv.tmax * lv.tmax, TRIAGE_THREADS) > 32) return SLAM2D_E_TOOLARGE;
+    return 0;
+}
+
+// frame geometry, axis index vectors, cleared occupancy image / tile flags (/ needed-tile bitmap)
+static int launch_frames(const Slam2dLidar& lid, const Slam2dLevel& lv, const Slam2dMap* d_maps, int P,
+                         const double* d_centre, int centre_stride, uint32_t* d_flags, bool lazy, hipStream_t s) {
+    k_frame_axis<<<dim3(cdiv(lv.wmax, 256), P, 2), 256, 0, s>>>(lid, lv, d_maps, d_centre, centre_stride, d_flags, lazy ? 1 : 0);
+    return (int)hipMemsetAsync(lv.occ, 0, (size_t)P * lv.fmax * lv.fpitch + (size_t)P * lv.tmax * lv.tmax, s);
+}
+
+// occupied cells -> field image, tile triage (+ fill), blur + clamp, minimum check
+static void launch_field(const Slam2dLevel& lv, const Slam2dMap* d_maps, int P, uint32_t* d_flags, bool lazy, hipStream_t s) {
     {
         StageScope prof(SLAM2D_STAGE_SCATTER, s);
         k_occ_scatter<<<dim3(cdiv(cdiv(lv.wmax, 32) + 1, 64), cdiv(lv.wmax, SCATTER_ROWS), P), dim3(64, 4), 0, s>>>(lv, d_maps);
     }
     const int ntile = lv.tmax * lv.tmax;
-    k_tile_classify<<<dim3(cdiv(ntile, 1024), P), 1024, 0, s>>>(lv);
-    k_tile_fill<<<dim3(min(cdiv(ntile, 4), 64), P), 256, 0, s>>>(lv);
+    k_tile_triage<<<P, TRIAGE_THREADS, 0, s>>>(lv, lazy ? 1 : 0);
     {
         StageScope prof(SLAM2D_STAGE_BLUR, s);
         const dim3 bgrid(min(ntile, SLAM2D_BLUR_BLOCKS_PER_PARTICLE), P);
@@ -1227,32 +1273,28 @@ int slam2d_field_build(const Slam2dLidar* lidar, const Slam2dLevel* level, const
         case 8: k_blur_check_redo<8><<<P, 256, 0, s>>>(lv, d_flags); break;
         default: k_blur_check_redo<0><<<P, 256, 0, s>>>(lv, d_flags); break;
     }
-    return launch_status();
 }
 
-int slam2d_sweep(const Slam2dLidar* lidar, const Slam2dLevel* level, int32_t P, const double* d_est,
-                 int32_t est_stride, const double* d_ranges, double est_moving_dist, const double* d_psi_cs,
-                 const double* d_uniform, Slam2dMatch* d_out, uint32_t* d_flags, void* stream) {
-    int rc = check_level(lidar, level, P);
-    if (rc) return rc;
-    if (!d_est || !d_ranges || !d_out || !d_flags || est_stride < 3) return SLAM2D_E_BADARG;
-    const Slam2dLevel& lv = *level;
-    if (lv.kmax < lidar->beams || !lv.partials || !lv.beam_xy) return SLAM2D_E_BADARG;
-    hipStream_t s = (hipStream_t)stream;
-    const int nx = 2 * lv.ncell + 1, npose = nx * nx;
-    {
-        StageScope prof(SLAM2D_STAGE_ENDPOINTS, s);
-        k_beam_points<<<dim3(cdiv(lidar->beams, 256), P), 256, 0, s>>>(*lidar, lv, d_est, est_stride, d_ranges);
-        int n = 256;
-        while (n < lidar->beams) n <<= 1;
-        const size_t ep_lds = (size_t)(4 * n + 8) * sizeof(int);
-        k_endpoints<<<dim3(lv.ntheta, P), 256, ep_lds, s>>>(*lidar, lv, d_est, est_stride, d_ranges, d_flags,
-                                                            est_moving_dist, lv.fine ? nullptr : d_psi_cs);
-    }
-    // slots (4 consecutive dx) per lane RQ
-    const int nslot = nx * ((nx + 3) / 4);
+// beam endpoints, unique cells per theta, priors (/ needed tiles)
+static void launch_endpoints(const Slam2dLidar& lid, const Slam2dLevel& lv, int P, const double* d_est, int est_stride,
+                             const double* d_ranges, double est_moving_dist, const double* d_psi_cs, uint32_t* d_flags,
+                             bool mark, hipStream_t s) {
+    StageScope prof(SLAM2D_STAGE_ENDPOINTS, s);
+    k_beam_points<<<dim3(cdiv(lid.beams, 256), P), 256, 0, s>>>(lid, lv, d_est, est_stride, d_ranges);
+    int n = 256;
+    while (n < lid.beams) n <<= 1;
+    const size_t ep_lds = (size_t)(4 * n + 8 + (mark ? (lv.tmax * lv.tmax + 31) / 32 : 0)) * sizeof(int);
+    k_endpoints<<<dim3(lv.ntheta, P), 256, ep_lds, s>>>(lid, lv, d_est, est_stride, d_ranges, d_flags, est_moving_dist,
+                                                        lv.fine ? nullptr : d_psi_cs, mark ? 1 : 0);
+}
+
+// cube sweep + selection
+static int launch_scores(const Slam2dLevel& lv, int P, const double* d_est, int est_stride, const double* d_uniform,
+                         Slam2dMatch* d_out, hipStream_t s) {
+    const int nx = 2 * lv.ncell + 1;
+    const int nslot = nx * ((nx + 3) / 4);            // slots of 4 consecutive dx
     const int need = cdiv(nslot, WAVE);
-    int bestR = 1;        // measured on MI355X (config 2): RQ = 1 124 us, RQ = 2..4 132-134 us
+    int bestR = 1;        // slots per lane; measured on MI355X (config 2): 1 -> 124 us, 2..4 -> 132-134 us
     if (const char* ov = getenv("SLAM2D_SWEEP_R")) {              // tuning knob
         const int R = atoi(ov);
         if (R >= 1 && R <= 4) bestR = R;
@@ -1272,6 +1314,50 @@ int slam2d_sweep(const Slam2dLidar* lidar, const Slam2dLevel* level, int32_t P, 
         StageScope prof(SLAM2D_STAGE_SELECT, s);
         k_select<<<P, WAVE, 0, s>>>(lv, chunks, bestR, d_est, est_stride, d_uniform, d_out);
     }
+    return 0;
+}
+
+int slam2d_field_build(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2dMap* d_maps, int32_t P,
+                       const double* d_centre, int32_t centre_stride, uint32_t* d_flags, void* stream) {
+    int rc = check_level(lidar, level, P);
+    if (rc) return rc;
+    if (!d_maps || !d_centre || !d_flags || centre_stride < 2) return SLAM2D_E_BADARG;
+    if ((rc = check_field_args(*level, P, false))) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = launch_frames(*lidar, *level, d_maps, P, d_centre, centre_stride, d_flags, false, s))) return rc;
+    launch_field(*level, d_maps, P, d_flags, false, s);
+    return launch_status();
+}
+
+int slam2d_sweep(const Slam2dLidar* lidar, const Slam2dLevel* level, int32_t P, const double* d_est,
+                 int32_t est_stride, const double* d_ranges, double est_moving_dist, const double* d_psi_cs,
+                 const double* d_uniform, Slam2dMatch* d_out, uint32_t* d_flags, void* stream) {
+    int rc = check_level(lidar, level, P);
+    if (rc) return rc;
+    if (!d_est || !d_ranges || !d_out || !d_flags || est_stride < 3) return SLAM2D_E_BADARG;
+    const Slam2dLevel& lv = *level;
+    if (lv.kmax < lidar->beams || !lv.partials || !lv.beam_xy) return SLAM2D_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    launch_endpoints(*lidar, lv, P, d_est, est_stride, d_ranges, est_moving_dist, d_psi_cs, d_flags, false, s);
+    if ((rc = launch_scores(lv, P, d_est, est_stride, d_uniform, d_out, s))) return rc;
+    return launch_status();
+}
+
+int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2dMap* d_maps, int32_t P,
+                 const double* d_est, int32_t est_stride, const double* d_ranges, double est_moving_dist,
+                 const double* d_psi_cs, const double* d_uniform, Slam2dMatch* d_out, uint32_t* d_flags, void* stream) {
+    int rc = check_level(lidar, level, P);
+    if (rc) return rc;
+    if (!d_maps || !d_est || !d_ranges || !d_out || !d_flags || est_stride < 3) return SLAM2D_E_BADARG;
+    const Slam2dLevel& lv = *level;
+    if (lv.kmax < lidar->beams || !lv.partials || !lv.beam_xy) return SLAM2D_E_BADARG;
+    if ((rc = check_field_args(lv, P, true))) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    // the endpoints need only the frame, so they run first and tell the field build which tiles matter
+    if ((rc = launch_frames(*lidar, lv, d_maps, P, d_est, est_stride, d_flags, true, s))) return rc;
+    launch_endpoints(*lidar, lv, P, d_est, est_stride, d_ranges, est_moving_dist, d_psi_cs, d_flags, true, s);
+    launch_field(lv, d_maps, P, d_flags, true, s);
+    if ((rc = launch_scores(lv, P, d_est, est_stride, d_uniform, d_out, s))) return rc;
     return launch_status();
 }
 

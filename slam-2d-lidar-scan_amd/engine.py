@@ -382,6 +382,7 @@ class SearchLevel:
             tilemin=torch.zeros((P, self.tmax, self.tmax), dtype=f64, device=device),
             tilelist=torch.zeros((P, 2, self.tmax * self.tmax), dtype=i32, device=device),
             tilecount=torch.zeros((P, 2), dtype=i32, device=device),
+            tileneed=torch.zeros((P, (self.tmax * self.tmax + 31) // 32), dtype=i32, device=device),
             # optional table-driven axis-0 pass; measured slower than the arithmetic on MI355X
             # (178 vs 164 us at config 2: the kernel is latency-, not ALU-bound), so off by default
             vtable=(_dev(column_pass_table(self.log_miss, self.taps, self.blur_radius), device)
@@ -399,7 +400,8 @@ class SearchLevel:
             cube=t["cube"].data_ptr(), partials=t["partials"].data_ptr(), npartial=self.npartial, tmax=self.tmax,
             tilemask=t["occ"].data_ptr() + P * self.fmax * self.fpitch, tilestate=t["tilestate"].data_ptr(),
             tilemin=t["tilemin"].data_ptr(), tilelist=t["tilelist"].data_ptr(),
-            tilecount=t["tilecount"].data_ptr(), vtable=t["vtable"].data_ptr() if t["vtable"] is not None else None)
+            tilecount=t["tilecount"].data_ptr(), vtable=t["vtable"].data_ptr() if t["vtable"] is not None else None,
+            tileneed=t["tileneed"].data_ptr())
 
     # -- results --
     def frames(self):
@@ -496,6 +498,14 @@ class ParticleEngine:
         check(self.L.slam2d_sweep(C.byref(self.lidar_c), C.byref(level.c), self.P, _ptr(d_est), stride,
                                   _ptr(d_ranges), float(est_moving_dist), _ptr(d_psi_cs), _ptr(d_uniform),
                                   _ptr(d_out), _ptr(self.flags), _stream()), "slam2d_sweep")
+
+    def match(self, level, d_est, stride, d_ranges, est_moving_dist, d_psi_cs, d_uniform, d_out):
+        """field_build + sweep of one level in one call, blurring only the field tiles the sweep reads
+        (slam2d_match): same matches and cube, level.field() is left incomplete."""
+        self.refresh_bits()
+        check(self.L.slam2d_match(C.byref(self.lidar_c), C.byref(level.c), _ptr(self.d_maps), self.P, _ptr(d_est),
+                                  stride, _ptr(d_ranges), float(est_moving_dist), _ptr(d_psi_cs), _ptr(d_uniform),
+                                  _ptr(d_out), _ptr(self.flags), _stream()), "slam2d_match")
 
     def grid_update(self, d_pose, stride, d_ranges, d_beam_shift=None):
         self.refresh_bits()

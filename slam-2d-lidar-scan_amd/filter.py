@@ -140,6 +140,7 @@ class ParticleFilter:
         self.last_confidence = np.ones(P)
         self.last_variance = None
         self._normalizer = None
+        self.lazy_field = True
         self.step = 0
 
     # ---- odometry prior (Algorithm/FastSlam.py:77-106) ----
@@ -205,14 +206,12 @@ class ParticleFilter:
             _lib.check(L.slam2d_prior(_ptr(self.d_pose), float(reading['theta']), float(self.prev_raw['theta']),
                                       has_turn, float(turn), _ptr(self.d_head), P, _ptr(self.d_est),
                                       _ptr(self.d_psi), _stream()), "slam2d_prior")
-            eng.field_build(self.coarse, self.d_est, 3)
-            eng.sweep(self.coarse, self.d_est, 3, self.d_ranges, dist, self.d_psi, self.d_uniform, self.m_coarse)
+            self._match(self.coarse, self.d_est, 3, dist, self.d_psi, self.d_uniform, self.m_coarse)
             if self.growable and not self._fine_window_cannot_grow(est_xy, (self.coarse.ncell + 1) * self.coarse.step):
                 eng.take_flags()
                 c = eng.read_matches(self.m_coarse)
                 self._grow_for_windows(c["x"], c["y"], self.fine.reach)
-            eng.field_build(self.fine, self.m_coarse, MATCH_DOUBLES)
-            eng.sweep(self.fine, self.m_coarse, MATCH_DOUBLES, self.d_ranges, dist, None, None, self.m_fine)
+            self._match(self.fine, self.m_coarse, MATCH_DOUBLES, dist, None, None, self.m_fine)
             _lib.check(L.slam2d_post_match(_ptr(self.m_fine), _ptr(self.m_coarse), P, _ptr(self.d_pose),
                                            _ptr(self.d_head), _ptr(self.d_logw), _stream()), "slam2d_post_match")
             eng.grid_update(self.d_pose, 3, self.d_ranges)          # :133 (the update window lies inside the
@@ -277,6 +276,16 @@ class ParticleFilter:
             raise _lib.Slam2dError("the first scan's lidar window leaves the initial map: pre-size the map "
                                    "(the per-beam growth of Utils/OccupancyGrid.py:147 is only reproduced by "
                                    "the single-particle OccupancyGrid class)")
+
+    def _match(self, level, d_est, stride, dist, d_psi, d_uniform, d_out):
+        """One level of matchScan for all particles.  lazy_field: blur only the field tiles the sweep reads
+        (slam2d_match) -- same results, the full probSP image is not materialised."""
+        eng = self.engine
+        if self.lazy_field:
+            eng.match(level, d_est, stride, self.d_ranges, dist, d_psi, d_uniform, d_out)
+        else:
+            eng.field_build(level, d_est, stride)
+            eng.sweep(level, d_est, stride, self.d_ranges, dist, d_psi, d_uniform, d_out)
 
     # ---- weights (Algorithm/FastSlam.py:30-48) ----
     def normalizeWeights(self):
