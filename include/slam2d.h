@@ -49,7 +49,8 @@
 extern "C" {
 #endif
 
-#define SLAM2D_ABI_VERSION 1
+#define SLAM2D_ABI_VERSION 2
+#define SLAM2D_SPOKE_BAND 16         /* radial band width of the beam-major spoke table, in cells */
 
 /* library error codes (negative; positive values are hipError_t) */
 #define SLAM2D_E_BADARG   (-1)
@@ -97,6 +98,14 @@ typedef struct {
     const uint32_t* lut_cell;/* [W][W] (spoke bin << 16) | floor(r / unit): 4 bytes decide most cells */
     const double*   lut_r;   /* [W][W] exact radius, read only within ~2 cells of a beam's range thresholds */
     const double*   lut_xs;  /* [W]  linspace(-R, R, W) */
+    /* the same table beam-major (radByX/radByY/radByR themselves, :47-57).  The cells of a spoke are
+     * ordered by radial band -- SLAM2D_SPOKE_BAND consecutive values of floor(r / unit) -- and row-major
+     * inside a band; a beam touches the bands up to the one that holds range + wallThickness/2 */
+    const int32_t*  spoke_band;  /* [num_spokes][num_bands + 1] index of each band's first cell (absolute) */
+    const uint32_t* spoke_cells; /* [W*W] (window row << 16) | window column */
+    const double*   spoke_r;     /* [W*W] radius of that cell */
+    int32_t num_bands;           /* floor(max r / unit) / SLAM2D_SPOKE_BAND + 1 */
+    int32_t _pad;
 } Slam2dLidar;
 
 /* Geometry of one particle's search field at one level, written by

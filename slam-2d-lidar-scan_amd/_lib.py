@@ -36,6 +36,7 @@ FLAG_NAMES = {
 INIT_CELL = 0x00010002
 MAX_BLUR_RADIUS = 16
 MAX_BEAMS = 2048
+SPOKE_BAND = 16
 
 STAGE_SWEEP, STAGE_BLUR, STAGE_SCATTER, STAGE_UPDATE, STAGE_SELECT, STAGE_ENDPOINTS = range(6)
 STAGE_NAMES = {STAGE_SWEEP: "k_sweep", STAGE_BLUR: "k_blur_clamp", STAGE_SCATTER: "k_occ_scatter",
@@ -54,7 +55,8 @@ class Slam2dMap(C.Structure):
 class Slam2dLidar(C.Structure):
     _fields_ = [("unit", C.c_double), ("max_range", C.c_double), ("fov", C.c_double), ("wall_half", C.c_double),
                 ("beams", C.c_int32), ("num_spokes", C.c_int32), ("spoke_start", C.c_int32), ("lut_w", C.c_int32),
-                ("lut_cell", _vp), ("lut_r", _vp), ("lut_xs", _vp)]
+                ("lut_cell", _vp), ("lut_r", _vp), ("lut_xs", _vp),
+                ("spoke_band", _vp), ("spoke_cells", _vp), ("spoke_r", _vp), ("num_bands", C.c_int32), ("_pad", C.c_int32)]
 
 
 class Slam2dFrame(C.Structure):

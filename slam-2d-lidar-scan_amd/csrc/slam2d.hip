@@ -1048,6 +1048,138 @@ __global__ __launch_bounds__(256) void k_grid_update(Slam2dLidar lid, const Slam
     if (f) atomicOr(&flags[p], f);
 }
 
+// Beam-major update: the reference's own formulation (:134-152 walks the cells of each beam's spoke).
+// Every spoke's cell list is ordered by radial band (SLAM2D_SPOKE_BAND cells of integer radius
+// floor(r / unit) per band) and row-major inside a band, with the start of every band tabulated:
+// a beam touches the bands up to the one holding range + w/2 -- work ~ touched cells (8 % of the
+// W x W window on the Intel log) instead of the whole window -- and consecutive lanes fall on
+// consecutive cells of a map row (the band is a short piece of the beam's wedge).  One wave per
+// beam; a block takes UPDB_BEAMS adjacent beams of one particle (adjacent wedges share cache lines)
+// and all blocks of a particle run on one XCD (block b -> XCD b % 8) so those lines meet in one L2.
+// Each window cell belongs to exactly one spoke and each spoke to at most one beam: plain RMW.
+// (int)rint(v / unit) without the fp64 division (~70 issue slots on gfx950, and the update needs two per
+// cell): v * (1/unit) differs from v / unit by < 4e-16 relative, so the two round to the same integer
+// unless the quotient is within 1e-6 of a half-integer -- there the exact division decides.
+__device__ __forceinline__ int rint_div(const double v, const double unit, const double inv_unit) {
+    const double t = v * inv_unit;
+    double rt = rint(t);
+    if (fabs(fabs(t - rt) - 0.5) < 1e-6 || !(fabs(t) < 1e9)) rt = rint(v / unit);
+    return (int)rt;
+}
+
+#define UPDB_BEAMS 4                 // = waves per block
+#define UPDB_UNROLL 4
+__global__ __launch_bounds__(256) void k_grid_update_beams(Slam2dLidar lid, const Slam2dMap* __restrict__ maps, int P,
+                                                           const double* __restrict__ pose, int pstride,
+                                                           const double* __restrict__ ranges,
+                                                           const int32_t* __restrict__ beam_shift, uint32_t* flags,
+                                                           int groups) {
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int p = (q / groups) * 8 + xcd, g = q % groups;
+    if (p >= P) return;
+    const int W = lid.lut_w, S = lid.num_spokes, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const Slam2dMap m = maps[p];
+    const double px = pose[(size_t)p * pstride], py = pose[(size_t)p * pstride + 1], th = pose[(size_t)p * pstride + 2];
+    // spokesOffsetIdxByTheta = int(rint(theta / (2*pi) * numSpokes))  (:131)
+    const int offset = (int)rint(th / (2 * 3.141592653589793) * (double)S);
+    int first_spoke = (lid.spoke_start + offset) % S;            // spoke of beam 0 (:134), in [0, S)
+    if (first_spoke < 0) first_spoke += S;
+    const double inv_unit = 1.0 / lid.unit;
+    uint32_t f = 0;
+    // one wave per beam, UPDB_UNROLL chunks of 64 cells in flight: the walk is a chain of dependent loads
+    // (list -> cell -> store), so the loads of several chunks are issued before the first use.  The map
+    // index of a cell is computed per cell (rint_div: tabulating both axes per block costs more than that)
+    {
+        const int beam = g * UPDB_BEAMS + wave;
+        if (beam >= lid.beams) return;
+        const double rg = ranges[beam];
+        const double lo = rg - lid.wall_half, hi = rg + lid.wall_half;
+        const bool returned = rg < lid.max_range;
+        const int spoke = (first_spoke + beam) % S;
+        // floor(r / unit) is monotone in r: cells with r > lo sit in bands >= band(lo), cells with r < hi in
+        // bands <= band(hi); a beam without return marks no free cells (:138) and starts at its wall band
+        const int nb = lid.num_bands;
+        const int* __restrict__ bp = lid.spoke_band + (size_t)spoke * (nb + 1);
+        const int qlo = lo > 0.0 ? (int)fmin(floor(lo / lid.unit), 2.0e9) : 0;
+        const int qhi = hi > 0.0 ? (int)fmin(floor(hi / lid.unit), 2.0e9) : -1;
+        if (qhi < 0) return;
+        const int b0 = returned ? 0 : min(qlo / SLAM2D_SPOKE_BAND, nb), b1 = min(qhi / SLAM2D_SPOKE_BAND + 1, nb);
+        const int kbeg = bp[b0], kend = bp[max(b0, b1)];
+        const double* __restrict__ sr = lid.spoke_r;
+        const uint32_t* __restrict__ sc = lid.spoke_cells;
+        int sx = 0, sy = 0;
+        if (beam_shift) {   // stale indices after a low-side growth inside this beam (:144-147)
+            sx = beam_shift[((size_t)p * lid.beams + beam) * 2 + 0];
+            sy = beam_shift[((size_t)p * lid.beams + beam) * 2 + 1];
+        }
+        const uint32_t ncells = (uint32_t)m.rows * (uint32_t)m.pitch;
+        for (int k0 = kbeg + lane; k0 < kend; k0 += 64 * UPDB_UNROLL) {
+            // straight-line phases, every load of a phase issued before its first use (no branches in between)
+            double r[UPDB_UNROLL], xj[UPDB_UNROLL], yi[UPDB_UNROLL];
+            uint32_t cell[UPDB_UNROLL], inc[UPDB_UNROLL], c[UPDB_UNROLL], at[UPDB_UNROLL];
+            int mxs[UPDB_UNROLL], mys[UPDB_UNROLL];
+#pragma unroll
+            for (int u = 0; u < UPDB_UNROLL; ++u) {
+                const int k = min(k0 + u * 64, kend - 1);
+                r[u] = sr[k];
+                cell[u] = sc[k];
+            }
+#pragma unroll
+            for (int u = 0; u < UPDB_UNROLL; ++u) {
+                xj[u] = lid.lut_xs[cell[u] & 0xffffu];
+                yi[u] = lid.lut_xs[cell[u] >> 16];
+            }
+            bool slow = false;
+#pragma unroll
+            for (int u = 0; u < UPDB_UNROLL; ++u) {
+                // convertRealXYToMapIdx(x + xAtSpokeDir, ...)  (:104-105,144-145) as rint_div, fast path only
+                const double tx = ((px + xj[u]) - m.lim_x0) * inv_unit, ty = ((py + yi[u]) - m.lim_y0) * inv_unit;
+                const double rx = rint(tx), ry = rint(ty);
+                slow |= fabs(fabs(tx - rx) - 0.5) < 1e-6 || fabs(fabs(ty - ry) - 0.5) < 1e-6 || !(fabs(tx) < 1e9) || !(fabs(ty) < 1e9);
+                mxs[u] = (int)rx; mys[u] = (int)ry;
+            }
+            if (__any(slow)) {                                     // a quotient next to a rounding boundary: exact division
+#pragma unroll
+                for (int u = 0; u < UPDB_UNROLL; ++u) {
+                    mxs[u] = (int)rint(((px + xj[u]) - m.lim_x0) / lid.unit);
+                    mys[u] = (int)rint(((py + yi[u]) - m.lim_y0) / lid.unit);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UPDB_UNROLL; ++u) {
+                inc[u] = 0u;
+                if (k0 + u * 64 < kend) {
+                    if (returned && r[u] < lo) inc[u] = 1u;                      // :138-139,149
+                    else if (r[u] > lo && r[u] < hi) inc[u] = 0x00020002u;       // :142-143,151-152
+                }
+                int mx = mxs[u] - sx, my = mys[u] - sy;
+                if (beam_shift) {
+                    if (mx < 0) mx += m.cols;
+                    if (my < 0) my += m.rows;
+                }
+                if (inc[u] && (mx < 0 || mx >= m.cols || my < 0 || my >= m.rows)) { f |= SLAM2D_F_UPDATE_OUTSIDE_MAP; inc[u] = 0u; }
+                mxs[u] = mx; mys[u] = my;
+                at[u] = inc[u] ? (uint32_t)my * (uint32_t)m.pitch + (uint32_t)mx : 0u;     // cell 0: a harmless read
+            }
+#pragma unroll
+            for (int u = 0; u < UPDB_UNROLL; ++u) c[u] = m.cells[min(at[u], ncells - 1u)];
+#pragma unroll
+            for (int u = 0; u < UPDB_UNROLL; ++u) {
+                if (!inc[u]) continue;
+                if ((c[u] & 0xffffu) + (inc[u] & 0xffffu) > 0xffffu) { f |= SLAM2D_F_COUNT_OVERFLOW; continue; }
+                const uint32_t nc = c[u] + inc[u];
+                m.cells[at[u]] = nc;
+                const bool was = 2u * (c[u] >> 16) > (c[u] & 0xffffu), is = 2u * (nc >> 16) > (nc & 0xffffu);
+                if (was != is) {                                       // keep the occupancy bit in step
+                    uint32_t* word = m.occ_bits + (size_t)mys[u] * m.bits_pitch + (mxs[u] >> 5);
+                    if (is) atomicOr(word, 1u << (mxs[u] & 31)); else atomicAnd(word, ~(1u << (mxs[u] & 31)));
+                }
+            }
+        }
+    }
+    if (f) atomicOr(&flags[p], f);
+}
+
 // ------------------------------------------------------------------------------------
 // K4  weights                                        (Algorithm/FastSlam.py:30-48,135)
 // ------------------------------------------------------------------------------------
@@ -1369,6 +1501,15 @@ int slam2d_grid_update(const Slam2dLidar* lidar, const Slam2dMap* d_maps, int32_
     if (lidar->beams < 1 || lidar->beams > SLAM2D_MAX_BEAMS) return SLAM2D_E_TOOLARGE;
     hipStream_t s = (hipStream_t)stream;
     const int W = lidar->lut_w;
+    static const bool dense = [] { const char* e = getenv("SLAM2D_UPDATE_DENSE"); return e && atoi(e) == 1; }();
+    if (!dense) {
+        if (!lidar->spoke_band || !lidar->spoke_cells || !lidar->spoke_r || lidar->num_bands < 1 || W > 65535) return SLAM2D_E_BADARG;
+        const int groups = cdiv(lidar->beams, UPDB_BEAMS);
+        StageScope prof(SLAM2D_STAGE_UPDATE, s);
+        k_grid_update_beams<<<8 * cdiv(P, 8) * groups, 64 * UPDB_BEAMS, 0, s>>>(
+            *lidar, d_maps, P, d_pose, pose_stride, d_ranges, d_beam_shift, d_flags, groups);
+        return launch_status();
+    }
     k_update_axis<<<dim3(cdiv(max(W, lidar->beams), 256), P, 2), 256, 0, s>>>(*lidar, d_maps, d_pose, pose_stride, d_ranges, P, d_axis_scratch);
     const int tiles_x = cdiv(W, 64), tiles_y = cdiv(W, UPD_ROWS);
     {

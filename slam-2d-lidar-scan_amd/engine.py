@@ -156,6 +156,25 @@ class LidarModel:
         r = np.sqrt(x ** 2 + y ** 2)
         return bins.astype(np.uint16), np.ascontiguousarray(r)
 
+    def spoke_lists(self):
+        """itemizeSpokesGrid (:47-57) beam-major for the update kernel: the cells of a spoke ordered by
+        radial band (SPOKE_BAND values of floor(r / unit)) and row-major inside a band.  Returns
+        (band_ptr int32 [S, nb + 1] absolute start of every band, cells uint32 [W*W] = row << 16 | column,
+        radius float64 [W*W], nb)."""
+        W, S = self.width, self.num_spokes
+        assert W <= 65535
+        flat_bin, flat_r = self.bin.ravel().astype(np.int64), self.r.ravel()
+        band = np.floor(flat_r / self.unit).astype(np.int64) // _lib.SPOKE_BAND
+        nb = int(band.max()) + 1
+        order = np.lexsort((np.arange(W * W), band, flat_bin))
+        counts = np.bincount(flat_bin * nb + band, minlength=S * nb).reshape(S, nb)
+        starts = np.concatenate(([0], np.cumsum(counts.ravel())))
+        band_ptr = np.empty((S, nb + 1), dtype=np.int32)
+        band_ptr[:, :nb] = starts[:-1].reshape(S, nb)
+        band_ptr[:, nb] = starts[nb::nb]
+        cells = ((order // W).astype(np.uint32) << np.uint32(16)) | (order % W).astype(np.uint32)
+        return band_ptr, cells, np.ascontiguousarray(flat_r[order]), nb
+
     def on(self, device):
         """Device copies + the C struct (kept alive with the tensors)."""
         key = str(device)
@@ -165,11 +184,15 @@ class LidarModel:
             rq = np.floor(self.r / self.unit)
             assert rq.max() < 65536
             cell = (self.bin.astype(np.uint32) << np.uint32(16)) | rq.astype(np.uint32)
-            t = dict(cell=_dev(cell.view(np.int32), device), r=_dev(self.r, device), xs=_dev(self.xs, device))
+            ptr, cells, radii, nb = self.spoke_lists()
+            t = dict(cell=_dev(cell.view(np.int32), device), r=_dev(self.r, device), xs=_dev(self.xs, device),
+                     sptr=_dev(ptr, device), scells=_dev(cells.view(np.int32), device), sr=_dev(radii, device))
             s = Slam2dLidar(unit=self.unit, max_range=self.max_range, fov=self.fov,
                             wall_half=self.wall_thickness / 2, beams=self.beams, num_spokes=self.num_spokes,
                             spoke_start=self.spoke_start, lut_w=self.width,
-                            lut_cell=t["cell"].data_ptr(), lut_r=t["r"].data_ptr(), lut_xs=t["xs"].data_ptr())
+                            lut_cell=t["cell"].data_ptr(), lut_r=t["r"].data_ptr(), lut_xs=t["xs"].data_ptr(),
+                            spoke_band=t["sptr"].data_ptr(), spoke_cells=t["scells"].data_ptr(),
+                            spoke_r=t["sr"].data_ptr(), num_bands=nb)
             self._dev[key] = (s, t)
         return self._dev[key][0]
 
