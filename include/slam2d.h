@@ -118,7 +118,8 @@ typedef struct {
     int32_t fh, fw;          /* field rows / cols actually used (<= fmax) */
     int32_t mx0, mx1;        /* map column window [mx0, mx1) */
     int32_t my0, my1;        /* map row window    [my0, my1) */
-    int32_t redo, _pad;
+    int32_t redo;            /* 1 = the clamp was redone with the measured minimum */
+    int32_t min_known;       /* 1 = some tile of the frame is free, so field_min is the analytic floor */
     unsigned long long min_bits; /* reserved */
 } Slam2dFrame;
 
@@ -164,7 +165,6 @@ typedef struct {
     uint32_t* field;         /* [P][fmax][fpitch]  fixed-point cost of probSP (see above) */
     int32_t* cells;          /* [P][ntheta][kmax] unique endpoint cells (patch-corner offsets) */
     int32_t* kcount;         /* [P][ntheta] */
-    double*  beam_xy;        /* [P][kmax][2] beam endpoints of the estimate pose (x = NaN: out of range) */
     double*  prior;          /* [P][2][ny][nx]  rv plane, thetaWeight plane */
     double*  cube;           /* [P][ntheta][ny][nx] convTotal */
     Slam2dPartial* partials; /* [P][npartial] per-wave reductions of the cube (sweep -> select) */
@@ -184,6 +184,11 @@ typedef struct {
                                 operation order; used when blur_radius is 2 or 8 */
     uint32_t* tileneed;      /* [P][ceil(tmax*tmax/32)] scratch of slam2d_match: bit t set = the sweep reads
                                 field tile t (may be NULL when only slam2d_field_build is used) */
+    int32_t occ_gen;         /* 0: occ + tilemask are cleared at every build.  1..255: generation stamp -- an
+                                occ / tilemask byte means "occupied" only when it equals occ_gen, so nothing is
+                                cleared; the caller passes a value unused since the buffers were last zeroed
+                                (count 1, 2, ... 255, zero the buffers, start again at 1) */
+    int32_t _pad;
 } Slam2dLevel;
 
 /* Result of one level for one particle. */

@@ -63,7 +63,7 @@ class Slam2dFrame(C.Structure):
     _fields_ = [("xlo", C.c_double), ("ylo", C.c_double), ("xhi", C.c_double), ("yhi", C.c_double),
                 ("cx", C.c_double), ("cy", C.c_double), ("field_min", C.c_double),
                 ("fh", C.c_int32), ("fw", C.c_int32), ("mx0", C.c_int32), ("mx1", C.c_int32),
-                ("my0", C.c_int32), ("my1", C.c_int32), ("redo", C.c_int32), ("_pad", C.c_int32),
+                ("my0", C.c_int32), ("my1", C.c_int32), ("redo", C.c_int32), ("min_known", C.c_int32),
                 ("min_bits", C.c_uint64)]
 
 
@@ -80,10 +80,11 @@ class Slam2dLevel(C.Structure):
                 ("thetas", _vp), ("theta_cos", _vp), ("theta_sin", _vp),
                 ("rv_coef", C.c_double), ("tw_coef", C.c_double), ("max_move_dev", C.c_double),
                 ("frames", _vp), ("axis_x", _vp), ("axis_y", _vp), ("occ", _vp), ("field", _vp),
-                ("cells", _vp), ("kcount", _vp), ("beam_xy", _vp), ("prior", _vp), ("cube", _vp),
+                ("cells", _vp), ("kcount", _vp), ("prior", _vp), ("cube", _vp),
                 ("partials", _vp), ("npartial", C.c_int32), ("tmax", C.c_int32), ("tilemask", _vp),
                 ("tilestate", _vp), ("tilemin", _vp),
-                ("tilelist", _vp), ("tilecount", _vp), ("vtable", _vp), ("tileneed", _vp)]
+                ("tilelist", _vp), ("tilecount", _vp), ("vtable", _vp), ("tileneed", _vp),
+                ("occ_gen", C.c_int32), ("_pad", C.c_int32)]
 
 
 class Slam2dMatch(C.Structure):

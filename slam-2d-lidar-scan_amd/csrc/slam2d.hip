@@ -68,6 +68,15 @@ __device__ __forceinline__ double unorder_bits(unsigned long long k) {
     unsigned long long b = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
     return __longlong_as_double((long long)b);
 }
+// The occupied-field image and the tile flags are not cleared between builds: a cell / tile is
+// occupied when its byte equals the build's generation stamp (Slam2dLevel.occ_gen, 1..255).
+__device__ __forceinline__ uint8_t occ_stamp(const Slam2dLevel& lv) { return (uint8_t)(lv.occ_gen ? lv.occ_gen : 1); }
+// 0x01 in every byte of v that equals the stamp byte (exact per byte), 0x00 elsewhere
+__device__ __forceinline__ uint32_t bytes_equal(const uint32_t v, const uint8_t stamp) {
+    const uint32_t t = v ^ (0x01010101u * stamp);
+    return (~(((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t | 0x7f7f7f7fu)) >> 7;
+}
+
 __device__ __forceinline__ int reflect_index(int i, int n) {
     // SciPy 'reflect' extension: d c b a | a b c d | d c b a
     int period = 2 * n;
@@ -103,7 +112,7 @@ __device__ __forceinline__ Slam2dFrame make_frame(const Slam2dLidar& lid, const 
     if (mx1 - mx0 > lv.wmax) { mx1 = mx0 + lv.wmax; f |= SLAM2D_F_WINDOW_OUTSIDE_MAP; }
     if (my1 - my0 > lv.wmax) { my1 = my0 + lv.wmax; f |= SLAM2D_F_WINDOW_OUTSIDE_MAP; }
     fr.fh = fh; fr.fw = fw; fr.mx0 = mx0; fr.mx1 = mx1; fr.my0 = my0; fr.my1 = my1;
-    fr.field_min = lv.floor_value; fr.redo = 0; fr._pad = 0;
+    fr.field_min = lv.floor_value; fr.redo = 0; fr.min_known = 0;
     fr.min_bits = ~0ull;
     return fr;
 }
@@ -173,6 +182,7 @@ __global__ __launch_bounds__(256) void k_occ_scatter(Slam2dLevel lv, const Slam2
     if (col_base + 32 > fr.mx1) edge &= ~0u >> (col_base + 32 - fr.mx1);
     uint8_t* occ = lv.occ + (size_t)p * lv.fmax * lv.fpitch;
     uint8_t* tiles = lv.tilemask + (size_t)p * lv.tmax * lv.tmax;
+    const uint8_t stamp = occ_stamp(lv);
     const int32_t* __restrict__ ax = lv.axis_x + (size_t)p * lv.wmax;
     const int half = lane >> 5, bit = lane & 31;
 #pragma unroll
@@ -193,8 +203,8 @@ __global__ __launch_bounds__(256) void k_occ_scatter(Slam2dLevel lv, const Slam2
                 const int col = ((w0 + src) << 5) + bit;
                 const int fx = ax[col - fr.mx0];
                 if (fx >= 0 && fy >= 0) {                                          // :36-37
-                    occ[(size_t)fy * lv.fpitch + fx] = 1;
-                    tiles[(fy >> BLUR_SHIFT) * lv.tmax + (fx >> BLUR_SHIFT)] = 1;
+                    occ[(size_t)fy * lv.fpitch + fx] = stamp;
+                    tiles[(fy >> BLUR_SHIFT) * lv.tmax + (fx >> BLUR_SHIFT)] = stamp;
                 }
             }
         }
@@ -262,6 +272,7 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
     const int ext = BLUR_TILE + 2 * r;
     const int tid = threadIdx.x;
     const uint8_t* occ = lv.occ + (size_t)p * lv.fmax * lv.fpitch;
+    const uint8_t stamp = occ_stamp(lv);
     uint8_t* state = lv.tilestate + ((size_t)p * lv.tmax + tby) * lv.tmax + tbx;
     // activity: an occupied cell within the halo (r <= 16 = tile edge) lies in one of the 3x3 tiles around
     int any = 1;
@@ -271,7 +282,7 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
         const int nty = (fh + BLUR_TILE - 1) >> BLUR_SHIFT, ntx = (fw + BLUR_TILE - 1) >> BLUR_SHIFT;
         if (tid < 9) {
             const int yy = tby + tid / 3 - 1, xx = tbx + tid % 3 - 1;
-            if (yy >= 0 && yy < nty && xx >= 0 && xx < ntx) any = tiles[yy * lv.tmax + xx];
+            if (yy >= 0 && yy < nty && xx >= 0 && xx < ntx) any = tiles[yy * lv.tmax + xx] == stamp;
         }
         any = __syncthreads_or(any);
     }
@@ -279,19 +290,63 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
         // word loads when the halo is interior and 4-byte aligned (r % 4 == 0), bytes + reflect otherwise
         const bool interior = ty0 - r >= 0 && ty0 + BLUR_TILE + r <= fh && tx0 - r >= 0 && tx0 + BLUR_TILE + r <= fw;
         int exact = 0;                 // the tile flags are conservative: re-test on the halo itself
+        // every load of the halo is issued before the first use: the image is not cache-resident (one
+        // HBM latency instead of one per 64-lane slice)
         if ((r & 3) == 0 && interior) {
             const int wpr = ext >> 2;
-            for (int idx = tid; idx < ext * wpr; idx += BLUR_THREADS) {
-                const int ly = idx / wpr, lw = idx - ly * wpr;
-                const uint32_t v = *reinterpret_cast<const uint32_t*>(occ + (size_t)(ty0 - r + ly) * lv.fpitch + (tx0 - r) + 4 * lw);
-                *reinterpret_cast<uint32_t*>(&sm.occ[ly][4 * lw]) = v;
-                exact |= (v != 0u);
+            constexpr int NW = RAD > 0 ? ((BLUR_TILE + 2 * RAD) * ((BLUR_TILE + 2 * RAD) / 4) + BLUR_THREADS - 1) / BLUR_THREADS : 1;
+            if constexpr (RAD > 0) {
+                uint32_t v[NW];
+#pragma unroll
+                for (int i = 0; i < NW; ++i) {
+                    const int idx = min(tid + i * BLUR_THREADS, ext * wpr - 1);
+                    const int ly = idx / wpr, lw = idx - ly * wpr;
+                    v[i] = *reinterpret_cast<const uint32_t*>(occ + (size_t)(ty0 - r + ly) * lv.fpitch + (tx0 - r) + 4 * lw);
+                }
+#pragma unroll
+                for (int i = 0; i < NW; ++i) {
+                    const int idx = tid + i * BLUR_THREADS;
+                    if (idx < ext * wpr) {
+                        const int ly = idx / wpr, lw = idx - ly * wpr;
+                        const uint32_t e = bytes_equal(v[i], stamp);
+                        *reinterpret_cast<uint32_t*>(&sm.occ[ly][4 * lw]) = e;
+                        exact |= (e != 0u);
+                    }
+                }
+            } else {
+                for (int idx = tid; idx < ext * wpr; idx += BLUR_THREADS) {
+                    const int ly = idx / wpr, lw = idx - ly * wpr;
+                    const uint32_t v = bytes_equal(*reinterpret_cast<const uint32_t*>(occ + (size_t)(ty0 - r + ly) * lv.fpitch + (tx0 - r) + 4 * lw), stamp);
+                    *reinterpret_cast<uint32_t*>(&sm.occ[ly][4 * lw]) = v;
+                    exact |= (v != 0u);
+                }
+            }
+        } else if constexpr (RAD > 0) {
+            constexpr int EXT_C = BLUR_TILE + 2 * RAD;
+            constexpr int NB = (EXT_C * EXT_C + BLUR_THREADS - 1) / BLUR_THREADS;
+            uint8_t v[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int idx = min(tid + i * BLUR_THREADS, EXT_C * EXT_C - 1);
+                const int ly = idx / EXT_C, lx = idx - ly * EXT_C;
+                const int gy = reflect_index(ty0 - r + ly, fh), gx = reflect_index(tx0 - r + lx, fw);
+                v[i] = occ[(size_t)gy * lv.fpitch + gx];
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int idx = tid + i * BLUR_THREADS;
+                if (idx < EXT_C * EXT_C) {
+                    const int ly = idx / EXT_C, lx = idx - ly * EXT_C;
+                    const uint8_t o = v[i] == stamp;
+                    sm.occ[ly][lx] = o;
+                    exact |= o;
+                }
             }
         } else {
             for (int idx = tid; idx < ext * ext; idx += BLUR_THREADS) {
                 const int ly = idx / ext, lx = idx - ly * ext;
                 const int gy = reflect_index(ty0 - r + ly, fh), gx = reflect_index(tx0 - r + lx, fw);
-                const uint8_t o = occ[(size_t)gy * lv.fpitch + gx];
+                const uint8_t o = occ[(size_t)gy * lv.fpitch + gx] == stamp;
                 sm.occ[ly][lx] = o;
                 exact |= o;
             }
@@ -395,15 +450,29 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
 // below it).  A frame without any free tile falls back to the full build.
 #define TRIAGE_THREADS 1024
 __global__ __launch_bounds__(TRIAGE_THREADS) void k_tile_triage(Slam2dLevel lv, int lazy) {
+    // tile flags, tile states and the needed-tile bitmap of the particle are staged in LDS with one batch
+    // of coalesced loads; everything after that runs out of LDS (the kernel is pure latency otherwise)
+    extern __shared__ __attribute__((aligned(16))) uint8_t tri_lds[];     // [ntile4] flags, [ntile4] states, [nneed] words
     __shared__ int wave_cnt[2][2][16];
     __shared__ int base[2];
     const int p = blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const Slam2dFrame fr = lv.frames[p];
     const int nty = (fr.fh + BLUR_TILE - 1) >> BLUR_SHIFT, ntx = (fr.fw + BLUR_TILE - 1) >> BLUR_SHIFT;
-    const int ntile = lv.tmax * lv.tmax;
+    const int ntile = lv.tmax * lv.tmax, ntile4 = (ntile + 3) & ~3, nneed = (ntile + 31) >> 5;
     const int iters = (ntile + TRIAGE_THREADS - 1) / TRIAGE_THREADS;          // <= 32 (checked by the host)
-    const uint8_t* tiles = lv.tilemask + (size_t)p * ntile;
+    uint8_t* tiles_s = tri_lds;
+    uint8_t* state_s = tri_lds + ntile4;
+    uint32_t* need_s = reinterpret_cast<uint32_t*>(tri_lds + 2 * ntile4);
+    const uint8_t stamp = occ_stamp(lv);
+    uint8_t* state = lv.tilestate + (size_t)p * ntile;
+    {
+        const uint8_t* tiles = lv.tilemask + (size_t)p * ntile;
+        for (int t = tid; t < ntile; t += TRIAGE_THREADS) { tiles_s[t] = tiles[t] == stamp; state_s[t] = state[t]; }
+        if (lazy) for (int w = tid; w < nneed; w += TRIAGE_THREADS) need_s[w] = lv.tileneed[(size_t)p * nneed + w];
+    }
+    if (tid < 2) base[tid] = 0;
+    __syncthreads();
     uint32_t liveb = 0u, anyb = 0u;
     int has_free = 0;
     for (int it = 0; it < iters; ++it) {
@@ -416,28 +485,26 @@ __global__ __launch_bounds__(TRIAGE_THREADS) void k_tile_triage(Slam2dLevel lv, 
 #pragma unroll
                 for (int dx = -1; dx <= 1; ++dx) {
                     const int yy = ty + dy, xx = tx + dx;
-                    if (yy >= 0 && yy < nty && xx >= 0 && xx < ntx) any |= tiles[yy * lv.tmax + xx];
+                    if (yy >= 0 && yy < nty && xx >= 0 && xx < ntx) any |= tiles_s[yy * lv.tmax + xx];
                 }
             liveb |= 1u << it;
             if (any) anyb |= 1u << it; else has_free = 1;
         }
     }
-    if (tid < 2) base[tid] = 0;
     has_free = __syncthreads_or(has_free);
+    // one free tile pins the field minimum (:43) to the analytic floor: k_blur_check_redo has nothing to do
+    if (tid == 0) lv.frames[p].min_known = has_free;
     const bool everything = !lazy || !has_free;
-    const int nneed = (ntile + 31) >> 5;
-    const uint32_t* __restrict__ need = lv.tileneed + (size_t)p * nneed;
-    uint8_t* state = lv.tilestate + (size_t)p * ntile;
     int* list = lv.tilelist + (size_t)p * 2 * ntile;
     const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
     for (int it = 0; it < iters; ++it) {
         const int t = it * TRIAGE_THREADS + tid;
         const bool live = (liveb >> it) & 1u, any = (anyb >> it) & 1u;
-        const bool wanted = live && (everything || ((need[t >> 5] >> (t & 31)) & 1u));
+        const bool wanted = live && (everything || ((need_s[t >> 5] >> (t & 31)) & 1u));
         bool to_fill = false;
         if (live && !any) {
             lv.tilemin[(size_t)p * ntile + t] = lv.floor_value;
-            if (wanted && state[t] != 0) { to_fill = true; state[t] = 0; }
+            if (wanted && state_s[t] != 0) { to_fill = true; state[t] = 0; }
         }
         const bool mine[2] = {wanted && any, to_fill};
         int rank[2];
@@ -448,10 +515,18 @@ __global__ __launch_bounds__(TRIAGE_THREADS) void k_tile_triage(Slam2dLevel lv, 
             if (lane == 0) wave_cnt[it & 1][which][wave] = __popcll(mask);
         }
         __syncthreads();
-        if (tid < 2) {
-            int tot = base[tid];
-            for (int w2 = 0; w2 < 16; ++w2) { const int c = wave_cnt[it & 1][tid][w2]; wave_cnt[it & 1][tid][w2] = tot; tot += c; }
-            base[tid] = tot;
+        if (tid < 32) {                                    // lanes 0-15: blur list, 16-31: fill list; 16-lane scans
+            const int which = tid >> 4, w2 = tid & 15;
+            const int c = wave_cnt[it & 1][which][w2];
+            int incl = c;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                const int up = __shfl_up(incl, o, 16);
+                if (w2 >= o) incl += up;
+            }
+            const int start = base[which];
+            wave_cnt[it & 1][which][w2] = start + incl - c;
+            if (w2 == 15) base[which] = start + incl;
         }
         __syncthreads();
 #pragma unroll
@@ -498,6 +573,7 @@ __global__ __launch_bounds__(256) void k_blur_check_redo(Slam2dLevel lv, uint32_
     __shared__ double red_s[4];
     const int p = blockIdx.x, tid = threadIdx.x;
     Slam2dFrame fr = lv.frames[p];
+    if (fr.min_known) return;                          // a free tile exists: the minimum is the analytic floor
     const int nty = (fr.fh + BLUR_TILE - 1) >> BLUR_SHIFT, ntx = (fr.fw + BLUR_TILE - 1) >> BLUR_SHIFT;
     const double* __restrict__ tm = lv.tilemin + (size_t)p * lv.tmax * lv.tmax;
     double m = INFINITY;
@@ -550,29 +626,6 @@ __device__ __forceinline__ void write_priors(const Slam2dLevel& lv, const int p,
 }
 
 // ------------------------------------------------------------------------------------
-// K1a0  beam endpoints of the estimate pose, once per particle   (Utils/ScanMatcher_OGBased.py:81-89)
-//       (the theta loop only rotates them; px = NaN marks a beam that is out of range, :84)
-// ------------------------------------------------------------------------------------
-__global__ void k_beam_points(Slam2dLidar lid, Slam2dLevel lv, const double* __restrict__ est, int estride,
-                              const double* __restrict__ ranges) {
-    const int p = blockIdx.y, b = blockIdx.x * blockDim.x + threadIdx.x;
-    const int B = lid.beams;
-    if (b >= B) return;
-    const double ex = est[(size_t)p * estride], ey = est[(size_t)p * estride + 1], eth = est[(size_t)p * estride + 2];
-    // np.linspace(theta - fov/2, theta + fov/2, num=B)  (:82-83)
-    const double a0 = eth - lid.fov / 2, a1 = eth + lid.fov / 2;
-    const double astep = (a1 - a0) / (double)(B - 1);
-    const double rg = ranges[b];
-    double px = NAN, py = NAN;
-    if (rg < lid.max_range) {                                                       // :84
-        const double a = (b == B - 1) ? a1 : (double)b * astep + a0;
-        px = ex + cos(a) * rg; py = ey + sin(a) * rg;                               // :87-88
-    }
-    lv.beam_xy[((size_t)p * lv.kmax + b) * 2] = px;
-    lv.beam_xy[((size_t)p * lv.kmax + b) * 2 + 1] = py;
-}
-
-// ------------------------------------------------------------------------------------
 // K1a  beam endpoints -> unique field cells per theta   (Utils/ScanMatcher_OGBased.py:81-89,
 //      117-121,162-176).  One block per (theta, particle); bitonic sort + compaction in LDS.
 //      A cell is stored as the offset of the corner of its (2*ncell+1)^2 patch:
@@ -605,7 +658,10 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
     const double c = lv.theta_cos[it], s = lv.theta_sin[it];
     const int nc = lv.ncell;
     const int per = n / 256;                               // beams per thread, contiguous: [tid*per, tid*per + per)
-    const double* __restrict__ bxy = lv.beam_xy + (size_t)p * lv.kmax * 2;
+    // np.linspace(theta - fov/2, theta + fov/2, num=B)  (:82-83)
+    const double eth = est[(size_t)p * estride + 2];
+    const double a0 = eth - lid.fov / 2, a1 = eth + lid.fov / 2;
+    const double astep = (a1 - a0) / (double)(B - 1);
     int key[SLAM2D_MAX_BEAMS / 256], slot[SLAM2D_MAX_BEAMS / 256];
     bool bad = false;
 #pragma unroll
@@ -613,8 +669,10 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
         key[q] = INT_MAX; slot[q] = 0;
         const int b = tid * per + q;
         if (q < per && b < B) {
-            const double px = bxy[2 * b], py = bxy[2 * b + 1];
-            if (!isnan(px)) {
+            const double rg = ranges[b];
+            if (rg < lid.max_range) {                                               // :84
+                const double a = (b == B - 1) ? a1 : (double)b * astep + a0;
+                const double px = ex + cos(a) * rg, py = ey + sin(a) * rg;          // :87-88
                 const double dx = px - ex, dy = py - ey;
                 const double qx = ex + c * dx - s * dy;                             // :169
                 const double qy = ey + s * dx + c * dy;                             // :170
@@ -1372,7 +1430,7 @@ static int check_field_args(const Slam2dLevel& lv, int P, bool lazy) {
     if (lv.tilemask != lv.occ + (size_t)P * lv.fmax * lv.fpitch || !lv.tilestate || !lv.tilemin || !lv.tilelist || !lv.tilecount)
         return SLAM2D_E_BADARG;
     if (lazy && !lv.tileneed) return SLAM2D_E_BADARG;
-    if (cdiv(lv.tmax * lv.tmax, TRIAGE_THREADS) > 32) return SLAM2D_E_TOOLARGE;
+    if (lv.tmax * lv.tmax > 28000) return SLAM2D_E_TOOLARGE;        // k_tile_triage: 32 passes, 64 KB of LDS
     return 0;
 }
 
@@ -1380,6 +1438,8 @@ static int check_field_args(const Slam2dLevel& lv, int P, bool lazy) {
 static int launch_frames(const Slam2dLidar& lid, const Slam2dLevel& lv, const Slam2dMap* d_maps, int P,
                          const double* d_centre, int centre_stride, uint32_t* d_flags, bool lazy, hipStream_t s) {
     k_frame_axis<<<dim3(cdiv(lv.wmax, 256), P, 2), 256, 0, s>>>(lid, lv, d_maps, d_centre, centre_stride, d_flags, lazy ? 1 : 0);
+    if (lv.occ_gen < 0 || lv.occ_gen > 255) return SLAM2D_E_BADARG;
+    if (lv.occ_gen != 0) return 0;                     // generation stamps: nothing to clear
     return (int)hipMemsetAsync(lv.occ, 0, (size_t)P * lv.fmax * lv.fpitch + (size_t)P * lv.tmax * lv.tmax, s);
 }
 
@@ -1390,10 +1450,11 @@ static void launch_field(const Slam2dLevel& lv, const Slam2dMap* d_maps, int P, 
         k_occ_scatter<<<dim3(cdiv(cdiv(lv.wmax, 32) + 1, 64), cdiv(lv.wmax, SCATTER_ROWS), P), dim3(64, 4), 0, s>>>(lv, d_maps);
     }
     const int ntile = lv.tmax * lv.tmax;
-    k_tile_triage<<<P, TRIAGE_THREADS, 0, s>>>(lv, lazy ? 1 : 0);
+    k_tile_triage<<<P, TRIAGE_THREADS, (size_t)2 * ((ntile + 3) & ~3) + 4 * ((ntile + 31) / 32), s>>>(lv, lazy ? 1 : 0);
     {
         StageScope prof(SLAM2D_STAGE_BLUR, s);
-        const dim3 bgrid(min(ntile, SLAM2D_BLUR_BLOCKS_PER_PARTICLE), P);
+        static const int blur_blocks = [] { const char* e = getenv("SLAM2D_BLUR_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : SLAM2D_BLUR_BLOCKS_PER_PARTICLE; }();
+        const dim3 bgrid(min(ntile, blur_blocks), P);
         switch (lv.blur_radius) {
             case 2: k_blur_clamp<2><<<bgrid, BLUR_THREADS, 0, s>>>(lv); break;
             case 8: k_blur_clamp<8><<<bgrid, BLUR_THREADS, 0, s>>>(lv); break;
@@ -1412,7 +1473,6 @@ static void launch_endpoints(const Slam2dLidar& lid, const Slam2dLevel& lv, int 
                              const double* d_ranges, double est_moving_dist, const double* d_psi_cs, uint32_t* d_flags,
                              bool mark, hipStream_t s) {
     StageScope prof(SLAM2D_STAGE_ENDPOINTS, s);
-    k_beam_points<<<dim3(cdiv(lid.beams, 256), P), 256, 0, s>>>(lid, lv, d_est, est_stride, d_ranges);
     int n = 256;
     while (n < lid.beams) n <<= 1;
     const size_t ep_lds = (size_t)(4 * n + 8 + (mark ? (lv.tmax * lv.tmax + 31) / 32 : 0)) * sizeof(int);
@@ -1468,7 +1528,7 @@ int slam2d_sweep(const Slam2dLidar* lidar, const Slam2dLevel* level, int32_t P, 
     if (rc) return rc;
     if (!d_est || !d_ranges || !d_out || !d_flags || est_stride < 3) return SLAM2D_E_BADARG;
     const Slam2dLevel& lv = *level;
-    if (lv.kmax < lidar->beams || !lv.partials || !lv.beam_xy) return SLAM2D_E_BADARG;
+    if (lv.kmax < lidar->beams || !lv.partials) return SLAM2D_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     launch_endpoints(*lidar, lv, P, d_est, est_stride, d_ranges, est_moving_dist, d_psi_cs, d_flags, false, s);
     if ((rc = launch_scores(lv, P, d_est, est_stride, d_uniform, d_out, s))) return rc;
@@ -1482,7 +1542,7 @@ int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2
     if (rc) return rc;
     if (!d_maps || !d_est || !d_ranges || !d_out || !d_flags || est_stride < 3) return SLAM2D_E_BADARG;
     const Slam2dLevel& lv = *level;
-    if (lv.kmax < lidar->beams || !lv.partials || !lv.beam_xy) return SLAM2D_E_BADARG;
+    if (lv.kmax < lidar->beams || !lv.partials) return SLAM2D_E_BADARG;
     if ((rc = check_field_args(lv, P, true))) return rc;
     hipStream_t s = (hipStream_t)stream;
     // the endpoints need only the frame, so they run first and tell the field build which tiles matter

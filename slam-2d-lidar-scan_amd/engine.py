@@ -23,7 +23,7 @@ _MATCH_DTYPE = np.dtype([("x", "f8"), ("y", "f8"), ("theta", "f8"), ("confidence
                          ("log_confidence", "f8"), ("best_score", "f8"), ("pick", "i4"), ("argmax", "i4")])
 _FRAME_DTYPE = np.dtype([("xlo", "f8"), ("ylo", "f8"), ("xhi", "f8"), ("yhi", "f8"), ("cx", "f8"), ("cy", "f8"),
                          ("field_min", "f8"), ("fh", "i4"), ("fw", "i4"), ("mx0", "i4"), ("mx1", "i4"),
-                         ("my0", "i4"), ("my1", "i4"), ("redo", "i4"), ("_pad", "i4"), ("min_bits", "u8")])
+                         ("my0", "i4"), ("my1", "i4"), ("redo", "i4"), ("min_known", "i4"), ("min_bits", "u8")])
 assert _MATCH_DTYPE.itemsize == C.sizeof(Slam2dMatch) and _FRAME_DTYPE.itemsize == C.sizeof(Slam2dFrame)
 
 
@@ -397,7 +397,6 @@ class SearchLevel:
             field=torch.zeros((P, self.fmax, self.fpitch), dtype=i32, device=device),     # uint32 costs
             cells=torch.zeros((P, self.ntheta, self.kmax), dtype=i32, device=device),
             kcount=torch.zeros((P, self.ntheta), dtype=i32, device=device),
-            beam_xy=torch.zeros((P, self.kmax, 2), dtype=f64, device=device),
             prior=torch.zeros((P, 2, npose), dtype=f64, device=device),
             cube=torch.zeros((P, self.ntheta, npose), dtype=f64, device=device),
             partials=torch.zeros((P, self.npartial, C.sizeof(Slam2dPartial)), dtype=torch.uint8, device=device),
@@ -419,12 +418,21 @@ class SearchLevel:
             theta_sin=t["sin"].data_ptr(), rv_coef=self.rv_coef, tw_coef=self.tw_coef,
             max_move_dev=max_move_dev, frames=t["frames"].data_ptr(), axis_x=t["axis_x"].data_ptr(),
             axis_y=t["axis_y"].data_ptr(), occ=t["occ"].data_ptr(), field=t["field"].data_ptr(),
-            cells=t["cells"].data_ptr(), kcount=t["kcount"].data_ptr(), beam_xy=t["beam_xy"].data_ptr(), prior=t["prior"].data_ptr(),
+            cells=t["cells"].data_ptr(), kcount=t["kcount"].data_ptr(), prior=t["prior"].data_ptr(),
             cube=t["cube"].data_ptr(), partials=t["partials"].data_ptr(), npartial=self.npartial, tmax=self.tmax,
             tilemask=t["occ"].data_ptr() + P * self.fmax * self.fpitch, tilestate=t["tilestate"].data_ptr(),
             tilemin=t["tilemin"].data_ptr(), tilelist=t["tilelist"].data_ptr(),
             tilecount=t["tilecount"].data_ptr(), vtable=t["vtable"].data_ptr() if t["vtable"] is not None else None,
             tileneed=t["tileneed"].data_ptr())
+
+    def next_generation(self):
+        """Advance the occupancy-image generation stamp (Slam2dLevel.occ_gen) for the next build: the
+        image is zeroed once per 255 builds instead of at every build."""
+        g = self.c.occ_gen + 1
+        if g > 255:
+            self.t["occ"].zero_()
+            g = 1
+        self.c.occ_gen = g
 
     # -- results --
     def frames(self):
@@ -514,6 +522,7 @@ class ParticleEngine:
     # -- kernels --
     def field_build(self, level, d_centre, stride):
         self.refresh_bits()
+        level.next_generation()
         check(self.L.slam2d_field_build(C.byref(self.lidar_c), C.byref(level.c), _ptr(self.d_maps), self.P,
                                         _ptr(d_centre), stride, _ptr(self.flags), _stream()), "slam2d_field_build")
 
@@ -526,6 +535,7 @@ class ParticleEngine:
         """field_build + sweep of one level in one call, blurring only the field tiles the sweep reads
         (slam2d_match): same matches and cube, level.field() is left incomplete."""
         self.refresh_bits()
+        level.next_generation()
         check(self.L.slam2d_match(C.byref(self.lidar_c), C.byref(level.c), _ptr(self.d_maps), self.P, _ptr(d_est),
                                   stride, _ptr(d_ranges), float(est_moving_dist), _ptr(d_psi_cs), _ptr(d_uniform),
                                   _ptr(d_out), _ptr(self.flags), _stream()), "slam2d_match")
