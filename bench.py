@@ -63,8 +63,6 @@ def parse():
     ap.add_argument("--particles", type=int, default=None, help="particles per GPU (default 64; config5: 128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample")
-    ap.add_argument("--streams", type=int, default=None,
-                    help="particle groups on separate HIP streams (default: SLAM2D_BENCH_STREAMS or 1)")
     return ap.parse_args()
 
 
@@ -98,8 +96,7 @@ class Scenario:
 class HotPath:
     """Device state + the per-step launch sequence (no host round trips)."""
 
-    def __init__(self, cfg, P, scen, device, first=0, total=None):
-        """State of the particles [first, first + P) of the rank's `total` particles."""
+    def __init__(self, cfg, P, scen, device):
         pkg = importlib.import_module("slam-2d-lidar-scan_amd")
         E = importlib.import_module("slam-2d-lidar-scan_amd.engine")
         self.E, self.cfg, self.P = E, cfg, P
@@ -119,10 +116,9 @@ class HotPath:
             self.fine = E.SearchLevel(self.lidar, P, device, step=u, sigma=cfg["sigma_cells"],
                                       miss_prob=cfg["miss"] ** (2 / cf), radius=cf * u, fine=True, **common)
         e = self.eng
-        sl = slice(first, first + P)
         self.d_ranges = e.to_device(scen.ranges)
-        self.d_est = e.to_device(np.ascontiguousarray(scen.est[:, sl]))
-        self.d_uniform = e.to_device(np.ascontiguousarray(scen.uniform[:, sl]))
+        self.d_est = e.to_device(scen.est)
+        self.d_uniform = e.to_device(scen.uniform)
         psi_cs = np.stack([np.cos(scen.psi), np.sin(scen.psi)], axis=1)            # shared heading prior
         self.d_psi = e.to_device(np.repeat(psi_cs[:, None, :], P, axis=1))
         self.dist = scen.dist
@@ -133,37 +129,18 @@ class HotPath:
         self.L = E._lib.lib()
         self.sharded = dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("SLAM2D_FORCE_DIST") == "1")
         self.par = importlib.import_module("slam-2d-lidar-scan_amd.parallel")
-        self.rank_particles = total or P
-        self.total_particles = self.rank_particles * (dist.get_world_size() if dist.is_initialized() else 1)
-        self.stream = torch.cuda.Stream(device=device) if total and total != P else None
-        self.done = torch.cuda.Event()
+        self.total_particles = P * (dist.get_world_size() if dist.is_initialized() else 1)
         self.normalizer = None
         self.lazy = os.environ.get("SLAM2D_BENCH_FULL_FIELD", "0") != "1"   # slam2d_match vs field_build + sweep
-        self.side = None
-        if os.environ.get("SLAM2D_BENCH_OVERLAP_WEIGHTS", "0") == "1" and self.stream is None:
-            self.side = torch.cuda.Stream(device=device)
-            self.coarse_done, self.side_done = torch.cuda.Event(), torch.cuda.Event()
-            self.side_done.record()
 
     def match_and_update(self, s):
-        """Field build, sweep (both levels) and map update of this group's particles for scan s."""
+        """Both levels of the scan match and the map update of all particles for scan s."""
         e, E = self.eng, self.E
         est, rng = self.d_est[s], self.d_ranges[s]
         if not self.lazy:
             e.field_build(self.coarse, est, 3)
-        if self.side is not None:
-            torch.cuda.current_stream().wait_event(self.side_done)     # last scan's normaliser has read m_coarse
         (e.match if self.lazy else e.sweep)(self.coarse, est, 3, rng, float(self.dist[s]), self.d_psi[s],
                                             self.d_uniform[s], self.m_coarse)
-        if self.side is not None:
-            # the weights need only the coarse confidence (the reference returns the COARSE confidence,
-            # Utils/ScanMatcher_OGBased.py:74-79): normalise -- local sums, the all-gather, merge -- on a
-            # side stream while the fine level and the map update run
-            self.coarse_done.record()
-            self.side.wait_event(self.coarse_done)
-            with torch.cuda.stream(self.side):
-                self.normalise()
-                self.side_done.record()
         final = self.m_coarse
         if self.fine is not None:
             if not self.lazy:
@@ -187,8 +164,7 @@ class HotPath:
 
     def step(self, s):
         self.match_and_update(s)
-        if self.side is None:
-            self.normalise()
+        self.normalise()
 
     def algorithmic_bytes(self, scen):
         """SURVEY.md 8(d) per particle-scan, with the build's real storage: packed uint32 cell
@@ -213,48 +189,6 @@ class HotPath:
         out["update"] = dict(touched_cells=int(empty.sum() + occ.sum()),
                              per_particle=8 * int(empty.sum() + occ.sum()), shared_lut=10 * lid.width ** 2)
         return out
-
-
-class HotGroups:
-    """The rank's particles split into groups on separate HIP streams: particles are independent during a
-    scan, so one group's latency-bound kernels (scatter, triage, endpoints, select, update) overlap the
-    other groups' throughput-bound ones (blur, sweep).  The weight normaliser runs once per scan over all
-    particles after every group's stream has been joined."""
-
-    def __init__(self, cfg, P, scen, device, n):
-        per = P // n
-        self.groups = [HotPath(cfg, per, scen, device, first=g * per, total=P) for g in range(n)]
-        g0 = self.groups[0]
-        self.eng, self.coarse, self.fine, self.P, self.E = g0.eng, g0.coarse, g0.fine, P, g0.E
-        self.all = HotPath.__new__(HotPath)                      # normaliser state over all P particles
-        a = self.all
-        a.E, a.L, a.P, a.par, a.sharded, a.total_particles = g0.E, g0.L, P, g0.par, g0.sharded, g0.total_particles
-        a.normalizer = None
-        a.d_logw = torch.zeros(P, dtype=torch.float64, device=device)
-        a.d_w = torch.zeros(P, dtype=torch.float64, device=device)
-        a.d_stats = torch.zeros(2, dtype=torch.float64, device=device)
-        a.m_coarse = torch.zeros((P, g0.E.MATCH_DOUBLES), dtype=torch.float64, device=device)
-        self.per = per
-
-    def step(self, s):
-        main = torch.cuda.current_stream()
-        start = torch.cuda.Event()
-        start.record(main)
-        for g in self.groups:
-            g.stream.wait_event(start)
-            with torch.cuda.stream(g.stream):
-                g.match_and_update(s)
-                g.done.record(g.stream)
-        for i, g in enumerate(self.groups):
-            main.wait_event(g.done)
-            self.all.m_coarse[i * self.per:(i + 1) * self.per].copy_(g.m_coarse, non_blocking=True)
-        self.all.normalise()
-
-    def algorithmic_bytes(self, scen):
-        return self.groups[0].algorithmic_bytes(scen)
-
-    def take_flags(self):
-        return np.concatenate([g.eng.take_flags() for g in self.groups])
 
 
 def cpu_baseline(cfg, scen, target_seconds):
@@ -318,11 +252,7 @@ def main():
     cfg = WORKLOADS[args.workload]
     P, K, W = args.particles or WORKLOAD_PARTICLES.get(args.workload, 64), args.steps, args.warmup
     scen = Scenario(cfg, P, K + W, seed=0, rank=rank)
-    n_streams = args.streams or int(os.environ.get("SLAM2D_BENCH_STREAMS", "1"))
-    if n_streams > 1 and P % n_streams == 0:
-        hot = HotGroups(cfg, P, scen, device, n_streams)
-    else:
-        hot = HotPath(cfg, P, scen, device)
+    hot = HotPath(cfg, P, scen, device)
 
     stages = [E._lib.STAGE_SWEEP, E._lib.STAGE_BLUR, E._lib.STAGE_SCATTER, E._lib.STAGE_UPDATE,
               E._lib.STAGE_SELECT, E._lib.STAGE_ENDPOINTS]
@@ -340,7 +270,7 @@ def main():
     E._lib.check(lib.slam2d_prof_enable(sum(1 << st for st in stages), 4 * max(W, 1) + 8), "prof_enable")
     for s in range(W):
         hot.step(s)
-    flags = hot.take_flags() if isinstance(hot, HotGroups) else hot.eng.take_flags()   # synchronises; raises on any fault
+    flags = hot.eng.take_flags()        # synchronises; raises on any fault
     warm_ms = collect()
     dom_stage = max(stages, key=lambda st: warm_ms.get(E._lib.STAGE_NAMES[st], {}).get("total_ms", 0.0))
     # timed region: only the dominant kernel keeps its event pair (an event pair costs ~5 us of
@@ -357,7 +287,7 @@ def main():
     if dist.is_initialized():
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    flags = hot.take_flags() if isinstance(hot, HotGroups) else hot.eng.take_flags()
+    flags = hot.eng.take_flags()
     lib.slam2d_prof_disable()
     if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -392,7 +322,7 @@ def main():
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 fixed-point field, u64 exact accumulate, f64 priors/scores, u32 packed counts", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {cfg['note']}", "particles_per_gpu": P, "streams_per_gpu": n_streams,
+            "config": {"workload": f"{args.workload}: {cfg['note']}", "particles_per_gpu": P,
                        "total_particles": P * world, "pose_hypotheses_per_particle_scan":
                        hot.coarse.ntheta * hot.coarse.nx ** 2 + (hot.fine.ntheta * hot.fine.nx ** 2 if hot.fine else 0),
                        "parallelism": f"particles sharded x{world}, one 24-byte-per-rank RCCL all-gather of the weight normaliser per scan"

@@ -84,8 +84,7 @@ typedef struct {
 } Slam2dMap;
 
 /* Lidar + polar spoke lookup table shared by all particles
- * (Utils/OccupancyGrid.py:22-57).  lut_cell / lut_r are the cell-major form of
- * radByX/radByY/radByR: spoke bin and radius of every cell of the W x W window. */
+ * (Utils/OccupancyGrid.py:22-57). */
 typedef struct {
     double unit;             /* unitGridSize */
     double max_range;        /* lidarMaxRange */
@@ -95,10 +94,8 @@ typedef struct {
     int32_t num_spokes;      /* numSpokes */
     int32_t spoke_start;     /* spokesStartIdx */
     int32_t lut_w;           /* W = 2*int(max_range/unit)+1 */
-    const uint32_t* lut_cell;/* [W][W] (spoke bin << 16) | floor(r / unit): 4 bytes decide most cells */
-    const double*   lut_r;   /* [W][W] exact radius, read only within ~2 cells of a beam's range thresholds */
     const double*   lut_xs;  /* [W]  linspace(-R, R, W) */
-    /* the same table beam-major (radByX/radByY/radByR themselves, :47-57).  The cells of a spoke are
+    /* radByX / radByY / radByR (:47-57): the window cells of every spoke.  The cells of a spoke are
      * ordered by radial band -- SLAM2D_SPOKE_BAND consecutive values of floor(r / unit) -- and row-major
      * inside a band; a beam touches the bands up to the one that holds range + wallThickness/2 */
     const int32_t*  spoke_band;  /* [num_spokes][num_bands + 1] index of each band's first cell (absolute) */
@@ -247,16 +244,16 @@ int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2
                  double est_moving_dist, const double* d_psi_cs, const double* d_uniform,
                  Slam2dMatch* d_out, uint32_t* d_flags, void* stream);
 
-/* updateOccupancyGrid for P particles (Utils/OccupancyGrid.py:127-159), as a dense
- * sweep of the W x W lidar window (each window cell is owned by exactly one beam).
+/* updateOccupancyGrid for P particles (Utils/OccupancyGrid.py:127-159): one wave per beam walks
+ * the cells of the beam's spoke up to the measured range (each window cell belongs to exactly
+ * one spoke, each spoke to at most one beam, so the counts are updated without atomics).
  *   d_pose[p*pose_stride + 0..2] = matched (x, y, theta)
  *   d_beam_shift: NULL, or [P][beams][2] int32 (dx, dy) index shifts reproducing the
  *                 reference's stale-index writes when the map grew during that beam
  *                 (Utils/OccupancyGrid.py:144-147). */
 int slam2d_grid_update(const Slam2dLidar* lidar, const Slam2dMap* d_maps, int32_t P,
                        const double* d_pose, int32_t pose_stride, const double* d_ranges,
-                       int32_t* d_axis_scratch /* [P*2*lut_w + beams] */, const int32_t* d_beam_shift,
-                       uint32_t* d_flags, void* stream);
+                       const int32_t* d_beam_shift, uint32_t* d_flags, void* stream);
 
 /* Particle.updateEstimatedPose for P particles (Algorithm/FastSlam.py:77-106): the pose prior of the
  * next scan from the previous matched poses and the raw odometry increment.

@@ -55,7 +55,7 @@ class Slam2dMap(C.Structure):
 class Slam2dLidar(C.Structure):
     _fields_ = [("unit", C.c_double), ("max_range", C.c_double), ("fov", C.c_double), ("wall_half", C.c_double),
                 ("beams", C.c_int32), ("num_spokes", C.c_int32), ("spoke_start", C.c_int32), ("lut_w", C.c_int32),
-                ("lut_cell", _vp), ("lut_r", _vp), ("lut_xs", _vp),
+                ("lut_xs", _vp),
                 ("spoke_band", _vp), ("spoke_cells", _vp), ("spoke_r", _vp), ("num_bands", C.c_int32), ("_pad", C.c_int32)]
 
 
@@ -107,7 +107,7 @@ SIGNATURES = {
                                C.c_double, _vp, _vp, _vp, _vp, _vp]),
     "slam2d_match": (C.c_int, [C.POINTER(Slam2dLidar), C.POINTER(Slam2dLevel), _vp, C.c_int32, _vp, C.c_int32, _vp,
                                C.c_double, _vp, _vp, _vp, _vp, _vp]),
-    "slam2d_grid_update": (C.c_int, [C.POINTER(Slam2dLidar), _vp, C.c_int32, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
+    "slam2d_grid_update": (C.c_int, [C.POINTER(Slam2dLidar), _vp, C.c_int32, _vp, C.c_int32, _vp, _vp, _vp, _vp]),
     "slam2d_prior": (C.c_int, [_vp, C.c_double, C.c_double, C.c_int32, C.c_double, _vp, C.c_int32, _vp, _vp, _vp]),
     "slam2d_post_match": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, _vp, _vp]),
     "slam2d_weights_normalize": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),

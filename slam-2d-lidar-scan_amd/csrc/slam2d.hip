@@ -989,123 +989,6 @@ __global__ __launch_bounds__(64) void k_select(Slam2dLevel lv, int chunks, int R
 // ------------------------------------------------------------------------------------
 // K3  occupancy-grid update                         (Utils/OccupancyGrid.py:127-152)
 // ------------------------------------------------------------------------------------
-__global__ void k_update_axis(Slam2dLidar lid, const Slam2dMap* __restrict__ maps, const double* __restrict__ pose,
-                              int pstride, const double* __restrict__ ranges, int P, int32_t* axis) {
-    const int p = blockIdx.y, a = blockIdx.z;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p == 0 && a == 0 && j < lid.beams) {
-        // Per beam, integer-radius bounds that are safe by one cell on either side:
-        //   floor(r/u) <  qe  =>  r < range - w/2   (empty if the beam returned, untouched otherwise)
-        //   floor(r/u) >= qb  =>  r > range + w/2   (untouched)
-        // only the thin band in between needs the exact fp64 radius.  Stored after the axis indices.
-        const double rg = ranges[j];
-        const double lo = rg - lid.wall_half, hi = rg + lid.wall_half;
-        int qe = (int)floor(lo / lid.unit) - 1, qb = (int)floor(hi / lid.unit) + 2;
-        qe = max(0, min(qe, 32767)); qb = max(0, min(qb, 32767));
-        axis[(size_t)P * 2 * lid.lut_w + j] = (int32_t)(((uint32_t)qe << 16) | (uint32_t)qb | (rg < lid.max_range ? 0x8000u : 0u));
-    }
-    if (j >= lid.lut_w) return;
-    const Slam2dMap m = maps[p];
-    const double base = pose[(size_t)p * pstride + a];
-    const double lim0 = a == 0 ? m.lim_x0 : m.lim_y0;
-    // convertRealXYToMapIdx(x + xAtSpokeDir, ...)  (:104-105,144-145)
-    axis[((size_t)p * 2 + a) * lid.lut_w + j] = (int)rint(((base + lid.lut_xs[j]) - lim0) / lid.unit);
-}
-
-#define UPD_ROWS 128
-#define UPD_BATCH 8
-__global__ __launch_bounds__(256) void k_grid_update(Slam2dLidar lid, const Slam2dMap* __restrict__ maps, int P,
-                                                     const double* __restrict__ pose, int pstride,
-                                                     const double* __restrict__ ranges,
-                                                     const int32_t* __restrict__ axis,
-                                                     const int32_t* __restrict__ beam_shift, uint32_t* flags,
-                                                     int tiles_x) {
-    __shared__ double rng_s[SLAM2D_MAX_BEAMS];
-    __shared__ uint32_t q_s[SLAM2D_MAX_BEAMS];
-    const int b = blockIdx.x;
-    const int p = b % P, t = b / P;
-    const int tx = t % tiles_x, ty = t / tiles_x;
-    const int tid = threadIdx.y * 64 + threadIdx.x;
-    for (int i = tid; i < lid.beams; i += 256) {
-        rng_s[i] = ranges[i];
-        q_s[i] = (uint32_t)axis[(size_t)P * 2 * lid.lut_w + i];      // per-beam integer bounds (k_update_axis)
-    }
-    __syncthreads();
-    const int W = lid.lut_w, S = lid.num_spokes;
-    const int j = tx * 64 + threadIdx.x;
-    if (j >= W) return;
-    // spokesOffsetIdxByTheta = int(rint(theta / (2*pi) * numSpokes))  (:131)
-    const double th = pose[(size_t)p * pstride + 2];
-    const int offset = (int)rint(th / (2 * 3.141592653589793) * (double)S);
-    int first_spoke = (lid.spoke_start + offset) % S;            // spoke of beam 0 (:134), in [0, S)
-    if (first_spoke < 0) first_spoke += S;
-    const Slam2dMap m = maps[p];
-    const int mx_base = axis[((size_t)p * 2 + 0) * W + j];
-    constexpr int NR = UPD_BATCH;
-    uint32_t f = 0;
-    for (int batch = 0; batch < UPD_ROWS / (4 * UPD_BATCH); ++batch) {
-        const int row0 = ty * UPD_ROWS + batch * 4 * UPD_BATCH;
-        if (row0 >= W) break;
-        // every load of a stage is issued before the first use (the window is latency-, not
-        // bandwidth-bound: LUT and maps mostly hit L2/MALL)
-        int row[NR], my[NR];
-        uint32_t lc[NR];
-#pragma unroll
-        for (int k = 0; k < NR; ++k) {
-            row[k] = row0 + k * 4 + threadIdx.y;
-            const int i = min(row[k], W - 1);
-            lc[k] = lid.lut_cell[(size_t)i * W + j];
-            my[k] = axis[((size_t)p * 2 + 1) * W + i];
-        }
-        uint32_t inc[NR];
-        int mxk[NR];
-#pragma unroll
-        for (int k = 0; k < NR; ++k) {
-            inc[k] = 0;
-            mxk[k] = mx_base;
-            int beam = (int)(lc[k] >> 16) - first_spoke;                             // inverse of :134
-            if (beam < 0) beam += S;
-            if (row[k] >= W || beam >= lid.beams) continue;
-            const uint32_t q = q_s[beam];
-            const int rq = (int)(lc[k] & 0xffffu), qe = (int)(q >> 16), qb = (int)(q & 0x7fffu);
-            if (rq >= qb) continue;                                                  // beyond the return
-            if (rq < qe) {
-                if (q & 0x8000u) inc[k] = 1u;                                        // :138-139,149
-            } else {
-                const double rg = rng_s[beam];
-                const double r = lid.lut_r[(size_t)row[k] * W + j];
-                const double lo = rg - lid.wall_half, hi = rg + lid.wall_half;
-                if (rg < lid.max_range && r < lo) inc[k] = 1u;                       // :138-139,149
-                else if (r > lo && r < hi) inc[k] = 0x00020002u;                     // :142-143,151-152
-            }
-            if (!inc[k]) continue;
-            if (beam_shift) {   // stale indices after a low-side growth inside this beam (:144-147)
-                mxk[k] -= beam_shift[((size_t)p * lid.beams + beam) * 2 + 0];
-                my[k] -= beam_shift[((size_t)p * lid.beams + beam) * 2 + 1];
-                if (mxk[k] < 0) mxk[k] += m.cols;
-                if (my[k] < 0) my[k] += m.rows;
-            }
-            if (mxk[k] < 0 || mxk[k] >= m.cols || my[k] < 0 || my[k] >= m.rows) { f |= SLAM2D_F_UPDATE_OUTSIDE_MAP; inc[k] = 0; }
-        }
-        uint32_t c[NR];
-#pragma unroll
-        for (int k = 0; k < NR; ++k) c[k] = inc[k] ? m.cells[(size_t)my[k] * m.pitch + mxk[k]] : 0u;
-#pragma unroll
-        for (int k = 0; k < NR; ++k) {
-            if (!inc[k]) continue;
-            if ((c[k] & 0xffffu) + (inc[k] & 0xffffu) > 0xffffu) { f |= SLAM2D_F_COUNT_OVERFLOW; continue; }
-            const uint32_t nc = c[k] + inc[k];
-            m.cells[(size_t)my[k] * m.pitch + mxk[k]] = nc;
-            const bool was = 2u * (c[k] >> 16) > (c[k] & 0xffffu), is = 2u * (nc >> 16) > (nc & 0xffffu);
-            if (was != is) {                                                      // keep the occupancy bit in step
-                uint32_t* word = m.occ_bits + (size_t)my[k] * m.bits_pitch + (mxk[k] >> 5);
-                if (is) atomicOr(word, 1u << (mxk[k] & 31)); else atomicAnd(word, ~(1u << (mxk[k] & 31)));
-            }
-        }
-    }
-    if (f) atomicOr(&flags[p], f);
-}
-
 // Beam-major update: the reference's own formulation (:134-152 walks the cells of each beam's spoke).
 // Every spoke's cell list is ordered by radial band (SLAM2D_SPOKE_BAND cells of integer radius
 // floor(r / unit) per band) and row-major inside a band, with the start of every band tabulated:
@@ -1554,29 +1437,17 @@ int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2
 }
 
 int slam2d_grid_update(const Slam2dLidar* lidar, const Slam2dMap* d_maps, int32_t P, const double* d_pose,
-                       int32_t pose_stride, const double* d_ranges, int32_t* d_axis_scratch,
-                       const int32_t* d_beam_shift, uint32_t* d_flags, void* stream) {
-    if (!lidar || !d_maps || !d_pose || !d_ranges || !d_axis_scratch || !d_flags || P <= 0 || pose_stride < 3)
-        return SLAM2D_E_BADARG;
+                       int32_t pose_stride, const double* d_ranges, const int32_t* d_beam_shift, uint32_t* d_flags,
+                       void* stream) {
+    if (!lidar || !d_maps || !d_pose || !d_ranges || !d_flags || P <= 0 || pose_stride < 3) return SLAM2D_E_BADARG;
     if (lidar->beams < 1 || lidar->beams > SLAM2D_MAX_BEAMS) return SLAM2D_E_TOOLARGE;
+    if (!lidar->spoke_band || !lidar->spoke_cells || !lidar->spoke_r || lidar->num_bands < 1 || lidar->lut_w > 65535)
+        return SLAM2D_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    const int W = lidar->lut_w;
-    static const bool dense = [] { const char* e = getenv("SLAM2D_UPDATE_DENSE"); return e && atoi(e) == 1; }();
-    if (!dense) {
-        if (!lidar->spoke_band || !lidar->spoke_cells || !lidar->spoke_r || lidar->num_bands < 1 || W > 65535) return SLAM2D_E_BADARG;
-        const int groups = cdiv(lidar->beams, UPDB_BEAMS);
-        StageScope prof(SLAM2D_STAGE_UPDATE, s);
-        k_grid_update_beams<<<8 * cdiv(P, 8) * groups, 64 * UPDB_BEAMS, 0, s>>>(
-            *lidar, d_maps, P, d_pose, pose_stride, d_ranges, d_beam_shift, d_flags, groups);
-        return launch_status();
-    }
-    k_update_axis<<<dim3(cdiv(max(W, lidar->beams), 256), P, 2), 256, 0, s>>>(*lidar, d_maps, d_pose, pose_stride, d_ranges, P, d_axis_scratch);
-    const int tiles_x = cdiv(W, 64), tiles_y = cdiv(W, UPD_ROWS);
-    {
-        StageScope prof(SLAM2D_STAGE_UPDATE, s);
-        k_grid_update<<<(unsigned)((long long)P * tiles_x * tiles_y), dim3(64, 4), 0, s>>>(
-            *lidar, d_maps, P, d_pose, pose_stride, d_ranges, d_axis_scratch, d_beam_shift, d_flags, tiles_x);
-    }
+    const int groups = cdiv(lidar->beams, UPDB_BEAMS);
+    StageScope prof(SLAM2D_STAGE_UPDATE, s);
+    k_grid_update_beams<<<8 * cdiv(P, 8) * groups, 64 * UPDB_BEAMS, 0, s>>>(*lidar, d_maps, P, d_pose, pose_stride, d_ranges,
+                                                                           d_beam_shift, d_flags, groups);
     return launch_status();
 }
 

@@ -179,18 +179,12 @@ class LidarModel:
         """Device copies + the C struct (kept alive with the tensors)."""
         key = str(device)
         if key not in self._dev:
-            # (bin << 16) | floor(r / unit): the integer radius lets the update kernel settle every cell
-            # that is not within a couple of cells of a range threshold without touching the fp64 radius
-            rq = np.floor(self.r / self.unit)
-            assert rq.max() < 65536
-            cell = (self.bin.astype(np.uint32) << np.uint32(16)) | rq.astype(np.uint32)
             ptr, cells, radii, nb = self.spoke_lists()
-            t = dict(cell=_dev(cell.view(np.int32), device), r=_dev(self.r, device), xs=_dev(self.xs, device),
-                     sptr=_dev(ptr, device), scells=_dev(cells.view(np.int32), device), sr=_dev(radii, device))
+            t = dict(xs=_dev(self.xs, device), sptr=_dev(ptr, device), scells=_dev(cells.view(np.int32), device),
+                     sr=_dev(radii, device))
             s = Slam2dLidar(unit=self.unit, max_range=self.max_range, fov=self.fov,
                             wall_half=self.wall_thickness / 2, beams=self.beams, num_spokes=self.num_spokes,
-                            spoke_start=self.spoke_start, lut_w=self.width,
-                            lut_cell=t["cell"].data_ptr(), lut_r=t["r"].data_ptr(), lut_xs=t["xs"].data_ptr(),
+                            spoke_start=self.spoke_start, lut_w=self.width, lut_xs=t["xs"].data_ptr(),
                             spoke_band=t["sptr"].data_ptr(), spoke_cells=t["scells"].data_ptr(),
                             spoke_r=t["sr"].data_ptr(), num_bands=nb)
             self._dev[key] = (s, t)
@@ -491,7 +485,6 @@ class ParticleEngine:
         self.maps = list(maps)
         self.P = len(self.maps)
         self.flags = torch.zeros(self.P, dtype=torch.int32, device=self.device)
-        self.axis_scratch = torch.zeros(self.P * 2 * lidar.width + lidar.beams, dtype=torch.int32, device=self.device)
         self.match_buf = {}
         self.refresh_maps()
 
@@ -543,7 +536,7 @@ class ParticleEngine:
     def grid_update(self, d_pose, stride, d_ranges, d_beam_shift=None):
         self.refresh_bits()
         check(self.L.slam2d_grid_update(C.byref(self.lidar_c), _ptr(self.d_maps), self.P, _ptr(d_pose), stride,
-                                        _ptr(d_ranges), _ptr(self.axis_scratch), _ptr(d_beam_shift),
+                                        _ptr(d_ranges), _ptr(d_beam_shift),
                                         _ptr(self.flags), _stream()), "slam2d_grid_update")
 
     def take_flags(self, fatal=_lib.FATAL_FLAGS):
