@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
     ap.add_argument("--particles", type=int, default=None, help="particles per GPU (default 64; config5: 128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the prior-pruned variant measurement")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample")
     return ap.parse_args()
 
@@ -132,6 +133,7 @@ class HotPath:
         self.total_particles = P * (dist.get_world_size() if dist.is_initialized() else 1)
         self.normalizer = None
         self.lazy = os.environ.get("SLAM2D_BENCH_FULL_FIELD", "0") != "1"   # slam2d_match vs field_build + sweep
+        self.prune = False      # SLAM2D_MATCH_PRUNE_BY_PRIOR: measured separately ("variants" in the JSON line)
 
     def match_and_update(self, s):
         """Both levels of the scan match and the map update of all particles for scan s."""
@@ -139,8 +141,11 @@ class HotPath:
         est, rng = self.d_est[s], self.d_ranges[s]
         if not self.lazy:
             e.field_build(self.coarse, est, 3)
-        (e.match if self.lazy else e.sweep)(self.coarse, est, 3, rng, float(self.dist[s]), self.d_psi[s],
-                                            self.d_uniform[s], self.m_coarse)
+        if self.lazy:
+            e.match(self.coarse, est, 3, rng, float(self.dist[s]), self.d_psi[s], self.d_uniform[s], self.m_coarse,
+                    prune=self.prune)
+        else:
+            e.sweep(self.coarse, est, 3, rng, float(self.dist[s]), self.d_psi[s], self.d_uniform[s], self.m_coarse)
         final = self.m_coarse
         if self.fine is not None:
             if not self.lazy:
@@ -296,6 +301,34 @@ def main():
 
     stage_ms = collect()
 
+    # Variant, measured after (and outside) the headline region: the same K scans with the poses that the
+    # motion prior rules out not scored (SLAM2D_MATCH_PRUNE_BY_PRIOR; same arg-max, confidence within 1e-12).
+    variant = None
+    if hot.lazy and not args.no_variants:
+        hot.prune = True
+        for s in range(W):
+            hot.step(s)
+        if dist.is_initialized():
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for s in range(W, W + K):
+            hot.step(s)
+        torch.cuda.synchronize()
+        if dist.is_initialized():
+            dist.barrier()
+        el2 = time.perf_counter() - t1
+        hot.eng.take_flags()
+        unsettled = int(hot.coarse.t["prune_state"].sum().item())
+        hot.prune = False
+        if dist.is_initialized():
+            t = torch.tensor([el2], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el2 = float(t.item())
+        variant = dict(value=P * world * K / el2, ms_per_step=1e3 * el2 / K, particles_swept_in_full_last_scan=unsettled,
+                       note="coarse-level poses outside the motion prior's ring (rv = -100) are not scored; "
+                            "arg-max identical, confidence within 1e-12 relative; the pose cube is not materialised")
+
     if rank == 0:
         total_units = P * world * K
         ab = hot.algorithmic_bytes(scen)
@@ -336,6 +369,8 @@ def main():
             "algorithmic_bytes_per_particle_scan": ab,
             "fault_flags": int(np.bitwise_or.reduce(flags)) if len(flags) else 0,
         }
+        if variant is not None:
+            out["variants"] = {"prior_pruned": variant}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, scen, args.cpu_seconds)
         print(json.dumps(out))

@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define SLAM2D_ABI_VERSION 2
+#define SLAM2D_ABI_VERSION 3
 #define SLAM2D_SPOKE_BAND 16         /* radial band width of the beam-major spoke table, in cells */
 
 /* library error codes (negative; positive values are hipError_t) */
@@ -181,11 +181,15 @@ typedef struct {
                                 operation order; used when blur_radius is 2 or 8 */
     uint32_t* tileneed;      /* [P][ceil(tmax*tmax/32)] scratch of slam2d_match: bit t set = the sweep reads
                                 field tile t (may be NULL when only slam2d_field_build is used) */
+    int32_t* ring;           /* [1 + ring_cap] scratch of SLAM2D_MATCH_PRUNE_BY_PRIOR: length, then the ascending
+                                sweep slots (4 consecutive dx of one dy) that hold a pose inside the prior's ring;
+                                NULL disables the option */
+    int32_t* prune_state;    /* [P] scratch of the same option: 1 = particle needs the full sweep */
+    int32_t ring_cap;        /* capacity of ring (ny * ceil(nx / 4) always suffices) */
     int32_t occ_gen;         /* 0: occ + tilemask are cleared at every build.  1..255: generation stamp -- an
                                 occ / tilemask byte means "occupied" only when it equals occ_gen, so nothing is
                                 cleared; the caller passes a value unused since the buffers were last zeroed
                                 (count 1, 2, ... 255, zero the buffers, start again at 1) */
-    int32_t _pad;
 } Slam2dLevel;
 
 /* Result of one level for one particle. */
@@ -238,11 +242,22 @@ int slam2d_sweep(const Slam2dLidar* lidar, const Slam2dLevel* level, int32_t P,
  * endpoint at some theta -- are blurred (typically 15-30 % of the tiles that hold a wall), so
  * level->field is left incomplete: tiles outside that set keep stale content.  Falls back to the
  * full build for a frame without a single free tile (the field minimum, :43, is then not known
- * without computing everything). */
+ * without computing everything).
+ *
+ * options: SLAM2D_MATCH_PRUNE_BY_PRIOR (coarse level only; ignored otherwise).  The reference adds
+ * rv = -100 to every pose whose distance from the estimate is not within maxMoveDeviation of the odometry
+ * step (:102-103), and no other term of a score is positive.  With this option the poses inside that ring
+ * are scored first; when the best of them reaches SLAM2D_PRUNE_SAFE_SCORE the poses outside cannot be the
+ * arg-max and change confidence and soft-max draw by < 1e-12 relative, so they are not scored and
+ * level->cube holds only the ring.  Any particle the ring does not settle (best ring score too low, a NaN
+ * prior outside the ring) is swept in full by the same call: d_out never differs in arg-max from the
+ * unpruned result. */
+#define SLAM2D_MATCH_PRUNE_BY_PRIOR 1u
+#define SLAM2D_PRUNE_SAFE_SCORE (-60.0)
 int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2dMap* d_maps, int32_t P,
                  const double* d_est, int32_t est_stride, const double* d_ranges,
                  double est_moving_dist, const double* d_psi_cs, const double* d_uniform,
-                 Slam2dMatch* d_out, uint32_t* d_flags, void* stream);
+                 Slam2dMatch* d_out, uint32_t* d_flags, uint32_t options, void* stream);
 
 /* updateOccupancyGrid for P particles (Utils/OccupancyGrid.py:127-159): one wave per beam walks
  * the cells of the beam's spoke up to the measured range (each window cell belongs to exactly

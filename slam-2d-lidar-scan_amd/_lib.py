@@ -37,6 +37,8 @@ INIT_CELL = 0x00010002
 MAX_BLUR_RADIUS = 16
 MAX_BEAMS = 2048
 SPOKE_BAND = 16
+MATCH_PRUNE_BY_PRIOR = 1
+PRUNE_SAFE_SCORE = -60.0
 
 STAGE_SWEEP, STAGE_BLUR, STAGE_SCATTER, STAGE_UPDATE, STAGE_SELECT, STAGE_ENDPOINTS = range(6)
 STAGE_NAMES = {STAGE_SWEEP: "k_sweep", STAGE_BLUR: "k_blur_clamp", STAGE_SCATTER: "k_occ_scatter",
@@ -84,7 +86,7 @@ class Slam2dLevel(C.Structure):
                 ("partials", _vp), ("npartial", C.c_int32), ("tmax", C.c_int32), ("tilemask", _vp),
                 ("tilestate", _vp), ("tilemin", _vp),
                 ("tilelist", _vp), ("tilecount", _vp), ("vtable", _vp), ("tileneed", _vp),
-                ("occ_gen", C.c_int32), ("_pad", C.c_int32)]
+                ("ring", _vp), ("prune_state", _vp), ("ring_cap", C.c_int32), ("occ_gen", C.c_int32)]
 
 
 class Slam2dMatch(C.Structure):
@@ -106,7 +108,7 @@ SIGNATURES = {
     "slam2d_sweep": (C.c_int, [C.POINTER(Slam2dLidar), C.POINTER(Slam2dLevel), C.c_int32, _vp, C.c_int32, _vp,
                                C.c_double, _vp, _vp, _vp, _vp, _vp]),
     "slam2d_match": (C.c_int, [C.POINTER(Slam2dLidar), C.POINTER(Slam2dLevel), _vp, C.c_int32, _vp, C.c_int32, _vp,
-                               C.c_double, _vp, _vp, _vp, _vp, _vp]),
+                               C.c_double, _vp, _vp, _vp, _vp, C.c_uint32, _vp]),
     "slam2d_grid_update": (C.c_int, [C.POINTER(Slam2dLidar), _vp, C.c_int32, _vp, C.c_int32, _vp, _vp, _vp, _vp]),
     "slam2d_prior": (C.c_int, [_vp, C.c_double, C.c_double, C.c_int32, C.c_double, _vp, C.c_int32, _vp, _vp, _vp]),
     "slam2d_post_match": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, _vp, _vp]),

@@ -596,12 +596,29 @@ __global__ __launch_bounds__(256) void k_blur_check_redo(Slam2dLevel lv, uint32_
 //      prior[p][0] = rv, prior[p][1] = thetaWeight, each [ny][nx]; computed by the theta-0 block of
 //      k_endpoints for its particle
 // ------------------------------------------------------------------------------------
+// Pruning by the motion prior (slam2d_match with SLAM2D_MATCH_PRUNE_BY_PRIOR, coarse level only).
+// The reference forces rv = -100 wherever the pose's distance from the estimate differs from the
+// odometry step by more than maxMoveDeviation (:102-103); field sums and thetaWeight are <= 0, so every
+// pose outside that ring scores <= -100.  The sweep first scores the ring alone (a few per cent of the
+// cube); if the best ring pose reaches SLAM2D_PRUNE_SAFE_SCORE = -60, no pose outside the ring can be the
+// arg-max and all of them together add less than 1e-12 (relative) to the confidence and to the soft-max
+// draw.  Otherwise -- or when a pose outside the ring has a NaN prior, which the reference's argmax would
+// return -- the particle is swept in full by a second, normally empty, launch.
+// prune_ring(): is pose offset (xv, yv) inside the ring?  The very expression that decides rv below.
+__device__ __forceinline__ bool prune_ring(const Slam2dLevel& lv, const int xv, const int yv, const double est_dist) {
+    const double mx = (double)xv * lv.step, my = (double)yv * lv.step;
+    return !(fabs(sqrt(mx * mx + my * my) - est_dist) > lv.max_move_dev);
+}
+
 __device__ __forceinline__ void write_priors(const Slam2dLevel& lv, const int p, const double est_dist,
-                                             const double* __restrict__ psi_cs) {
+                                             const double* __restrict__ psi_cs, const int prune) {
+    __shared__ int ring_cnt[4];
+    __shared__ int ring_base;
     const int nx = 2 * lv.ncell + 1, np_ = nx * nx;
     double* out = lv.prior + (size_t)p * 2 * np_;
     const double cpsi = psi_cs ? psi_cs[2 * p] : NAN;
     const double spsi = psi_cs ? psi_cs[2 * p + 1] : NAN;
+    int need_full = 0;
     for (int q = threadIdx.x; q < np_; q += blockDim.x) {
         double rv = 0.0, tw = 0.0;
         if (!lv.fine) {
@@ -619,10 +636,38 @@ __device__ __forceinline__ void write_priors(const Slam2dLevel& lv, const int p,
                 const double th = acos(arg);            // NaN when |arg| > 1, as np.arccos
                 tw = lv.tw_coef * (th * th);
             }
+            if (prune && isnan(tw) && !prune_ring(lv, xv, yv, est_dist)) need_full = 1;
         }
         out[q] = rv;
         out[np_ + q] = tw;
     }
+    if (!prune) return;
+    need_full = __syncthreads_or(need_full);
+    if (threadIdx.x == 0) lv.prune_state[p] = need_full;
+    if (p != 0) return;
+    // the ring as an ascending list of sweep slots (4 consecutive dx of one dy), shared by all particles
+    const int nq = (nx + 3) >> 2, nslot = nx * nq;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) ring_base = 0;
+    __syncthreads();
+    for (int s0 = 0; s0 < nslot; s0 += 256) {
+        const int u = s0 + threadIdx.x;
+        bool in = false;
+        if (u < nslot) {
+            const int iy = u / nq, dx = (u - iy * nq) * 4;
+            for (int e = 0; e < 4 && dx + e < nx; ++e) in = in || prune_ring(lv, dx + e - lv.ncell, iy - lv.ncell, est_dist);
+        }
+        const unsigned long long mask = __ballot(in);
+        if (lane == 0) ring_cnt[wave] = __popcll(mask);
+        __syncthreads();
+        int pos = ring_base + __popcll(mask & (lane ? (~0ull >> (64 - lane)) : 0ull));
+        for (int w2 = 0; w2 < wave; ++w2) pos += ring_cnt[w2];
+        if (in && pos < lv.ring_cap) lv.ring[1 + pos] = u;
+        __syncthreads();
+        if (threadIdx.x == 0) ring_base += ring_cnt[0] + ring_cnt[1] + ring_cnt[2] + ring_cnt[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) lv.ring[0] = ring_base <= lv.ring_cap ? ring_base : -1;     // -1: does not fit, sweep in full
 }
 
 // ------------------------------------------------------------------------------------
@@ -633,7 +678,7 @@ __device__ __forceinline__ void write_priors(const Slam2dLevel& lv, const int p,
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel lv, const double* __restrict__ est,
                                                    int estride, const double* __restrict__ ranges, uint32_t* flags,
-                                                   double est_dist, const double* __restrict__ psi_cs, int mark) {
+                                                   double est_dist, const double* __restrict__ psi_cs, int mark, int prune) {
     // np.unique (:120) through an LDS hash set: every beam inserts its cell; of the beams that hit one
     // cell the lowest beam index owns it (atomicMin), so the list keeps beam order -- which is spatially
     // coherent (neighbouring beams hit neighbouring cells) and deterministic.  Scores are exact
@@ -741,7 +786,7 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
         lv.kcount[p * lv.ntheta + it] = K;
     }
     if (bad) atomicOr(&flags[p], SLAM2D_F_ENDPOINT_OUTSIDE);
-    if (it == 0) write_priors(lv, p, est_dist, psi_cs);
+    if (it == 0) write_priors(lv, p, est_dist, psi_cs, prune);
 }
 
 // ------------------------------------------------------------------------------------
@@ -790,12 +835,16 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // gathers run at L1 delivery rate, bypassing L1 costs 1.6x) -- and their exact integer partial sums
 // meet in LDS.
 template <int RQ>
-__global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks, int bpp) {
+__global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks, int bpp, int mode) {
+    // mode 0: the whole cube.  mode 1 (RQ = 1): only the slots of the prior's ring (lv.ring).  mode 2: the
+    // whole cube, for the particles the ring pass could not settle (lv.prune_state[p] != 0) -- see write_priors.
     __shared__ unsigned long long part_s[3][WAVE * RQ * 4];
     const int b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
     const int p = (slot / bpp) * 8 + xcd;
     if (p >= P) return;
+    if (mode == 2 && lv.prune_state[p] == 0) return;
+    if (mode == 1 && lv.prune_state[p] != 0) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int w = slot % bpp;                              // (theta, chunk) of this block
@@ -805,6 +854,8 @@ __global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks
     const uint32_t* __restrict__ F = lv.field + (size_t)p * lv.fmax * lv.fpitch;
     const int* __restrict__ cl = lv.cells + ((size_t)p * lv.ntheta + it) * lv.kmax;
     const int K = lv.kcount[p * lv.ntheta + it];
+    const int nring = mode == 1 ? lv.ring[0] : 0;
+    if (mode == 1 && ch * WAVE >= nring) return;           // also nring = -1: the ring did not fit
     const int u0 = ch * (WAVE * RQ) + lane;
     // Buffer addressing (SRSRC): address = field base + per-lane VGPR byte offset (constant
     // over k) + wave-uniform SGPR byte offset (the cell) -- no vector address arithmetic in
@@ -815,7 +866,8 @@ __global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks
     unsigned lo[RQ][4], hi[RQ][4];        // exact 64-bit integer sums as 32-bit halves
 #pragma unroll
     for (int r = 0; r < RQ; ++r) {
-        const int u = u0 + r * WAVE;
+        int u = u0 + r * WAVE;
+        if (mode == 1) u = u < nring ? lv.ring[1 + u] : nslot;
         const int uu = u < nslot ? u : 0;
         const int iy = uu / nq, dx = (uu - iy * nq) * 4;
         off[r] = (iy * lv.fpitch + dx) * 4;
@@ -896,25 +948,37 @@ __global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks
 //      one wave per particle, working on the per-wave partials of the sweep
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_select(Slam2dLevel lv, int chunks, int RQ, const double* __restrict__ est,
-                                               int estride, const double* __restrict__ uniform, Slam2dMatch* out) {
+                                               int estride, const double* __restrict__ uniform, Slam2dMatch* out, int mode) {
+    // mode as in k_sweep.  In mode 1 only the first ceil(ring length / 64) chunks of every theta hold
+    // partials; the partial of (theta it, chunk ch) sits at it * chunks + ch in every mode.
     const int p = blockIdx.x, lane = threadIdx.x;
     const int nx = 2 * lv.ncell + 1, npose = nx * nx;
-    const int nW = lv.ntheta * chunks;
-    const Slam2dPartial* __restrict__ pt = lv.partials + (size_t)p * lv.npartial;
+    if (mode == 2 && lv.prune_state[p] == 0) return;
+    if (mode == 1 && lv.prune_state[p] != 0) return;
+    const int nring = mode == 1 ? lv.ring[0] : 0;
+    if (mode == 1 && nring < 0) { if (lane == 0) lv.prune_state[p] = 1; return; }
+    const int vch = mode == 1 ? (nring + WAVE - 1) / WAVE : chunks;          // chunks that hold partials
+    const int nW = lv.ntheta * vch;
+    const Slam2dPartial* __restrict__ pt0 = lv.partials + (size_t)p * lv.npartial;
+    auto part = [&](const int v) -> const Slam2dPartial& { return pt0[(v / vch) * chunks + (v % vch)]; };
     const double* __restrict__ c = lv.cube + (size_t)p * lv.ntheta * npose;
     // global max / argmax
     Best me{-INFINITY, INT_MAX, 0};
     for (int w = lane; w < nW; w += WAVE) {
-        Best cand{pt[w].max, pt[w].argmax, pt[w].has_nan};
+        Best cand{part(w).max, part(w).argmax, part(w).has_nan};
         if (better(cand, me)) me = cand;
     }
     me = wave_best(me);
     const double M = me.v;
+    if (mode == 1 && !(M >= SLAM2D_PRUNE_SAFE_SCORE)) {   // also NaN: the ring alone does not settle this particle
+        if (lane == 0) lv.prune_state[p] = 1;
+        return;
+    }
     // total = sum_w sumexp_w * exp(max_w - M): each lane owns a contiguous run of partials
     const int per = (nW + WAVE - 1) / WAVE;
     const int w0 = lane * per, w1 = min(nW, w0 + per);
     double mine = 0.0;
-    for (int w = w0; w < w1; ++w) mine += pt[w].sumexp * exp(pt[w].max - M);
+    for (int w = w0; w < w1; ++w) mine += part(w).sumexp * exp(part(w).max - M);
     double incl = mine;                           // inclusive scan over lanes
 #pragma unroll
     for (int o = 1; o < WAVE; o <<= 1) {
@@ -932,14 +996,44 @@ __global__ __launch_bounds__(64) void k_select(Slam2dLevel lv, int chunks, int R
         const int s0 = min(lsel * per, nW - 1), s1 = max(s0 + 1, min(nW, lsel * per + per));
         int wsel = s1 - 1;
         for (int w = s0; w < s1; ++w) {                           // wave-uniform loop
-            const double t = pt[w].sumexp * exp(pt[w].max - M);
+            const double t = part(w).sumexp * exp(part(w).max - M);
             if (run + t > target || w == s1 - 1) { wsel = w; break; }
             run += t;
         }
+        const int it = wsel / vch, ch = wsel - it * vch;
+        const int nq = (nx + 3) >> 2, nslot = nx * nq;
+        if (mode == 1) {
+            // ring chunk: lane l owns slot ring[ch*64 + l] = up to 4 consecutive poses; slots ascend with l,
+            // so the lanes walk the chunk's poses in cube order
+            const int idx = ch * WAVE + lane;
+            const int u = idx < nring ? lv.ring[1 + idx] : nslot;
+            const int iy = u / nq, dx = (u - iy * nq) * 4;
+            const int q0 = iy * nx + dx, nvl = u < nslot ? min(4, nx - dx) : 0;
+            double lsum = 0.0;
+            for (int e = 0; e < nvl; ++e) lsum += exp(c[(size_t)it * npose + q0 + e] - M);
+            double linc = lsum;
+#pragma unroll
+            for (int o = 1; o < WAVE; o <<= 1) {
+                const double up = __shfl_up(linc, o);
+                if (lane >= o) linc += up;
+            }
+            const unsigned long long hit = __ballot(nvl > 0 && run + linc > target);
+            const unsigned long long have = __ballot(nvl > 0);
+            const int llast = 63 - __clzll((long long)have);                      // chunk's last slot (have != 0)
+            const int l2 = hit ? __ffsll((long long)hit) - 1 : llast;
+            double r2 = run + __shfl(linc - lsum, l2);
+            int found = -1;
+            if (lane == l2) {
+                for (int e = 0; e < nvl; ++e) {
+                    r2 += exp(c[(size_t)it * npose + q0 + e] - M);
+                    if (r2 > target) { found = it * npose + q0 + e; break; }
+                }
+                if (found < 0) found = it * npose + q0 + max(0, nvl - 1);         // rounding fallback: last pose
+            }
+            pick = __shfl(found, l2);
+        } else {
         // inside chunk wsel: it covers slots [ch*64*RQ, ...) = a contiguous pose range [qlo, qhi);
         // lane l owns a contiguous run of `per2` poses of it
-        const int it = wsel / chunks, ch = wsel - it * chunks;
-        const int nq = (nx + 3) >> 2, nslot = nx * nq;
         const int s0c = min(nslot, ch * WAVE * RQ), s1c = min(nslot, (ch + 1) * WAVE * RQ);
         const int qlo = (s0c / nq) * nx + min(nx, 4 * (s0c % nq));
         const int qhi = (s1c / nq) * nx + min(nx, 4 * (s1c % nq));
@@ -967,6 +1061,7 @@ __global__ __launch_bounds__(64) void k_select(Slam2dLevel lv, int chunks, int R
                 if (found < 0) found = it * npose + max(a0, a1 - 1);
             }
             pick = __shfl(found, l2);
+        }
         }
     }
     if (lane == 0) {
@@ -1272,9 +1367,9 @@ __global__ void k_fill(uint32_t* cells, long long n, uint32_t value) {
 // C ABI
 // ------------------------------------------------------------------------------------
 template <int R>
-static void launch_sweep(const Slam2dLevel& lv, int P, int chunks, hipStream_t s) {
+static void launch_sweep(const Slam2dLevel& lv, int P, int chunks, hipStream_t s, int mode = 0) {
     const int bpp = lv.ntheta * chunks;                 // blocks per particle: one per (theta, chunk)
-    k_sweep<R><<<cdiv(P, 8) * 8 * bpp, 256, 0, s>>>(lv, P, chunks, bpp);
+    k_sweep<R><<<cdiv(P, 8) * 8 * bpp, 256, 0, s>>>(lv, P, chunks, bpp, mode);
 }
 
 extern "C" {
@@ -1354,18 +1449,18 @@ static void launch_field(const Slam2dLevel& lv, const Slam2dMap* d_maps, int P, 
 // beam endpoints, unique cells per theta, priors (/ needed tiles)
 static void launch_endpoints(const Slam2dLidar& lid, const Slam2dLevel& lv, int P, const double* d_est, int est_stride,
                              const double* d_ranges, double est_moving_dist, const double* d_psi_cs, uint32_t* d_flags,
-                             bool mark, hipStream_t s) {
+                             bool mark, bool prune, hipStream_t s) {
     StageScope prof(SLAM2D_STAGE_ENDPOINTS, s);
     int n = 256;
     while (n < lid.beams) n <<= 1;
     const size_t ep_lds = (size_t)(4 * n + 8 + (mark ? (lv.tmax * lv.tmax + 31) / 32 : 0)) * sizeof(int);
     k_endpoints<<<dim3(lv.ntheta, P), 256, ep_lds, s>>>(lid, lv, d_est, est_stride, d_ranges, d_flags, est_moving_dist,
-                                                        lv.fine ? nullptr : d_psi_cs, mark ? 1 : 0);
+                                                        lv.fine ? nullptr : d_psi_cs, mark ? 1 : 0, prune ? 1 : 0);
 }
 
 // cube sweep + selection
 static int launch_scores(const Slam2dLevel& lv, int P, const double* d_est, int est_stride, const double* d_uniform,
-                         Slam2dMatch* d_out, hipStream_t s) {
+                         Slam2dMatch* d_out, hipStream_t s, int ring_chunks = 0) {
     const int nx = 2 * lv.ncell + 1;
     const int nslot = nx * ((nx + 3) / 4);            // slots of 4 consecutive dx
     const int need = cdiv(nslot, WAVE);
@@ -1374,22 +1469,55 @@ static int launch_scores(const Slam2dLevel& lv, int P, const double* d_est, int 
         const int R = atoi(ov);
         if (R >= 1 && R <= 4) bestR = R;
     }
+    if (ring_chunks > 0) bestR = 1;
     const int chunks = cdiv(need, bestR);
     if (lv.ntheta * chunks > lv.npartial) return SLAM2D_E_BADARG;
+    if (ring_chunks > 0) {
+        // the prior's ring first (write_priors); the particles it does not settle are swept in full by the
+        // second pair of launches, whose blocks return at once for everyone else
+        {
+            StageScope prof(SLAM2D_STAGE_SWEEP, s);
+            launch_sweep<1>(lv, P, min(ring_chunks, chunks), s, 1);
+        }
+        {
+            StageScope prof(SLAM2D_STAGE_SELECT, s);
+            k_select<<<P, WAVE, 0, s>>>(lv, min(ring_chunks, chunks), 1, d_est, est_stride, d_uniform, d_out, 1);
+        }
+    }
+    const int mode = ring_chunks > 0 ? 2 : 0;
     {
         StageScope prof(SLAM2D_STAGE_SWEEP, s);
         switch (bestR) {
-            case 1: launch_sweep<1>(lv, P, chunks, s); break;
-            case 2: launch_sweep<2>(lv, P, chunks, s); break;
-            case 3: launch_sweep<3>(lv, P, chunks, s); break;
-            default: launch_sweep<4>(lv, P, chunks, s); break;
+            case 1: launch_sweep<1>(lv, P, chunks, s, mode); break;
+            case 2: launch_sweep<2>(lv, P, chunks, s, mode); break;
+            case 3: launch_sweep<3>(lv, P, chunks, s, mode); break;
+            default: launch_sweep<4>(lv, P, chunks, s, mode); break;
         }
     }
     {
         StageScope prof(SLAM2D_STAGE_SELECT, s);
-        k_select<<<P, WAVE, 0, s>>>(lv, chunks, bestR, d_est, est_stride, d_uniform, d_out);
+        k_select<<<P, WAVE, 0, s>>>(lv, chunks, bestR, d_est, est_stride, d_uniform, d_out, mode);
     }
     return 0;
+}
+
+// Upper bound (a superset is harmless) of the number of sweep slots the prior's ring touches, for the grid of
+// the ring pass; 0 = pruning not applicable.  The ring itself is listed on the device by write_priors.
+static int ring_slot_bound(const Slam2dLevel& lv, double est_dist) {
+    if (lv.fine || !lv.ring || !lv.prune_state || lv.ring_cap <= 0 || !(est_dist >= 0.0)) return 0;
+    const int nx = 2 * lv.ncell + 1, nq = (nx + 3) / 4;
+    const double slack = 1e-9 * (1.0 + est_dist + lv.step * nx);
+    int n = 0;
+    for (int iy = 0; iy < nx; ++iy)
+        for (int sq = 0; sq < nq; ++sq) {
+            bool in = false;
+            for (int e = 0; e < 4 && 4 * sq + e < nx; ++e) {
+                const double mx = (double)(4 * sq + e - lv.ncell) * lv.step, my = (double)(iy - lv.ncell) * lv.step;
+                in = in || !(fabs(sqrt(mx * mx + my * my) - est_dist) > lv.max_move_dev + slack);
+            }
+            n += in ? 1 : 0;
+        }
+    return n <= lv.ring_cap ? n : 0;
 }
 
 int slam2d_field_build(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2dMap* d_maps, int32_t P,
@@ -1413,14 +1541,15 @@ int slam2d_sweep(const Slam2dLidar* lidar, const Slam2dLevel* level, int32_t P, 
     const Slam2dLevel& lv = *level;
     if (lv.kmax < lidar->beams || !lv.partials) return SLAM2D_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    launch_endpoints(*lidar, lv, P, d_est, est_stride, d_ranges, est_moving_dist, d_psi_cs, d_flags, false, s);
+    launch_endpoints(*lidar, lv, P, d_est, est_stride, d_ranges, est_moving_dist, d_psi_cs, d_flags, false, false, s);
     if ((rc = launch_scores(lv, P, d_est, est_stride, d_uniform, d_out, s))) return rc;
     return launch_status();
 }
 
 int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2dMap* d_maps, int32_t P,
                  const double* d_est, int32_t est_stride, const double* d_ranges, double est_moving_dist,
-                 const double* d_psi_cs, const double* d_uniform, Slam2dMatch* d_out, uint32_t* d_flags, void* stream) {
+                 const double* d_psi_cs, const double* d_uniform, Slam2dMatch* d_out, uint32_t* d_flags,
+                 uint32_t options, void* stream) {
     int rc = check_level(lidar, level, P);
     if (rc) return rc;
     if (!d_maps || !d_est || !d_ranges || !d_out || !d_flags || est_stride < 3) return SLAM2D_E_BADARG;
@@ -1428,11 +1557,17 @@ int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2
     if (lv.kmax < lidar->beams || !lv.partials) return SLAM2D_E_BADARG;
     if ((rc = check_field_args(lv, P, true))) return rc;
     hipStream_t s = (hipStream_t)stream;
+    int ring_chunks = 0;
+    if (options & SLAM2D_MATCH_PRUNE_BY_PRIOR) {
+        const int bound = ring_slot_bound(lv, est_moving_dist);
+        const int nx = 2 * lv.ncell + 1, nslot = nx * ((nx + 3) / 4);
+        if (bound > 0 && 2 * bound <= nslot) ring_chunks = cdiv(bound, WAVE);     // worth it only for a thin ring
+    }
     // the endpoints need only the frame, so they run first and tell the field build which tiles matter
     if ((rc = launch_frames(*lidar, lv, d_maps, P, d_est, est_stride, d_flags, true, s))) return rc;
-    launch_endpoints(*lidar, lv, P, d_est, est_stride, d_ranges, est_moving_dist, d_psi_cs, d_flags, true, s);
+    launch_endpoints(*lidar, lv, P, d_est, est_stride, d_ranges, est_moving_dist, d_psi_cs, d_flags, true, ring_chunks > 0, s);
     launch_field(lv, d_maps, P, d_flags, true, s);
-    if ((rc = launch_scores(lv, P, d_est, est_stride, d_uniform, d_out, s))) return rc;
+    if ((rc = launch_scores(lv, P, d_est, est_stride, d_uniform, d_out, s, ring_chunks))) return rc;
     return launch_status();
 }
 

@@ -399,6 +399,8 @@ class SearchLevel:
             tilelist=torch.zeros((P, 2, self.tmax * self.tmax), dtype=i32, device=device),
             tilecount=torch.zeros((P, 2), dtype=i32, device=device),
             tileneed=torch.zeros((P, (self.tmax * self.tmax + 31) // 32), dtype=i32, device=device),
+            ring=torch.zeros(1 + self.nx * ((self.nx + 3) // 4), dtype=i32, device=device),
+            prune_state=torch.zeros(P, dtype=i32, device=device),
             # optional table-driven axis-0 pass; measured slower than the arithmetic on MI355X
             # (178 vs 164 us at config 2: the kernel is latency-, not ALU-bound), so off by default
             vtable=(_dev(column_pass_table(self.log_miss, self.taps, self.blur_radius), device)
@@ -417,7 +419,8 @@ class SearchLevel:
             tilemask=t["occ"].data_ptr() + P * self.fmax * self.fpitch, tilestate=t["tilestate"].data_ptr(),
             tilemin=t["tilemin"].data_ptr(), tilelist=t["tilelist"].data_ptr(),
             tilecount=t["tilecount"].data_ptr(), vtable=t["vtable"].data_ptr() if t["vtable"] is not None else None,
-            tileneed=t["tileneed"].data_ptr())
+            tileneed=t["tileneed"].data_ptr(), ring=t["ring"].data_ptr(), prune_state=t["prune_state"].data_ptr(),
+            ring_cap=self.nx * ((self.nx + 3) // 4))
 
     def next_generation(self):
         """Advance the occupancy-image generation stamp (Slam2dLevel.occ_gen) for the next build: the
@@ -524,14 +527,17 @@ class ParticleEngine:
                                   _ptr(d_ranges), float(est_moving_dist), _ptr(d_psi_cs), _ptr(d_uniform),
                                   _ptr(d_out), _ptr(self.flags), _stream()), "slam2d_sweep")
 
-    def match(self, level, d_est, stride, d_ranges, est_moving_dist, d_psi_cs, d_uniform, d_out):
+    def match(self, level, d_est, stride, d_ranges, est_moving_dist, d_psi_cs, d_uniform, d_out, prune=False):
         """field_build + sweep of one level in one call, blurring only the field tiles the sweep reads
-        (slam2d_match): same matches and cube, level.field() is left incomplete."""
+        (slam2d_match): same matches and cube, level.field() is left incomplete.  prune: score the poses
+        inside the motion prior's ring first and skip the rest when they cannot matter
+        (SLAM2D_MATCH_PRUNE_BY_PRIOR; coarse level only; level.cube() then holds only the ring)."""
         self.refresh_bits()
         level.next_generation()
         check(self.L.slam2d_match(C.byref(self.lidar_c), C.byref(level.c), _ptr(self.d_maps), self.P, _ptr(d_est),
                                   stride, _ptr(d_ranges), float(est_moving_dist), _ptr(d_psi_cs), _ptr(d_uniform),
-                                  _ptr(d_out), _ptr(self.flags), _stream()), "slam2d_match")
+                                  _ptr(d_out), _ptr(self.flags), _lib.MATCH_PRUNE_BY_PRIOR if prune else 0, _stream()),
+              "slam2d_match")
 
     def grid_update(self, d_pose, stride, d_ranges, d_beam_shift=None):
         self.refresh_bits()

@@ -141,6 +141,7 @@ class ParticleFilter:
         self.last_variance = None
         self._normalizer = None
         self.lazy_field = True
+        self.prune_by_prior = True      # coarse level: poses the motion prior rules out are not scored
         self.step = 0
 
     # ---- odometry prior (Algorithm/FastSlam.py:77-106) ----
@@ -282,7 +283,7 @@ class ParticleFilter:
         (slam2d_match) -- same results, the full probSP image is not materialised."""
         eng = self.engine
         if self.lazy_field:
-            eng.match(level, d_est, stride, self.d_ranges, dist, d_psi, d_uniform, d_out)
+            eng.match(level, d_est, stride, self.d_ranges, dist, d_psi, d_uniform, d_out, prune=self.prune_by_prior)
         else:
             eng.field_build(level, d_est, stride)
             eng.sweep(level, d_est, stride, self.d_ranges, dist, d_psi, d_uniform, d_out)
