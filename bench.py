@@ -180,7 +180,7 @@ class HotPath:
                 continue
             f = int(2 * lv.reach / lv.step) + 1
             wm = int(2 * lv.reach / lid.unit)
-            out[name] = dict(scatter=4 * wm * wm + f * f, blur=f * f + 4 * f * f,
+            out[name] = dict(scatter=wm * wm // 8 + f * f, blur=f * f + 4 * f * f,      # map bits in, occupied image out / in, field out
                              sweep=4 * f * f + 8 * lid.beams + 8 * lv.ntheta * lv.nx * lv.nx)
         # update: touched cells of one representative scan (cell-major classification on the host LUT)
         rng = scen.ranges[0]
@@ -192,7 +192,7 @@ class HotPath:
         empty = own & (rb < lid.max_range) & (lid.r < rb - hw)
         occ = own & (lid.r > rb - hw) & (lid.r < rb + hw)
         out["update"] = dict(touched_cells=int(empty.sum() + occ.sum()),
-                             per_particle=8 * int(empty.sum() + occ.sum()), shared_lut=10 * lid.width ** 2)
+                             per_particle=8 * int(empty.sum() + occ.sum()), shared_lut=12 * lid.width ** 2)    # RMW of 4-byte cells; spoke table (4 + 8 B per window cell)
         return out
 
 

@@ -834,8 +834,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // the same field rows at the same time -- one L1 working set per block (measured 124 -> 117 us; the
 // gathers run at L1 delivery rate, bypassing L1 costs 1.6x) -- and their exact integer partial sums
 // meet in LDS.
-template <int RQ>
-__global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks, int bpp, int mode) {
+template <int RQ, int mode>
+__global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks, int bpp) {
     // mode 0: the whole cube.  mode 1 (RQ = 1): only the slots of the prior's ring (lv.ring).  mode 2: the
     // whole cube, for the particles the ring pass could not settle (lv.prune_state[p] != 0) -- see write_priors.
     __shared__ unsigned long long part_s[3][WAVE * RQ * 4];
@@ -947,8 +947,9 @@ __global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks
 // K1d  arg-max / soft-max draw / confidence / matched pose   (Utils/ScanMatcher_OGBased.py:133-143)
 //      one wave per particle, working on the per-wave partials of the sweep
 // ------------------------------------------------------------------------------------
+template <int mode>
 __global__ __launch_bounds__(64) void k_select(Slam2dLevel lv, int chunks, int RQ, const double* __restrict__ est,
-                                               int estride, const double* __restrict__ uniform, Slam2dMatch* out, int mode) {
+                                               int estride, const double* __restrict__ uniform, Slam2dMatch* out) {
     // mode as in k_sweep.  In mode 1 only the first ceil(ring length / 64) chunks of every theta hold
     // partials; the partial of (theta it, chunk ch) sits at it * chunks + ch in every mode.
     const int p = blockIdx.x, lane = threadIdx.x;
@@ -1105,7 +1106,7 @@ __device__ __forceinline__ int rint_div(const double v, const double unit, const
 
 #define UPDB_BEAMS 4                 // = waves per block
 #define UPDB_UNROLL 4
-__global__ __launch_bounds__(256) void k_grid_update_beams(Slam2dLidar lid, const Slam2dMap* __restrict__ maps, int P,
+__global__ __launch_bounds__(256) void k_grid_update(Slam2dLidar lid, const Slam2dMap* __restrict__ maps, int P,
                                                            const double* __restrict__ pose, int pstride,
                                                            const double* __restrict__ ranges,
                                                            const int32_t* __restrict__ beam_shift, uint32_t* flags,
@@ -1369,7 +1370,10 @@ __global__ void k_fill(uint32_t* cells, long long n, uint32_t value) {
 template <int R>
 static void launch_sweep(const Slam2dLevel& lv, int P, int chunks, hipStream_t s, int mode = 0) {
     const int bpp = lv.ntheta * chunks;                 // blocks per particle: one per (theta, chunk)
-    k_sweep<R><<<cdiv(P, 8) * 8 * bpp, 256, 0, s>>>(lv, P, chunks, bpp, mode);
+    const unsigned grid = cdiv(P, 8) * 8 * bpp;
+    if (mode == 0) k_sweep<R, 0><<<grid, 256, 0, s>>>(lv, P, chunks, bpp);
+    else if (mode == 2) k_sweep<R, 2><<<grid, 256, 0, s>>>(lv, P, chunks, bpp);
+    else if constexpr (R == 1) k_sweep<1, 1><<<grid, 256, 0, s>>>(lv, P, chunks, bpp);
 }
 
 extern "C" {
@@ -1481,7 +1485,7 @@ static int launch_scores(const Slam2dLevel& lv, int P, const double* d_est, int 
         }
         {
             StageScope prof(SLAM2D_STAGE_SELECT, s);
-            k_select<<<P, WAVE, 0, s>>>(lv, min(ring_chunks, chunks), 1, d_est, est_stride, d_uniform, d_out, 1);
+            k_select<1><<<P, WAVE, 0, s>>>(lv, min(ring_chunks, chunks), 1, d_est, est_stride, d_uniform, d_out);
         }
     }
     const int mode = ring_chunks > 0 ? 2 : 0;
@@ -1496,7 +1500,8 @@ static int launch_scores(const Slam2dLevel& lv, int P, const double* d_est, int 
     }
     {
         StageScope prof(SLAM2D_STAGE_SELECT, s);
-        k_select<<<P, WAVE, 0, s>>>(lv, chunks, bestR, d_est, est_stride, d_uniform, d_out, mode);
+        if (mode == 0) k_select<0><<<P, WAVE, 0, s>>>(lv, chunks, bestR, d_est, est_stride, d_uniform, d_out);
+        else k_select<2><<<P, WAVE, 0, s>>>(lv, chunks, bestR, d_est, est_stride, d_uniform, d_out);
     }
     return 0;
 }
@@ -1581,7 +1586,7 @@ int slam2d_grid_update(const Slam2dLidar* lidar, const Slam2dMap* d_maps, int32_
     hipStream_t s = (hipStream_t)stream;
     const int groups = cdiv(lidar->beams, UPDB_BEAMS);
     StageScope prof(SLAM2D_STAGE_UPDATE, s);
-    k_grid_update_beams<<<8 * cdiv(P, 8) * groups, 64 * UPDB_BEAMS, 0, s>>>(*lidar, d_maps, P, d_pose, pose_stride, d_ranges,
+    k_grid_update<<<8 * cdiv(P, 8) * groups, 64 * UPDB_BEAMS, 0, s>>>(*lidar, d_maps, P, d_pose, pose_stride, d_ranges,
                                                                            d_beam_shift, d_flags, groups);
     return launch_status();
 }
