@@ -92,6 +92,9 @@ class Scenario:
         self.dist = np.hypot(d[:, 0], d[:, 1])
         self.psi = np.arctan2(d[:, 1], d[:, 0])
         self.uniform = rs.random_sample((n_scans, P))
+        # heading of the odometry step with a little odometry noise (an exactly lattice-aligned heading makes the
+        # reference's arccos argument round above 1 -> NaN thetaWeight along that direction, Q-list in SURVEY App. A)
+        self.psi = self.psi + rs.normal(0.0, 0.01, size=self.psi.shape)
 
 
 class HotPath:

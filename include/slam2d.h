@@ -117,7 +117,7 @@ typedef struct {
     int32_t my0, my1;        /* map row window    [my0, my1) */
     int32_t redo;            /* 1 = the clamp was redone with the measured minimum */
     int32_t min_known;       /* 1 = some tile of the frame is free, so field_min is the analytic floor */
-    unsigned long long min_bits; /* reserved */
+    double field_max;        /* largest value of the (clamped) field over the tiles built at this call */
 } Slam2dFrame;
 
 /* Reduction of the 64*R consecutive cube entries one wave of the sweep scored. */
@@ -174,6 +174,7 @@ typedef struct {
                                 Initialise to 1; set to 1 whenever the field buffer is written by
                                 anything other than slam2d_field_build */
     double*  tilemin;        /* [P][tmax][tmax] scratch: per-tile minimum of the blurred field */
+    double*  tilemax;        /* [P][tmax][tmax] scratch: per-tile maximum of the field as stored */
     int32_t* tilelist;       /* [P][2][tmax*tmax] scratch: work lists (tiles to blur, tiles to fill) */
     int32_t* tilecount;      /* [P][2] scratch: their lengths */
     const double* vtable;    /* NULL, or [2^(2*blur_radius+1)] axis-0 blur result of every binary column
@@ -247,13 +248,14 @@ int slam2d_sweep(const Slam2dLidar* lidar, const Slam2dLevel* level, int32_t P,
  * options: SLAM2D_MATCH_PRUNE_BY_PRIOR (coarse level only; ignored otherwise).  The reference adds
  * rv = -100 to every pose whose distance from the estimate is not within maxMoveDeviation of the odometry
  * step (:102-103), and no other term of a score is positive.  With this option the poses inside that ring
- * are scored first; when the best of them reaches SLAM2D_PRUNE_SAFE_SCORE the poses outside cannot be the
+ * are scored first; when the best of them exceeds -100 + K * max(field) (K = fewest endpoint cells of any
+ * theta: the best any pose outside could reach) by SLAM2D_PRUNE_MARGIN, the poses outside cannot be the
  * arg-max and change confidence and soft-max draw by < 1e-12 relative, so they are not scored and
  * level->cube holds only the ring.  Any particle the ring does not settle (best ring score too low, a NaN
  * prior outside the ring) is swept in full by the same call: d_out never differs in arg-max from the
  * unpruned result. */
 #define SLAM2D_MATCH_PRUNE_BY_PRIOR 1u
-#define SLAM2D_PRUNE_SAFE_SCORE (-60.0)
+#define SLAM2D_PRUNE_MARGIN 40.0
 int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2dMap* d_maps, int32_t P,
                  const double* d_est, int32_t est_stride, const double* d_ranges,
                  double est_moving_dist, const double* d_psi_cs, const double* d_uniform,

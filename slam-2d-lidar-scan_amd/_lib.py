@@ -38,7 +38,7 @@ MAX_BLUR_RADIUS = 16
 MAX_BEAMS = 2048
 SPOKE_BAND = 16
 MATCH_PRUNE_BY_PRIOR = 1
-PRUNE_SAFE_SCORE = -60.0
+PRUNE_MARGIN = 40.0
 
 STAGE_SWEEP, STAGE_BLUR, STAGE_SCATTER, STAGE_UPDATE, STAGE_SELECT, STAGE_ENDPOINTS = range(6)
 STAGE_NAMES = {STAGE_SWEEP: "k_sweep", STAGE_BLUR: "k_blur_clamp", STAGE_SCATTER: "k_occ_scatter",
@@ -66,7 +66,7 @@ class Slam2dFrame(C.Structure):
                 ("cx", C.c_double), ("cy", C.c_double), ("field_min", C.c_double),
                 ("fh", C.c_int32), ("fw", C.c_int32), ("mx0", C.c_int32), ("mx1", C.c_int32),
                 ("my0", C.c_int32), ("my1", C.c_int32), ("redo", C.c_int32), ("min_known", C.c_int32),
-                ("min_bits", C.c_uint64)]
+                ("field_max", C.c_double)]
 
 
 class Slam2dPartial(C.Structure):
@@ -84,7 +84,7 @@ class Slam2dLevel(C.Structure):
                 ("frames", _vp), ("axis_x", _vp), ("axis_y", _vp), ("occ", _vp), ("field", _vp),
                 ("cells", _vp), ("kcount", _vp), ("prior", _vp), ("cube", _vp),
                 ("partials", _vp), ("npartial", C.c_int32), ("tmax", C.c_int32), ("tilemask", _vp),
-                ("tilestate", _vp), ("tilemin", _vp),
+                ("tilestate", _vp), ("tilemin", _vp), ("tilemax", _vp),
                 ("tilelist", _vp), ("tilecount", _vp), ("vtable", _vp), ("tileneed", _vp),
                 ("ring", _vp), ("prune_state", _vp), ("ring_cap", C.c_int32), ("occ_gen", C.c_int32)]
 

@@ -113,7 +113,7 @@ __device__ __forceinline__ Slam2dFrame make_frame(const Slam2dLidar& lid, const 
     if (my1 - my0 > lv.wmax) { my1 = my0 + lv.wmax; f |= SLAM2D_F_WINDOW_OUTSIDE_MAP; }
     fr.fh = fh; fr.fw = fw; fr.mx0 = mx0; fr.mx1 = mx1; fr.my0 = my0; fr.my1 = my1;
     fr.field_min = lv.floor_value; fr.redo = 0; fr.min_known = 0;
-    fr.min_bits = ~0ull;
+    fr.field_max = 0.0;
     return fr;
 }
 
@@ -360,7 +360,10 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
     const double* __restrict__ w = lv.blur_w;
     if (!any) {
         const double v = lv.floor_value;
-        if (mode == 0 && tid == 0) lv.tilemin[((size_t)p * lv.tmax + tby) * lv.tmax + tbx] = v;
+        if (mode == 0 && tid == 0) {
+            lv.tilemin[((size_t)p * lv.tmax + tby) * lv.tmax + tbx] = v;
+            lv.tilemax[((size_t)p * lv.tmax + tby) * lv.tmax + tbx] = v > thr ? 0.0 : v;
+        }
         if (mode == 0 && *state == 0) return;          // already holds the constant: nothing to write
         const uint32_t c = v > thr ? 0u : (uint32_t)rint(-v * lv.cost_scale);
         for (int idx = tid; idx < BLUR_TILE * BLUR_TILE; idx += BLUR_THREADS) {
@@ -371,7 +374,7 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
         return;
     }
     if (tid == 0) *state = 1;
-    double lmin = INFINITY;
+    double lmin = INFINITY, lmax = -INFINITY;     // of the blurred values / of the values as stored (after the clamp)
     // SciPy symmetric correlate1d order: out = a[c]*w[c]; for j=-r..-1: out += (a[c+j] + a[c-j]) * w[j]
     if constexpr (RAD > 0) {
         {   // axis-0 pass: lane = (column lx, half of the tile's rows: 8 consecutive outputs)
@@ -405,6 +408,7 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
                 const int gy = ty0 + y, gx = tx0 + x0 + o;
                 if (gy < fh && gx < fw) {
                     lmin = fmin(lmin, acc);
+                    lmax = fmax(lmax, acc > thr ? 0.0 : acc);
                     field[(size_t)gy * lv.fpitch + gx] = acc > thr ? 0u : (uint32_t)rint(-acc * lv.cost_scale);
                 }
             }
@@ -428,13 +432,17 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
             const int gy = ty0 + y, gx = tx0 + x;
             if (gy < fh && gx < fw) {
                 lmin = fmin(lmin, acc);
+                lmax = fmax(lmax, acc > thr ? 0.0 : acc);
                 field[(size_t)gy * lv.fpitch + gx] = acc > thr ? 0u : (uint32_t)rint(-acc * lv.cost_scale);
             }
         }
     }
     if (mode == 0) {
-        for (int o = 32; o > 0; o >>= 1) lmin = fmin(lmin, __shfl_down(lmin, o));
-        if (tid == 0) lv.tilemin[((size_t)p * lv.tmax + tby) * lv.tmax + tbx] = lmin;   // reduced by k_blur_check_redo
+        for (int o = 32; o > 0; o >>= 1) { lmin = fmin(lmin, __shfl_down(lmin, o)); lmax = fmax(lmax, __shfl_down(lmax, o)); }
+        if (tid == 0) {                                // reduced by k_blur_check_redo
+            lv.tilemin[((size_t)p * lv.tmax + tby) * lv.tmax + tbx] = lmin;
+            lv.tilemax[((size_t)p * lv.tmax + tby) * lv.tmax + tbx] = lmax;
+        }
     }
     __syncthreads();                                   // LDS is reused by the block's next tile
 }
@@ -573,6 +581,17 @@ __global__ __launch_bounds__(256) void k_blur_check_redo(Slam2dLevel lv, uint32_
     __shared__ double red_s[4];
     const int p = blockIdx.x, tid = threadIdx.x;
     Slam2dFrame fr = lv.frames[p];
+    {   // largest value any pose can read: free tiles hold the floor, the blurred ones recorded theirs
+        const int n = lv.tilecount[2 * p];
+        const int* list = lv.tilelist + (size_t)p * 2 * lv.tmax * lv.tmax;
+        double mx = lv.floor_value > 0.5 * lv.floor_value ? 0.0 : lv.floor_value;
+        for (int i = tid; i < n; i += 256) mx = fmax(mx, lv.tilemax[(size_t)p * lv.tmax * lv.tmax + list[i]]);
+        for (int o = 1; o < WAVE; o <<= 1) mx = fmax(mx, __shfl_xor(mx, o));
+        if ((tid & 63) == 0) red_s[tid >> 6] = mx;
+        __syncthreads();
+        if (tid == 0) lv.frames[p].field_max = fmax(fmax(red_s[0], red_s[1]), fmax(red_s[2], red_s[3]));
+        __syncthreads();
+    }
     if (fr.min_known) return;                          // a free tile exists: the minimum is the analytic floor
     const int nty = (fr.fh + BLUR_TILE - 1) >> BLUR_SHIFT, ntx = (fr.fw + BLUR_TILE - 1) >> BLUR_SHIFT;
     const double* __restrict__ tm = lv.tilemin + (size_t)p * lv.tmax * lv.tmax;
@@ -600,9 +619,9 @@ __global__ __launch_bounds__(256) void k_blur_check_redo(Slam2dLevel lv, uint32_
 // The reference forces rv = -100 wherever the pose's distance from the estimate differs from the
 // odometry step by more than maxMoveDeviation (:102-103); field sums and thetaWeight are <= 0, so every
 // pose outside that ring scores <= -100.  The sweep first scores the ring alone (a few per cent of the
-// cube); if the best ring pose reaches SLAM2D_PRUNE_SAFE_SCORE = -60, no pose outside the ring can be the
-// arg-max and all of them together add less than 1e-12 (relative) to the confidence and to the soft-max
-// draw.  Otherwise -- or when a pose outside the ring has a NaN prior, which the reference's argmax would
+// cube); if the best ring pose beats -100 + K * (largest value of the field) by SLAM2D_PRUNE_MARGIN = 40, no
+// pose outside the ring can be the arg-max and all of them together add less than 1e-12 (relative) to the
+// confidence and to the soft-max draw.  Otherwise -- or when a pose outside the ring has a NaN prior, which the reference's argmax would
 // return -- the particle is swept in full by a second, normally empty, launch.
 // prune_ring(): is pose offset (xv, yv) inside the ring?  The very expression that decides rv below.
 __device__ __forceinline__ bool prune_ring(const Slam2dLevel& lv, const int xv, const int yv, const double est_dist) {
@@ -971,9 +990,17 @@ __global__ __launch_bounds__(64) void k_select(Slam2dLevel lv, int chunks, int R
     }
     me = wave_best(me);
     const double M = me.v;
-    if (mode == 1 && !(M >= SLAM2D_PRUNE_SAFE_SCORE)) {   // also NaN: the ring alone does not settle this particle
-        if (lane == 0) lv.prune_state[p] = 1;
-        return;
+    if (mode == 1) {
+        // a pose outside the ring scores rv + (field sum) + thetaWeight <= -100 + K * (largest field value);
+        // K = cells of its theta, so the fewest cells of any theta give the bound for all of them
+        int kmin = INT_MAX;
+        for (int it = lane; it < lv.ntheta; it += WAVE) kmin = min(kmin, lv.kcount[p * lv.ntheta + it]);
+        for (int o = 1; o < WAVE; o <<= 1) kmin = min(kmin, __shfl_xor(kmin, o));
+        const double outside = -100.0 + (double)kmin * lv.frames[p].field_max;
+        if (!(M >= outside + SLAM2D_PRUNE_MARGIN)) {     // also NaN: the ring alone does not settle this particle
+            if (lane == 0) lv.prune_state[p] = 1;
+            return;
+        }
     }
     // total = sum_w sumexp_w * exp(max_w - M): each lane owns a contiguous run of partials
     const int per = (nW + WAVE - 1) / WAVE;
@@ -1409,7 +1436,7 @@ static int check_level(const Slam2dLidar* lidar, const Slam2dLevel* lv, int P) {
 
 // ---- launch sequences shared by slam2d_field_build / slam2d_sweep / slam2d_match ----
 static int check_field_args(const Slam2dLevel& lv, int P, bool lazy) {
-    if (lv.tilemask != lv.occ + (size_t)P * lv.fmax * lv.fpitch || !lv.tilestate || !lv.tilemin || !lv.tilelist || !lv.tilecount)
+    if (lv.tilemask != lv.occ + (size_t)P * lv.fmax * lv.fpitch || !lv.tilestate || !lv.tilemin || !lv.tilemax || !lv.tilelist || !lv.tilecount)
         return SLAM2D_E_BADARG;
     if (lazy && !lv.tileneed) return SLAM2D_E_BADARG;
     if (lv.tmax * lv.tmax > 28000) return SLAM2D_E_TOOLARGE;        // k_tile_triage: 32 passes, 64 KB of LDS

@@ -23,7 +23,7 @@ _MATCH_DTYPE = np.dtype([("x", "f8"), ("y", "f8"), ("theta", "f8"), ("confidence
                          ("log_confidence", "f8"), ("best_score", "f8"), ("pick", "i4"), ("argmax", "i4")])
 _FRAME_DTYPE = np.dtype([("xlo", "f8"), ("ylo", "f8"), ("xhi", "f8"), ("yhi", "f8"), ("cx", "f8"), ("cy", "f8"),
                          ("field_min", "f8"), ("fh", "i4"), ("fw", "i4"), ("mx0", "i4"), ("mx1", "i4"),
-                         ("my0", "i4"), ("my1", "i4"), ("redo", "i4"), ("min_known", "i4"), ("min_bits", "u8")])
+                         ("my0", "i4"), ("my1", "i4"), ("redo", "i4"), ("min_known", "i4"), ("field_max", "f8")])
 assert _MATCH_DTYPE.itemsize == C.sizeof(Slam2dMatch) and _FRAME_DTYPE.itemsize == C.sizeof(Slam2dFrame)
 
 
@@ -396,6 +396,7 @@ class SearchLevel:
             partials=torch.zeros((P, self.npartial, C.sizeof(Slam2dPartial)), dtype=torch.uint8, device=device),
             tilestate=torch.ones((P, self.tmax, self.tmax), dtype=torch.uint8, device=device),   # all dirty
             tilemin=torch.zeros((P, self.tmax, self.tmax), dtype=f64, device=device),
+            tilemax=torch.zeros((P, self.tmax, self.tmax), dtype=f64, device=device),
             tilelist=torch.zeros((P, 2, self.tmax * self.tmax), dtype=i32, device=device),
             tilecount=torch.zeros((P, 2), dtype=i32, device=device),
             tileneed=torch.zeros((P, (self.tmax * self.tmax + 31) // 32), dtype=i32, device=device),
@@ -417,7 +418,7 @@ class SearchLevel:
             cells=t["cells"].data_ptr(), kcount=t["kcount"].data_ptr(), prior=t["prior"].data_ptr(),
             cube=t["cube"].data_ptr(), partials=t["partials"].data_ptr(), npartial=self.npartial, tmax=self.tmax,
             tilemask=t["occ"].data_ptr() + P * self.fmax * self.fpitch, tilestate=t["tilestate"].data_ptr(),
-            tilemin=t["tilemin"].data_ptr(), tilelist=t["tilelist"].data_ptr(),
+            tilemin=t["tilemin"].data_ptr(), tilemax=t["tilemax"].data_ptr(), tilelist=t["tilelist"].data_ptr(),
             tilecount=t["tilecount"].data_ptr(), vtable=t["vtable"].data_ptr() if t["vtable"] is not None else None,
             tileneed=t["tileneed"].data_ptr(), ring=t["ring"].data_ptr(), prune_state=t["prune_state"].data_ptr(),
             ring_cap=self.nx * ((self.nx + 3) // 4))

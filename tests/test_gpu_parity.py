@@ -606,7 +606,7 @@ def test_prior_pruning_equals_full_sweep(pkg):
                 assert np.array_equal(mf[p:p + 1].view(np.uint8), mp[p:p + 1].view(np.uint8))
                 assert np.array_equal(cf[p].view(np.uint8), cp[p].view(np.uint8))
             else:
-                assert mf["best_score"][p] == mp["best_score"][p] >= lib.PRUNE_SAFE_SCORE
+                assert mf["best_score"][p] == mp["best_score"][p] >= -100.0 + lib.PRUNE_MARGIN - 170 * 2.0
                 np.testing.assert_allclose(mp["confidence"][p], mf["confidence"][p], rtol=1e-10)
                 np.testing.assert_allclose(mp["log_confidence"][p], mf["log_confidence"][p], rtol=1e-12)
                 for u in ring[1:1 + ring[0]]:
