@@ -170,12 +170,23 @@ __global__ __launch_bounds__(256) void k_occ_scatter(Slam2dLevel lv, const Slam2
     const Slam2dMap m = maps[p];
     constexpr int NR = SCATTER_ROWS / 4;
     const int i0 = blockIdx.y * SCATTER_ROWS + wave;
+    // the field column of every window column is staged in LDS and the rows' field indices are loaded with
+    // the words: the expansion loop below then has no global load in its dependency chain
+    extern __shared__ int32_t ax_s[];
+    const int ncol = fr.mx1 - fr.mx0;
+    {
+        const int32_t* __restrict__ ax = lv.axis_x + (size_t)p * lv.wmax;
+        for (int j = wave * 64 + lane; j < ncol; j += 256) ax_s[j] = ax[j];
+    }
     uint32_t words[NR];
+    int fyk[NR];
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
         const int i = i0 + 4 * k;
         words[k] = (i < nrow && w <= wlast) ? m.occ_bits[(size_t)(fr.my0 + i) * m.bits_pitch + w] : 0u;
+        fyk[k] = i < nrow ? lv.axis_y[(size_t)p * lv.wmax + i] : -1;
     }
+    __syncthreads();
     const int col_base = w << 5;
     uint32_t edge = ~0u;
     if (col_base < fr.mx0) edge &= ~0u << (fr.mx0 - col_base);                    // window edges
@@ -183,14 +194,13 @@ __global__ __launch_bounds__(256) void k_occ_scatter(Slam2dLevel lv, const Slam2
     uint8_t* occ = lv.occ + (size_t)p * lv.fmax * lv.fpitch;
     uint8_t* tiles = lv.tilemask + (size_t)p * lv.tmax * lv.tmax;
     const uint8_t stamp = occ_stamp(lv);
-    const int32_t* __restrict__ ax = lv.axis_x + (size_t)p * lv.wmax;
     const int half = lane >> 5, bit = lane & 31;
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
         const uint32_t word = words[k] & edge;
         unsigned long long nz = __ballot(word != 0u);
         if (!nz) continue;
-        const int fy = lv.axis_y[(size_t)p * lv.wmax + i0 + 4 * k];
+        const int fy = fyk[k];
         while (nz) {
             const int sa = __ffsll((long long)nz) - 1;
             nz &= nz - 1;
@@ -201,7 +211,7 @@ __global__ __launch_bounds__(256) void k_occ_scatter(Slam2dLevel lv, const Slam2
             const int src = half ? sb : sa;
             if ((wsel >> bit) & 1u) {
                 const int col = ((w0 + src) << 5) + bit;
-                const int fx = ax[col - fr.mx0];
+                const int fx = ax_s[col - fr.mx0];
                 if (fx >= 0 && fy >= 0) {                                          // :36-37
                     occ[(size_t)fy * lv.fpitch + fx] = stamp;
                     tiles[(fy >> BLUR_SHIFT) * lv.tmax + (fx >> BLUR_SHIFT)] = stamp;
@@ -1456,7 +1466,7 @@ static int launch_frames(const Slam2dLidar& lid, const Slam2dLevel& lv, const Sl
 static void launch_field(const Slam2dLevel& lv, const Slam2dMap* d_maps, int P, uint32_t* d_flags, bool lazy, hipStream_t s) {
     {
         StageScope prof(SLAM2D_STAGE_SCATTER, s);
-        k_occ_scatter<<<dim3(cdiv(cdiv(lv.wmax, 32) + 1, 64), cdiv(lv.wmax, SCATTER_ROWS), P), dim3(64, 4), 0, s>>>(lv, d_maps);
+        k_occ_scatter<<<dim3(cdiv(cdiv(lv.wmax, 32) + 1, 64), cdiv(lv.wmax, SCATTER_ROWS), P), dim3(64, 4), (size_t)lv.wmax * sizeof(int32_t), s>>>(lv, d_maps);
     }
     const int ntile = lv.tmax * lv.tmax;
     k_tile_triage<<<P, TRIAGE_THREADS, (size_t)2 * ((ntile + 3) & ~3) + 4 * ((ntile + 31) / 32), s>>>(lv, lazy ? 1 : 0);
