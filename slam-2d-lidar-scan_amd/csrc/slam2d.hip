@@ -622,8 +622,8 @@ __global__ __launch_bounds__(256) void k_blur_check_redo(Slam2dLevel lv, uint32_
 
 // ------------------------------------------------------------------------------------
 // K1b  motion priors rv / thetaWeight              (Utils/ScanMatcher_OGBased.py:97-110)
-//      prior[p][0] = rv, prior[p][1] = thetaWeight, each [ny][nx]; computed by the theta-0 block of
-//      k_endpoints for its particle
+//      prior[p][0] = rv, prior[p][1] = thetaWeight, each [ny][nx]; computed by the extra block of
+//      k_endpoints' extra block of the particle
 // ------------------------------------------------------------------------------------
 // Pruning by the motion prior (slam2d_match with SLAM2D_MATCH_PRUNE_BY_PRIOR, coarse level only).
 // The reference forces rv = -100 wherever the pose's distance from the estimate differs from the
@@ -716,6 +716,10 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
     // lv.tileneed, through an LDS bitmap, so that the field build can skip every other tile.
     extern __shared__ __attribute__((aligned(16))) int ep_lds[];     // [2n] keys, [2n] owners, [8] wave counts, [nneed] tiles
     const int it = blockIdx.x, p = blockIdx.y, tid = threadIdx.x;
+    if (it == lv.ntheta) {                                 // the extra block of every particle: motion priors (+ ring)
+        write_priors(lv, p, est_dist, psi_cs, prune);
+        return;
+    }
     const Slam2dFrame fr = lv.frames[p];
     const double ex = est[(size_t)p * estride], ey = est[(size_t)p * estride + 1];
     const int B = lid.beams;
@@ -815,7 +819,6 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
         lv.kcount[p * lv.ntheta + it] = K;
     }
     if (bad) atomicOr(&flags[p], SLAM2D_F_ENDPOINT_OUTSIDE);
-    if (it == 0) write_priors(lv, p, est_dist, psi_cs, prune);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1495,7 +1498,7 @@ static void launch_endpoints(const Slam2dLidar& lid, const Slam2dLevel& lv, int 
     int n = 256;
     while (n < lid.beams) n <<= 1;
     const size_t ep_lds = (size_t)(4 * n + 8 + (mark ? (lv.tmax * lv.tmax + 31) / 32 : 0)) * sizeof(int);
-    k_endpoints<<<dim3(lv.ntheta, P), 256, ep_lds, s>>>(lid, lv, d_est, est_stride, d_ranges, d_flags, est_moving_dist,
+    k_endpoints<<<dim3(lv.ntheta + 1, P), 256, ep_lds, s>>>(lid, lv, d_est, est_stride, d_ranges, d_flags, est_moving_dist,
                                                         lv.fine ? nullptr : d_psi_cs, mark ? 1 : 0, prune ? 1 : 0);
 }
 
