@@ -471,7 +471,6 @@ __global__ __launch_bounds__(TRIAGE_THREADS) void k_tile_triage(Slam2dLevel lv, 
     // tile flags, tile states and the needed-tile bitmap of the particle are staged in LDS with one batch
     // of coalesced loads; everything after that runs out of LDS (the kernel is pure latency otherwise)
     extern __shared__ __attribute__((aligned(16))) uint8_t tri_lds[];     // [ntile4] flags, [ntile4] states, [nneed] words
-    __shared__ int wave_cnt[2][2][16];
     __shared__ int base[2];
     const int p = blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -514,6 +513,8 @@ __global__ __launch_bounds__(TRIAGE_THREADS) void k_tile_triage(Slam2dLevel lv, 
     if (tid == 0) lv.frames[p].min_known = has_free;
     const bool everything = !lazy || !has_free;
     int* list = lv.tilelist + (size_t)p * 2 * ntile;
+    // list positions from LDS counters (one aggregated atomic per wave and list): the order of a list does not
+    // matter -- every tile is blurred / filled independently -- and the loop needs no barrier
     const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
     for (int it = 0; it < iters; ++it) {
         const int t = it * TRIAGE_THREADS + tid;
@@ -525,31 +526,15 @@ __global__ __launch_bounds__(TRIAGE_THREADS) void k_tile_triage(Slam2dLevel lv, 
             if (wanted && state_s[t] != 0) { to_fill = true; state[t] = 0; }
         }
         const bool mine[2] = {wanted && any, to_fill};
-        int rank[2];
 #pragma unroll
         for (int which = 0; which < 2; ++which) {
             const unsigned long long mask = __ballot(mine[which]);
-            rank[which] = __popcll(mask & below);
-            if (lane == 0) wave_cnt[it & 1][which][wave] = __popcll(mask);
+            if (!mask) continue;
+            int start = 0;
+            if (lane == 0) start = atomicAdd(&base[which], __popcll(mask));
+            start = __shfl(start, 0);
+            if (mine[which]) list[which * ntile + start + __popcll(mask & below)] = t;
         }
-        __syncthreads();
-        if (tid < 32) {                                    // lanes 0-15: blur list, 16-31: fill list; 16-lane scans
-            const int which = tid >> 4, w2 = tid & 15;
-            const int c = wave_cnt[it & 1][which][w2];
-            int incl = c;
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                const int up = __shfl_up(incl, o, 16);
-                if (w2 >= o) incl += up;
-            }
-            const int start = base[which];
-            wave_cnt[it & 1][which][w2] = start + incl - c;
-            if (w2 == 15) base[which] = start + incl;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int which = 0; which < 2; ++which)
-            if (mine[which]) list[which * ntile + wave_cnt[it & 1][which][wave] + rank[which]] = t;
     }
     __syncthreads();
     if (tid < 2) lv.tilecount[2 * p + tid] = base[tid];
