@@ -176,7 +176,8 @@ class HotPath:
 
     def algorithmic_bytes(self, scen):
         """SURVEY.md 8(d) per particle-scan, with the build's real storage: packed uint32 cell
-        (both counts) => 4 B per map cell read, 8 B per updated cell; float32 field; float64 cube."""
+        (both counts) => 8 B per updated cell, 1 bit per map cell read by the field build; uint32 fixed-point field;
+        float64 cube."""
         lid, out = self.lidar, {}
         for name, lv in (("coarse", self.coarse), ("fine", self.fine)):
             if lv is None:

@@ -167,8 +167,8 @@ typedef struct {
     Slam2dPartial* partials; /* [P][npartial] per-wave reductions of the cube (sweep -> select) */
     int32_t npartial;        /* capacity per particle: ntheta * ceil(ny*nx / 64) */
     int32_t tmax;            /* ceil(fmax / 16): 16x16-cell tiles per field edge */
-    uint8_t* tilemask;       /* [P][tmax][tmax] 1 = tile holds an occupied field cell (must follow occ
-                                contiguously: both are cleared by one memset) */
+    uint8_t* tilemask;       /* [P][tmax][tmax] tile holds an occupied field cell (stamped like occ; must follow occ
+                                contiguously: one memset clears both when occ_gen == 0) */
     uint8_t* tilestate;      /* [P][tmax][tmax] PERSISTENT across calls: 0 = the field tile already holds
                                 the free-space constant (no rewrite needed), 1 = dirty/unknown.
                                 Initialise to 1; set to 1 whenever the field buffer is written by

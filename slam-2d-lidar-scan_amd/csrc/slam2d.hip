@@ -686,7 +686,8 @@ __device__ __forceinline__ void write_priors(const Slam2dLevel& lv, const int p,
 
 // ------------------------------------------------------------------------------------
 // K1a  beam endpoints -> unique field cells per theta   (Utils/ScanMatcher_OGBased.py:81-89,
-//      117-121,162-176).  One block per (theta, particle); bitonic sort + compaction in LDS.
+//      117-121,162-176).  One block per (theta, particle); np.unique through an LDS hash set, ordered
+//      compaction; plus one block per particle for the motion priors.
 //      A cell is stored as the offset of the corner of its (2*ncell+1)^2 patch:
 //      (cy - ncell) * fpitch + (cx - ncell).
 // ------------------------------------------------------------------------------------
@@ -810,13 +811,12 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
 // K1c  pose-cube sweep                              (Utils/ScanMatcher_OGBased.py:116-132)
 //      score[theta][dy][dx] = sum_k field[cy_k + dy][cx_k + dx] + rv + thetaWeight
 //
-//      One WAVE scores 64*R consecutive poses of one (particle, theta): lanes run along
-//      the flattened (dy, dx) plane, so every gather of a wave is a few contiguous row
-//      segments of the float32 field.  The unique-cell list is wave-uniform: it is
-//      read with scalar loads and the field is read through a buffer resource as
-//      (per-lane constant VGPR offset) + (scalar cell offset).  float32 field
-//      values are accumulated in float64 (sums of <= 2048 float32 values are then
-//      exact to ~1e-13, so argmax ties in the reference stay ties here).
+//      One BLOCK scores 64*RQ slots of 4 consecutive dx of one (particle, theta): lanes run along the
+//      flattened (dy, dx/4) plane, so every gather of a wave is a few contiguous row segments of the
+//      fixed-point uint32 field; its 4 waves split the unique-cell list.  The list is wave-uniform: it is
+//      read with scalar loads and the field through a buffer resource as (per-lane constant VGPR offset) +
+//      (scalar cell offset), 16 bytes per lane.  Costs are summed exactly in 64-bit integers (as lo / hi
+//      halves), so the sum does not depend on the order and argmax ties in the reference stay ties here.
 //      Blocks of one particle are pinned to one XCD (block b runs on XCD b % 8) so that
 //      particle's field stays in that XCD's 4 MiB L2 while its cube is swept.
 // ------------------------------------------------------------------------------------
