@@ -851,6 +851,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // the same field rows at the same time -- one L1 working set per block (measured 124 -> 117 us; the
 // gathers run at L1 delivery rate, bypassing L1 costs 1.6x) -- and their exact integer partial sums
 // meet in LDS.
+#define SWEEP_REST_CHUNKS 4
 template <int RQ, int mode>
 __global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks, int bpp) {
     // mode 0: the whole cube.  mode 1 (RQ = 1): only the slots of the prior's ring (lv.ring).  mode 2: the
@@ -864,21 +865,25 @@ __global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks
     if (mode == 1 && lv.prune_state[p] != 0) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const int w = slot % bpp;                              // (theta, chunk) of this block
-    const int it = w / chunks, ch = w - it * chunks;
+    // modes 0 / 1: one block per (theta, chunk).  mode 2: one block per (theta, SWEEP_REST_CHUNKS chunks), so that
+    // the launch -- empty for every settled particle -- is a quarter of the blocks
+    const int w = slot % bpp;
+    const int groups = (chunks + SWEEP_REST_CHUNKS - 1) / SWEEP_REST_CHUNKS;
+    const int it = mode == 2 ? w / groups : w / chunks;
     const int nx = 2 * lv.ncell + 1, npose = nx * nx;
     const int nq = (nx + 3) >> 2, nslot = nx * nq;
     const uint32_t* __restrict__ F = lv.field + (size_t)p * lv.fmax * lv.fpitch;
     const int* __restrict__ cl = lv.cells + ((size_t)p * lv.ntheta + it) * lv.kmax;
     const int K = lv.kcount[p * lv.ntheta + it];
     const int nring = mode == 1 ? lv.ring[0] : 0;
-    if (mode == 1 && ch * WAVE >= nring) return;           // also nring = -1: the ring did not fit
-    const int u0 = ch * (WAVE * RQ) + lane;
+    if (mode == 1 && (w - it * chunks) * WAVE >= nring) return;     // also nring = -1: the ring did not fit
     // Buffer addressing (SRSRC): address = field base + per-lane VGPR byte offset (constant
     // over k) + wave-uniform SGPR byte offset (the cell) -- no vector address arithmetic in
     // the loop, and out-of-range offsets read 0 instead of faulting.
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)F, (short)0, (int)((size_t)lv.fmax * lv.fpitch * sizeof(uint32_t)), 0x00020000);
+    auto sweep_chunk = [&](const int ch) {
+    const int u0 = ch * (WAVE * RQ) + lane;
     int off[RQ], q0[RQ], nv[RQ];          // byte offset, first pose index, valid poses (0..4) of each slot
     unsigned lo[RQ][4], hi[RQ][4];        // exact 64-bit integer sums as 32-bit halves
 #pragma unroll
@@ -916,6 +921,7 @@ __global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks
     }
     __syncthreads();
     if (wave > 0) return;
+    {
 #pragma unroll
     for (int r = 0; r < RQ; ++r)
 #pragma unroll
@@ -956,7 +962,18 @@ __global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks
     if (lane == 0) {
         Slam2dPartial pt;
         pt.max = me.v; pt.sumexp = ex; pt.argmax = me.i; pt.has_nan = me.nan;
-        lv.partials[(size_t)p * lv.npartial + w] = pt;
+        lv.partials[(size_t)p * lv.npartial + it * chunks + ch] = pt;
+    }
+    }
+    };
+    if constexpr (mode == 2) {
+        const int c0 = (w - it * groups) * SWEEP_REST_CHUNKS;
+        for (int ch = c0; ch < min(chunks, c0 + SWEEP_REST_CHUNKS); ++ch) {
+            sweep_chunk(ch);
+            __syncthreads();                               // part_s is reused by the next chunk
+        }
+    } else {
+        sweep_chunk(w - it * chunks);
     }
 }
 
@@ -1394,7 +1411,7 @@ __global__ void k_fill(uint32_t* cells, long long n, uint32_t value) {
 // ------------------------------------------------------------------------------------
 template <int R>
 static void launch_sweep(const Slam2dLevel& lv, int P, int chunks, hipStream_t s, int mode = 0) {
-    const int bpp = lv.ntheta * chunks;                 // blocks per particle: one per (theta, chunk)
+    const int bpp = mode == 2 ? lv.ntheta * cdiv(chunks, SWEEP_REST_CHUNKS) : lv.ntheta * chunks;       // blocks per particle
     const unsigned grid = cdiv(P, 8) * 8 * bpp;
     if (mode == 0) k_sweep<R, 0><<<grid, 256, 0, s>>>(lv, P, chunks, bpp);
     else if (mode == 2) k_sweep<R, 2><<<grid, 256, 0, s>>>(lv, P, chunks, bpp);
