@@ -700,7 +700,7 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
     // integer sums, so the order of the list cannot change a result.
     // mark != 0 (slam2d_match): the block also ORs the 16x16 field tiles its patches touch into
     // lv.tileneed, through an LDS bitmap, so that the field build can skip every other tile.
-    extern __shared__ __attribute__((aligned(16))) int ep_lds[];     // [2n] keys, [2n] owners, [8] wave counts, [nneed] tiles
+    extern __shared__ __attribute__((aligned(16))) int ep_lds[];     // [hsize] keys, [hsize] owners, [8] wave counts, [nneed] tiles
     const int it = blockIdx.x, p = blockIdx.y, tid = threadIdx.x;
     if (it == lv.ntheta) {                                 // the extra block of every particle: motion priors (+ ring)
         write_priors(lv, p, est_dist, psi_cs, prune);
@@ -711,7 +711,9 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
     const int B = lid.beams;
     int n = 256;
     while (n < B) n <<= 1;
-    const int hsize = 2 * n, hmask = hsize - 1;
+    int hsize = 512;                                       // power of two >= 1.5 * beams (load factor <= 2/3)
+    while (hsize < B + (B >> 1)) hsize <<= 1;
+    const int hmask = hsize - 1;
     int* hkey = ep_lds;
     int* hown = ep_lds + hsize;
     int* cnt_s = ep_lds + 2 * hsize;
@@ -1481,12 +1483,14 @@ static void launch_field(const Slam2dLevel& lv, const Slam2dMap* d_maps, int P, 
         const dim3 bgrid(min(ntile, blur_blocks), P);
         switch (lv.blur_radius) {
             case 2: k_blur_clamp<2><<<bgrid, BLUR_THREADS, 0, s>>>(lv); break;
+            case 4: k_blur_clamp<4><<<bgrid, BLUR_THREADS, 0, s>>>(lv); break;
             case 8: k_blur_clamp<8><<<bgrid, BLUR_THREADS, 0, s>>>(lv); break;
             default: k_blur_clamp<0><<<bgrid, BLUR_THREADS, 0, s>>>(lv); break;
         }
     }
     switch (lv.blur_radius) {
         case 2: k_blur_check_redo<2><<<P, 256, 0, s>>>(lv, d_flags); break;
+        case 4: k_blur_check_redo<4><<<P, 256, 0, s>>>(lv, d_flags); break;
         case 8: k_blur_check_redo<8><<<P, 256, 0, s>>>(lv, d_flags); break;
         default: k_blur_check_redo<0><<<P, 256, 0, s>>>(lv, d_flags); break;
     }
@@ -1499,7 +1503,9 @@ static void launch_endpoints(const Slam2dLidar& lid, const Slam2dLevel& lv, int 
     StageScope prof(SLAM2D_STAGE_ENDPOINTS, s);
     int n = 256;
     while (n < lid.beams) n <<= 1;
-    const size_t ep_lds = (size_t)(4 * n + 8 + (mark ? (lv.tmax * lv.tmax + 31) / 32 : 0)) * sizeof(int);
+    int hsize = 512;
+    while (hsize < lid.beams + (lid.beams >> 1)) hsize <<= 1;
+    const size_t ep_lds = (size_t)(2 * hsize + 8 + (mark ? (lv.tmax * lv.tmax + 31) / 32 : 0)) * sizeof(int);
     k_endpoints<<<dim3(lv.ntheta + 1, P), 256, ep_lds, s>>>(lid, lv, d_est, est_stride, d_ranges, d_flags, est_moving_dist,
                                                         lv.fine ? nullptr : d_psi_cs, mark ? 1 : 0, prune ? 1 : 0);
 }

@@ -717,11 +717,11 @@ def test_fault_flags_instead_of_out_of_bounds(pkg):
     assert maps[0][1].sum() > 2.0 * v.size
 
 
-@pytest.mark.parametrize("sigma", [1.3, 3.0, 0.2])
+@pytest.mark.parametrize("sigma", [1.3, 3.0, 0.2, 1.0])
 def test_generic_blur_radius(pkg, sigma):
-    """Blur radii other than the two specialised ones (2 and 8) take the generic kernel path
-    (sigma 1.3 -> radius 5, 3.0 -> 12, 0.2 -> 1): quantised field and probMin still bit-exact,
-    and the match on it agrees with the oracle."""
+    """Blur radii other than the reference's two (2 and 8): the generic kernel path (sigma 1.3 -> radius 5,
+    3.0 -> 12, 0.2 -> 1) and the radius-4 specialisation (sigma 1.0, BASELINE config 5's coarse level):
+    quantised field and probMin still bit-exact, and the match on it agrees with the oracle."""
     synth = importlib.import_module("slam-2d-lidar-scan_amd.synth")
     unit, R, size_m, beams = 0.1, 8.0, 30, 120
     world = synth.make_world(size_m, unit, seed=5, n_boxes=20)
