@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define SLAM2D_ABI_VERSION 3
+#define SLAM2D_ABI_VERSION 4
 #define SLAM2D_SPOKE_BAND 16         /* radial band width of the beam-major spoke table, in cells */
 
 /* library error codes (negative; positive values are hipError_t) */
@@ -182,6 +182,8 @@ typedef struct {
                                 operation order; used when blur_radius is 2 or 8 */
     uint32_t* tileneed;      /* [P][ceil(tmax*tmax/32)] scratch of slam2d_match: bit t set = the sweep reads
                                 field tile t (may be NULL when only slam2d_field_build is used) */
+    unsigned long long* freerow; /* [P][64] scratch (used when tmax <= 64): bit tx of word ty = field tile (ty, tx)
+                                holds the free-space constant; lets the sweep skip loads.  NULL disables */
     int32_t* ring;           /* [1 + ring_cap] scratch of SLAM2D_MATCH_PRUNE_BY_PRIOR: length, then the ascending
                                 sweep slots (4 consecutive dx of one dy) that hold a pose inside the prior's ring;
                                 NULL disables the option */
