@@ -35,8 +35,9 @@ for k, d in sorted(agg.items()):
     hit, miss = mean.get("TCC_HIT_sum", 0.0), mean.get("TCC_MISS_sum", 0.0)
     name = k.split("<")[0]
     targs = k[k.index("<") + 1:k.rindex(">")].replace(" ", "").split(",") if "<" in k else []
-    if name in ("k_sweep", "k_select") and targs and targs[-1] != "0":
-        name += {"1": "_ring", "2": "_rest"}.get(targs[-1], "_" + targs[-1])     # passes of the prior-pruned variant
+    mode = (targs[1] if name == "k_sweep" and len(targs) > 1 else targs[0] if name == "k_select" and targs else "0")
+    if mode != "0":
+        name += {"1": "_ring", "2": "_rest"}.get(mode, "_" + mode)             # passes of the prior-pruned variant
     traffic[f"config2:{name}"] = {"fetch_bytes_raw": fetch, "write_bytes_raw": write,
                                   "hbm_bytes_corrected": 2 * fetch + write,
                                   "l2_hit_rate": hit / (hit + miss) if hit + miss else None,
