@@ -177,9 +177,6 @@ typedef struct {
     double*  tilemax;        /* [P][tmax][tmax] scratch: per-tile maximum of the field as stored */
     int32_t* tilelist;       /* [P][2][tmax*tmax] scratch: work lists (tiles to blur, tiles to fill) */
     int32_t* tilecount;      /* [P][2] scratch: their lengths */
-    const double* vtable;    /* NULL, or [2^(2*blur_radius+1)] axis-0 blur result of every binary column
-                                window (bit k set = window row k occupied), filled with the kernel's
-                                operation order; used when blur_radius is 2 or 8 */
     uint32_t* tileneed;      /* [P][ceil(tmax*tmax/32)] scratch of slam2d_match: bit t set = the sweep reads
                                 field tile t (may be NULL when only slam2d_field_build is used) */
     unsigned long long* freerow; /* [P][64] scratch (used when tmax <= 64): bit tx of word ty = field tile (ty, tx)

@@ -85,7 +85,7 @@ class Slam2dLevel(C.Structure):
                 ("cells", _vp), ("kcount", _vp), ("prior", _vp), ("cube", _vp),
                 ("partials", _vp), ("npartial", C.c_int32), ("tmax", C.c_int32), ("tilemask", _vp),
                 ("tilestate", _vp), ("tilemin", _vp), ("tilemax", _vp),
-                ("tilelist", _vp), ("tilecount", _vp), ("vtable", _vp), ("tileneed", _vp), ("freerow", _vp),
+                ("tilelist", _vp), ("tilecount", _vp), ("tileneed", _vp), ("freerow", _vp),
                 ("ring", _vp), ("prune_state", _vp), ("ring_cap", C.c_int32), ("occ_gen", C.c_int32)]
 
 

@@ -78,22 +78,6 @@ def blurred_free_value(log_miss, taps, radius):
     return float(one_pass(one_pass(L)))
 
 
-USE_COLUMN_TABLE = False
-
-
-def column_pass_table(log_miss, taps, radius):
-    """Axis-0 blur result of every binary column window: entry `pat` has bit k set when
-    window row k is occupied.  Same operation order as the kernel / SciPy's symmetric
-    correlate1d (out = a[c]*w[c]; for j=-r..-1: out += (a[c+j] + a[c-j]) * w[j])."""
-    n = 2 * radius + 1
-    pat = np.arange(1 << n, dtype=np.uint32)
-    f = np.where(((pat[:, None] >> np.arange(n, dtype=np.uint32)[None, :]) & 1) == 1, 0.0, np.float64(log_miss))
-    acc = f[:, radius] * taps[radius]
-    for j in range(-radius, 0):
-        acc = acc + (f[:, radius + j] + f[:, radius - j]) * taps[radius + j]
-    return np.ascontiguousarray(acc)
-
-
 def cost_scale_for(min_value):
     """2^k with -min_value * 2^k < 2^32 (k <= 31): the fixed-point scale of a search field
     whose values lie in [min_value, 0] (include/slam2d.h, "Search field format")."""
@@ -403,10 +387,6 @@ class SearchLevel:
             freerow=torch.zeros((P, 64), dtype=torch.int64, device=device),
             ring=torch.zeros(1 + self.nx * ((self.nx + 3) // 4), dtype=i32, device=device),
             prune_state=torch.zeros(P, dtype=i32, device=device),
-            # optional table-driven axis-0 pass; measured slower than the arithmetic on MI355X
-            # (178 vs 164 us at config 2: the kernel is latency-, not ALU-bound), so off by default
-            vtable=(_dev(column_pass_table(self.log_miss, self.taps, self.blur_radius), device)
-                    if (USE_COLUMN_TABLE and self.blur_radius in (2, 8)) else None),
         )
         self.c = Slam2dLevel(
             step=step, reach=self.reach, log_miss=self.log_miss, floor_value=self.floor_value,
@@ -420,7 +400,7 @@ class SearchLevel:
             cube=t["cube"].data_ptr(), partials=t["partials"].data_ptr(), npartial=self.npartial, tmax=self.tmax,
             tilemask=t["occ"].data_ptr() + P * self.fmax * self.fpitch, tilestate=t["tilestate"].data_ptr(),
             tilemin=t["tilemin"].data_ptr(), tilemax=t["tilemax"].data_ptr(), tilelist=t["tilelist"].data_ptr(),
-            tilecount=t["tilecount"].data_ptr(), vtable=t["vtable"].data_ptr() if t["vtable"] is not None else None,
+            tilecount=t["tilecount"].data_ptr(),
             tileneed=t["tileneed"].data_ptr(), freerow=t["freerow"].data_ptr(), ring=t["ring"].data_ptr(), prune_state=t["prune_state"].data_ptr(),
             ring_cap=self.nx * ((self.nx + 3) // 4))
 
