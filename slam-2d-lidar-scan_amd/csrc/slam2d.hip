@@ -1029,8 +1029,17 @@ __global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks
     const double* __restrict__ pr = lv.prior + (size_t)p * 2 * npose;
     double* __restrict__ out = lv.cube + ((size_t)p * lv.ntheta + it) * npose;
     const double inv = 1.0 / lv.cost_scale;
-    double sc[RQ][4];
+    double sc[RQ][4], prv[RQ][4], ptw[RQ][4];
     Best me{-INFINITY, INT_MAX, 0};
+    // both prior planes of the lane's poses in one batch of loads (one round trip, not eight)
+#pragma unroll
+    for (int r = 0; r < RQ; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int q = min(q0[r] + e, npose - 1);
+            prv[r][e] = pr[q];
+            ptw[r][e] = pr[npose + q];
+        }
 #pragma unroll
     for (int r = 0; r < RQ; ++r)
 #pragma unroll
@@ -1040,7 +1049,7 @@ __global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks
                 const int q = q0[r] + e;
                 const unsigned long long acc = ((unsigned long long)hi[r][e] << 32) | lo[r][e];
                 const double sum = -((double)acc * inv);                           // sum of probSP values
-                sc[r][e] = (sum + pr[q]) + pr[npose + q];                          // :131
+                sc[r][e] = (sum + prv[r][e]) + ptw[r][e];                          // :131
                 out[q] = sc[r][e];
                 Best cand{sc[r][e], it * npose + q, isnan(sc[r][e]) ? 1 : 0};
                 if (better(cand, me)) me = cand;
