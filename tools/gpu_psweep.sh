@@ -1,5 +1,5 @@
 for P in 8 16 32 64 128 256 512; do
- timeout 300 python bench.py --particles $P --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
+ timeout 300 python bench.py --particles $P --steps 20 --warmup 3 --no-cpu-baseline --no-variants 2>/dev/null | python -c "
 import sys, json
 for line in sys.stdin:
     if line.startswith('{'):
