@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define SLAM2D_ABI_VERSION 5
+#define SLAM2D_ABI_VERSION 6
 #define SLAM2D_SPOKE_BAND 16         /* radial band width of the beam-major spoke table, in cells */
 
 /* library error codes (negative; positive values are hipError_t) */
@@ -103,6 +103,8 @@ typedef struct {
     const double*   spoke_r;     /* [W*W] radius of that cell */
     int32_t num_bands;           /* floor(max r / unit) / SLAM2D_SPOKE_BAND + 1 */
     int32_t _pad;
+    double lut_xs_step;          /* 2*max_range/(W-1) when lut_xs[j] == j*lut_xs_step - max_range bit for bit
+                                    (last element max_range), as numpy.linspace computes it; 0: use lut_xs */
 } Slam2dLidar;
 
 /* Geometry of one particle's search field at one level, written by

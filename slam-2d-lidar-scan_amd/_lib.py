@@ -58,7 +58,8 @@ class Slam2dLidar(C.Structure):
     _fields_ = [("unit", C.c_double), ("max_range", C.c_double), ("fov", C.c_double), ("wall_half", C.c_double),
                 ("beams", C.c_int32), ("num_spokes", C.c_int32), ("spoke_start", C.c_int32), ("lut_w", C.c_int32),
                 ("lut_xs", _vp),
-                ("spoke_band", _vp), ("spoke_cells", _vp), ("spoke_r", _vp), ("num_bands", C.c_int32), ("_pad", C.c_int32)]
+                ("spoke_band", _vp), ("spoke_cells", _vp), ("spoke_r", _vp), ("num_bands", C.c_int32), ("_pad", C.c_int32),
+                ("lut_xs_step", C.c_double)]
 
 
 class Slam2dFrame(C.Structure):

@@ -1308,10 +1308,21 @@ __global__ __launch_bounds__(256) void k_grid_update(Slam2dLidar lid, const Slam
                 r[u] = sr[k];
                 cell[u] = sc[k];
             }
+            // window coordinate of a column / row: np.linspace(-R, R, W)[j] = j * step + (-R), last element R
+            // (lut_xs_step, checked against the table by the host), else the table itself
+            if (lid.lut_xs_step != 0.0) {
 #pragma unroll
-            for (int u = 0; u < UPDB_UNROLL; ++u) {
-                xj[u] = lid.lut_xs[cell[u] & 0xffffu];
-                yi[u] = lid.lut_xs[cell[u] >> 16];
+                for (int u = 0; u < UPDB_UNROLL; ++u) {
+                    const int cj = (int)(cell[u] & 0xffffu), ci = (int)(cell[u] >> 16);
+                    xj[u] = cj == W - 1 ? lid.max_range : (double)cj * lid.lut_xs_step + -lid.max_range;
+                    yi[u] = ci == W - 1 ? lid.max_range : (double)ci * lid.lut_xs_step + -lid.max_range;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < UPDB_UNROLL; ++u) {
+                    xj[u] = lid.lut_xs[cell[u] & 0xffffu];
+                    yi[u] = lid.lut_xs[cell[u] >> 16];
+                }
             }
             bool slow = false;
 #pragma unroll

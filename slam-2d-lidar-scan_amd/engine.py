@@ -140,6 +140,17 @@ class LidarModel:
         r = np.sqrt(x ** 2 + y ** 2)
         return bins.astype(np.uint16), np.ascontiguousarray(r)
 
+    def xs_step(self):
+        """Step of the window coordinates if np.linspace's arithmetic (j * step + start, last element = stop)
+        reproduces them bit for bit -- the update kernel then computes them instead of gathering; else 0."""
+        W, R = self.width, float(self.max_range)
+        if W < 2:
+            return 0.0
+        step = (R - (-R)) / (W - 1)
+        y = np.arange(W, dtype=np.float64) * step + (-R)
+        y[-1] = R
+        return float(step) if np.array_equal(y, self.xs) else 0.0
+
     def spoke_lists(self):
         """itemizeSpokesGrid (:47-57) beam-major for the update kernel: the cells of a spoke ordered by
         radial band (SPOKE_BAND values of floor(r / unit)) and row-major inside a band.  Returns
@@ -170,7 +181,7 @@ class LidarModel:
                             wall_half=self.wall_thickness / 2, beams=self.beams, num_spokes=self.num_spokes,
                             spoke_start=self.spoke_start, lut_w=self.width, lut_xs=t["xs"].data_ptr(),
                             spoke_band=t["sptr"].data_ptr(), spoke_cells=t["scells"].data_ptr(),
-                            spoke_r=t["sr"].data_ptr(), num_bands=nb)
+                            spoke_r=t["sr"].data_ptr(), num_bands=nb, lut_xs_step=self.xs_step())
             self._dev[key] = (s, t)
         return self._dev[key][0]
 
