@@ -1572,7 +1572,7 @@ static int check_level(const Slam2dLidar* lidar, const Slam2dLevel* lv, int P) {
     if (lidar->beams < 2 || lidar->beams > SLAM2D_MAX_BEAMS) return SLAM2D_E_TOOLARGE;
     if (lv->fmax <= 0 || lv->fpitch < lv->fmax || lv->wmax <= 0 || lv->ncell < 0 || lv->ntheta <= 0) return SLAM2D_E_BADARG;
     if (!(lv->cost_scale > 0.0)) return SLAM2D_E_BADARG;
-    if ((long long)lv->fmax * lv->fpitch >= (1ll << 31)) return SLAM2D_E_TOOLARGE;
+    if ((long long)lv->fmax * lv->fpitch >= (1ll << 29)) return SLAM2D_E_TOOLARGE;     // byte offsets into one field stay below 2^31
     return 0;
 }
 
