@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define SLAM2D_ABI_VERSION 6
+#define SLAM2D_ABI_VERSION 7
 #define SLAM2D_SPOKE_BAND 16         /* radial band width of the beam-major spoke table, in cells */
 
 /* library error codes (negative; positive values are hipError_t) */
@@ -290,9 +290,11 @@ int slam2d_prior(const double* d_prev_pose, double raw_theta, double prev_raw_th
  *   d_fine / d_coarse        Slam2dMatch[P] of the fine / coarse level
  *   d_prev_pose[P][3]        in: previous matched pose, out: this scan's matched pose
  *   d_heading[P]             out: prevMatchedMovingTheta (NaN when the pose did not move)
- *   d_logw[P]                in/out */
+ *   d_logw[P]                in/out
+ *   d_report[P][5]           out (may be NULL): matched x, y, theta, coarse confidence, log of it -- the one
+ *                            buffer a caller needs to download per scan */
 int slam2d_post_match(const Slam2dMatch* d_fine, const Slam2dMatch* d_coarse, int32_t P, double* d_prev_pose,
-                      double* d_heading, double* d_logw, void* stream);
+                      double* d_heading, double* d_logw, double* d_report, void* stream);
 
 /* Particle.update's `weight *= confidence` in the log domain followed by
  * ParticleFilter.normalizeWeights / weightUnbalanced (Algorithm/FastSlam.py:30-48,135).

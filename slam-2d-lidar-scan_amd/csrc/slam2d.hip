@@ -1492,7 +1492,7 @@ __global__ void k_prior(const double* __restrict__ prev, double raw_theta, doubl
 }
 
 __global__ void k_post_match(const Slam2dMatch* __restrict__ fine, const Slam2dMatch* __restrict__ coarse, int P,
-                             double* prev, double* heading, double* logw) {
+                             double* prev, double* heading, double* logw, double* report) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     const double x = fine[p].x, y = fine[p].y;
@@ -1503,6 +1503,10 @@ __global__ void k_post_match(const Slam2dMatch* __restrict__ fine, const Slam2dM
     heading[p] = h;
     prev[3 * p] = x; prev[3 * p + 1] = y; prev[3 * p + 2] = fine[p].theta;          // :134
     logw[p] += coarse[p].log_confidence;                                            // :135
+    if (report) {                                      // what the caller downloads once per scan
+        report[5 * p] = x; report[5 * p + 1] = y; report[5 * p + 2] = fine[p].theta;
+        report[5 * p + 3] = coarse[p].confidence; report[5 * p + 4] = coarse[p].log_confidence;       // :79 (coarse)
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1774,9 +1778,9 @@ int slam2d_prior(const double* d_prev_pose, double raw_theta, double prev_raw_th
 }
 
 int slam2d_post_match(const Slam2dMatch* d_fine, const Slam2dMatch* d_coarse, int32_t P, double* d_prev_pose,
-                      double* d_heading, double* d_logw, void* stream) {
+                      double* d_heading, double* d_logw, double* d_report, void* stream) {
     if (!d_fine || !d_coarse || !d_prev_pose || !d_heading || !d_logw || P <= 0) return SLAM2D_E_BADARG;
-    k_post_match<<<cdiv(P, 64), 64, 0, (hipStream_t)stream>>>(d_fine, d_coarse, P, d_prev_pose, d_heading, d_logw);
+    k_post_match<<<cdiv(P, 64), 64, 0, (hipStream_t)stream>>>(d_fine, d_coarse, P, d_prev_pose, d_heading, d_logw, d_report);
     return launch_status();
 }
 

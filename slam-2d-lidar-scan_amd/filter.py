@@ -214,12 +214,11 @@ class ParticleFilter:
                 self._grow_for_windows(c["x"], c["y"], self.fine.reach)
             self._match(self.fine, self.m_coarse, MATCH_DOUBLES, dist, None, None, self.m_fine)
             _lib.check(L.slam2d_post_match(_ptr(self.m_fine), _ptr(self.m_coarse), P, _ptr(self.d_pose),
-                                           _ptr(self.d_head), _ptr(self.d_logw), _stream()), "slam2d_post_match")
+                                           _ptr(self.d_head), _ptr(self.d_logw), _ptr(self.d_report), _stream()),
+                       "slam2d_post_match")
             eng.grid_update(self.d_pose, 3, self.d_ranges)          # :133 (the update window lies inside the
             #                                                         search window that was grown for)
-            self.d_report[:, 0:3] = self.d_pose
-            self.d_report[:, 3:5] = self.m_coarse[:, 3:5]           # confidence, log-confidence
-            self._h_report.copy_(self.d_report, non_blocking=True)
+            self._h_report.copy_(self.d_report, non_blocking=True)  # x, y, theta, confidence, log-confidence
             eng.take_flags()                                        # the one synchronisation of the scan
             rep = self._h_report.numpy()
             matched, conf = rep[:, 0:3].copy(), rep[:, 3].copy()
