@@ -170,6 +170,46 @@ class LidarModel:
         cells = ((order // W).astype(np.uint32) << np.uint32(16)) | (order % W).astype(np.uint32)
         return band_ptr, cells, np.ascontiguousarray(flat_r[order]), nb
 
+    # -- host mirror of the per-beam walk (Utils/OccupancyGrid.py:133-147), used only where the reference
+    #    grows the map INSIDE an update (first scan of a small map) and by the update=False variant --
+    def _spoke_lists_host(self):
+        if not hasattr(self, "_spoke_ptr"):
+            flat = self.bin.ravel().astype(np.int64)
+            self._spoke_cells = np.argsort(flat, kind="stable")
+            self._spoke_ptr = np.concatenate(([0], np.cumsum(np.bincount(flat, minlength=self.num_spokes))))
+        return self._spoke_cells, self._spoke_ptr
+
+    def beam_cells(self, theta, rng):
+        """Per beam: (beam index, flat LUT cells of its spoke, empty mask, occupied mask), reference order."""
+        cells, ptr = self._spoke_lists_host()
+        S = self.num_spokes
+        offset = int(np.rint(theta / (2 * np.pi) * S))                        # :131
+        r_flat = self.r.ravel()
+        half_w = self.wall_thickness / 2
+        for i in range(self.beams):
+            spoke = int(np.rint((self.spoke_start + offset + i) % S))         # :134
+            c = cells[ptr[spoke]:ptr[spoke + 1]]
+            rs = r_flat[c]
+            empty = rs < rng[i] - half_w if rng[i] < self.max_range else np.zeros(rs.shape, dtype=bool)   # :138-141
+            occ = (rs > rng[i] - half_w) & (rs < rng[i] + half_w)             # :142-143
+            yield i, c, empty, occ
+
+    def grow_for_update(self, m, x, y, theta, rng):
+        """Per-beam growth of MapState ``m`` exactly in the reference's order (:147).  Returns the
+        [beams, 2] int32 low-side shifts that make k_grid_update reproduce the reference's stale-index
+        writes (:144-152), or None if nothing grew."""
+        W, xs = self.width, self.xs
+        shifts = np.zeros((self.beams, 2), dtype=np.int32)
+        grew = False
+        for i, c, _, occ in self.beam_cells(theta, rng):
+            if not occ.any():
+                continue
+            dc, dr = m.ensure_contains(x + xs[c[occ] % W], y + xs[c[occ] // W], self.unit)
+            if dc or dr:
+                shifts[i] = (dc, dr)
+                grew = True
+        return shifts if grew else None
+
     def on(self, device):
         """Device copies + the C struct (kept alive with the tensors)."""
         key = str(device)

@@ -105,6 +105,10 @@ class ParticleFilter:
             self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
             if parallel.shard_range(self.total_particles, self.world, self.rank) != (first_index, numParticles):
                 raise ValueError("first_index / numParticles do not match parallel.shard_range for this rank")
+            if rng is None:
+                # every rank must draw the same uniforms and resample indices: an unseeded per-process stream
+                # would give inconsistent send / receive plans (deadlock or silent divergence)
+                raise ValueError("a sharded ParticleFilter needs rng=np.random.RandomState(seed), the same seed on every rank")
         self.lidar = LidarModel.get(unit, max_range, fov, beams, wall)
         maps = [MapState.create(mapX, mapY, initXY, unit, self.device) for _ in range(numParticles)]
         self.engine = ParticleEngine(self.lidar, maps, self.device)
@@ -194,9 +198,8 @@ class ParticleFilter:
             self.d_head.fill_(float("nan"))
             matched = np.tile([reading['x'], reading['y'], reading['theta']], (P, 1)).astype(np.float64)
             conf = np.ones(P)
-            if self.growable:
-                self._grow_for_update(matched)
-            eng.grid_update(self.d_pose, 3, self.d_ranges)          # :133
+            d_shift = self._grow_for_first_update(reading) if self.growable else None
+            eng.grid_update(self.d_pose, 3, self.d_ranges, d_shift)          # :133
             eng.take_flags()
         else:
             dist, raw_heading, has_turn, turn = self._raw_odometry(reading)
@@ -269,13 +272,27 @@ class ParticleFilter:
         coarse result is, and the mid-scan synchronisation can be skipped."""
         return self._outside(est[:, 0], est[:, 1], self.coarse.reach + margin).size == 0
 
-    def _grow_for_update(self, matched):
-        """The update window (pose +/- R) lies inside the search window that was grown for
-        (estimate +/- (1.1 R + searchRadius)), except on the first scan of a small map."""
-        if self._outside(matched[:, 0], matched[:, 1], self.lidar.max_range).size:
-            raise _lib.Slam2dError("the first scan's lidar window leaves the initial map: pre-size the map "
-                                   "(the per-beam growth of Utils/OccupancyGrid.py:147 is only reproduced by "
-                                   "the single-particle OccupancyGrid class)")
+    def _grow_for_first_update(self, reading):
+        """The first scan's update may leave a small initial map; the reference then grows the map beam by
+        beam INSIDE the update and writes with stale indices (Utils/OccupancyGrid.py:144-152).  Every
+        particle has the same pose and the same map at that point, so the growth sequence and the per-beam
+        index shifts are computed once (LidarModel.grow_for_update) and replayed on the other maps.
+        Returns the [P, beams, 2] shift tensor for slam2d_grid_update, or None."""
+        x, y, R = reading['x'], reading['y'], self.lidar.max_range
+        maps = self.engine.maps
+        m0 = maps[0]
+        if not (x - R < m0.lim_x[0] or x + R > m0.lim_x[1] or y - R < m0.lim_y[0] or y + R > m0.lim_y[1]):
+            return None
+        n0 = len(m0.growth_log)
+        shifts = self.lidar.grow_for_update(m0, x, y, reading['theta'], np.asarray(reading['range'], dtype=np.float64))
+        for m in maps[1:]:
+            for side, _ in m0.growth_log[n0:]:
+                m._grow(side, self.lidar.unit)
+        if len(m0.growth_log) != n0:
+            self.engine.refresh_maps()
+        if shifts is None:
+            return None
+        return self.engine.to_device(np.repeat(shifts[None], self.numParticles, axis=0), dtype=np.int32)
 
     def _match(self, level, d_est, stride, dist, d_psi, d_uniform, d_out):
         """One level of matchScan for all particles.  lazy_field: blur only the field tiles the sweep reads
@@ -288,27 +305,51 @@ class ParticleFilter:
             eng.sweep(level, d_est, stride, self.d_ranges, dist, d_psi, d_uniform, d_out)
 
     # ---- weights (Algorithm/FastSlam.py:30-48) ----
+    # The reference's resample trigger (:37) sits at total degeneracy: variance > ((N-1)/N)^2 + (N-1-1e-15)/N^2,
+    # i.e. within ~1e-15 of the largest value sum (w - 1/N)^2 can take.  A variance more than this far below
+    # that maximum cannot trigger, whatever the rounding of the reference's sequential sum:
+    _DEGENERACY_BAND = 1e-9
+
     def normalizeWeights(self):
-        """weights <- weights / sum (:43-48) in the log domain.  Sharded: one all-gather of every rank's
-        three partial sums (parallel.ShardedNormalizer), then an all-gather of the N weights so that
-        every rank evaluates the degeneracy test on identical numbers.  ``self.weights`` holds this
-        rank's particles, ``self.all_weights`` all N."""
+        """weights <- weights / sum (:43-48) in the log domain.  Sharded: ONE collective per scan -- the
+        all-gather of every rank's three partial sums (parallel.ShardedNormalizer), which yields the
+        normalised weights of this rank's particles and sum (w - 1/N)^2 over all N, identical on every rank.
+        The N weights themselves are gathered only when the filter is within _DEGENERACY_BAND of total
+        degeneracy (the only place the reference's trigger can fire) or when a resample needs them.
+        ``self.weights`` holds this rank's particles; ``self.all_weights`` all N (None until gathered)."""
         n = self.total_particles
         if self.sharded:
             if self._normalizer is None:
                 self._normalizer = parallel.ShardedNormalizer(_lib.lib(), _lib.check, self.device, n, self.group)
             self._normalizer(self.d_logw, None, 1, self.d_w, self.d_stats)
-            self.all_weights = parallel.gather_weights(self.d_w, n, self.world, self.group).cpu().numpy()
-            self.weights = self.all_weights[self.first_index:self.first_index + self.numParticles].copy()
+            self.weights = self.d_w.cpu().numpy()
+            self.all_weights = None
+            self.last_variance = float(self.d_stats[0].item())       # sum w^2 - 1/N, same bits on every rank
+            if self.last_variance >= (n - 1) / n - self._DEGENERACY_BAND:
+                self._gather_all_weights()
         else:
             L = _lib.lib()
             _lib.check(L.slam2d_weights_normalize(_ptr(self.d_logw), None, 1, self.numParticles, _ptr(self.d_w),
                                                   _ptr(self.d_stats), _stream()), "slam2d_weights_normalize")
             self.weights = self.d_w.cpu().numpy()
             self.all_weights = self.weights
-        # sum (w_i - 1/N)^2 in the reference's sequential order (:32-35): its resample trigger sits at
-        # total degeneracy, where the outcome is decided by the rounding of this very sum
+            self._sequential_variance()
+        if np.isnan(self.weights).any():
+            # the reference fails loudly here: np.random.choice raises on NaN probabilities (a NaN cube entry,
+            # e.g. the arccos argument of the heading prior rounding above 1, ScanMatcher_OGBased.py:107,138)
+            raise _lib.Slam2dError("a particle weight is NaN (NaN confidence from the scan matcher)")
+
+    def _sequential_variance(self):
+        # sum (w_i - 1/N)^2 in the reference's sequential order (:32-35): at total degeneracy the outcome of
+        # its trigger is decided by the rounding of this very sum
+        n = self.total_particles
         self.last_variance = float(np.cumsum((self.all_weights - 1 / n) ** 2)[-1])
+
+    def _gather_all_weights(self):
+        """All N normalised weights on every rank (second collective; near-degeneracy and resampling only)."""
+        if self.all_weights is None:
+            self.all_weights = parallel.gather_weights(self.d_w, self.total_particles, self.world, self.group).cpu().numpy()
+            self._sequential_variance()
 
     def weightUnbalanced(self):
         self.normalizeWeights()
@@ -318,9 +359,11 @@ class ParticleFilter:
     # ---- resample (Algorithm/FastSlam.py:50-62) ----
     def resample(self):
         """np.random.choice(N, N, p=weights) (:59) on every rank from the shared seeded stream, then the
-        state movement: local clones, and -- sharded -- point-to-point transfers of the maps that change
-        rank (parallel.migrate)."""
+        state movement: local clones, and -- sharded -- point-to-point transfers of the particles that change
+        rank (parallel.migrate_ragged)."""
         n = self.total_particles
+        if self.sharded:
+            self._gather_all_weights()
         src = self.rng if self.rng is not None else np.random
         idx = src.choice(np.arange(n), n, p=self.all_weights)                            # :59
         self.apply_resample(idx)
@@ -364,27 +407,27 @@ class ParticleFilter:
             self.prev_matched = self.prev_matched[local].copy()
             self.trajectory = [t[local].copy() for t in self.trajectory]
         else:
-            shape = (maps[0].rows, maps[0].cols)
-            if any((m.rows, m.cols) != shape or m.lim_x != maps[0].lim_x or m.lim_y != maps[0].lim_y for m in maps):
-                raise _lib.Slam2dError("sharded resample needs maps of one extent on a rank (pre-size the maps)")
+            # every particle travels whole: count map + (coordinate vectors, growth log, pose, heading,
+            # trajectory), whatever extent its map has grown to (parallel.migrate_ragged)
+            head = self.d_head.cpu().numpy()
+            traj = np.stack(self.trajectory, axis=1) if self.trajectory else np.zeros((P, 0, 2))
+            aux = [parallel.pack_particle(m.X, m.Y, m.growth_log, self.prev_matched[i], head[i], traj[i]).to(self.device)
+                   for i, m in enumerate(maps)]
+            cells, aux = parallel.migrate_ragged([m.cells for m in maps], aux, idx, n, self.world, self.rank, self.group)
+            new_maps, poses, heads, trajs = [], [], [], []
+            for c, a in zip(cells, aux):
+                o = parallel.unpack_particle(a)
+                m = MapState(o["X"], o["Y"], self.device, cells=c.contiguous())
+                m.growth_log = o["growth_log"]
+                new_maps.append(m)
+                poses.append(o["pose"]); heads.append(o["heading"]); trajs.append(o["trajectory"])
+            self.engine.maps = new_maps
+            self.prev_matched = np.array(poses).reshape(P, 3)
+            self.d_pose = torch.as_tensor(self.prev_matched, device=self.device).contiguous()
+            self.d_head = torch.as_tensor(np.array(heads, dtype=np.float64), device=self.device)
             T = len(self.trajectory)
-            # one record per particle: pose, heading, trajectory; and its map
-            rec = torch.zeros((P, 4 + 2 * T), dtype=torch.float64, device=self.device)
-            rec[:, 0:3] = self.d_pose
-            rec[:, 3] = self.d_head
-            if T:
-                rec[:, 4:] = torch.as_tensor(np.stack(self.trajectory, axis=1).reshape(P, 2 * T), device=self.device)
-            recs = parallel.migrate([rec[i] for i in range(P)], idx, n, self.world, self.rank, self.group)
-            cells = parallel.migrate([m.cells for m in maps], idx, n, self.world, self.rank, self.group)
-            rec = torch.stack(recs)
-            self.d_pose = rec[:, 0:3].contiguous()
-            self.d_head = rec[:, 3].contiguous()
-            host = rec.cpu().numpy()
-            self.prev_matched = host[:, 0:3].copy()
-            self.trajectory = [host[:, 4 + 2 * t:6 + 2 * t].copy() for t in range(T)]
-            for m, c in zip(maps, cells):
-                m.cells = c
-                m.bits_valid = False
+            tr = np.array(trajs).reshape(P, T, 2)
+            self.trajectory = [tr[:, t].copy() for t in range(T)]
         self.engine.refresh_maps()
         self.weights = np.full(P, 1 / n)                                                 # :62
         self.all_weights = np.full(n, 1 / n)

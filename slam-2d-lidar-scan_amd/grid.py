@@ -101,47 +101,18 @@ class OccupancyGrid:
         return shift
 
     # ---- per-scan update (Utils/OccupancyGrid.py:127-159) ----
-    def _spoke_lists(self):
-        lid = self.lidar
-        if not hasattr(lid, "_spoke_ptr"):
-            flat = lid.bin.ravel().astype(np.int64)
-            lid._spoke_cells = np.argsort(flat, kind="stable")
-            lid._spoke_ptr = np.concatenate(([0], np.cumsum(np.bincount(flat, minlength=lid.num_spokes))))
-        return lid._spoke_cells, lid._spoke_ptr
-
     def _beam_cells(self, theta, rng):
-        """Per beam: (flat LUT cells, empty mask, occupied mask), reference order."""
-        lid = self.lidar
-        cells, ptr = self._spoke_lists()
-        S = lid.num_spokes
-        offset = int(np.rint(theta / (2 * np.pi) * S))
-        r_flat = lid.r.ravel()
-        half_w = self.wallThickness / 2
-        for i in range(self.numSamplesPerRev):
-            spoke = int(np.rint((self.spokesStartIdx + offset + i) % S))
-            c = cells[ptr[spoke]:ptr[spoke + 1]]
-            rs = r_flat[c]
-            empty = rs < rng[i] - half_w if rng[i] < self.lidarMaxRange else np.zeros(rs.shape, dtype=bool)
-            occ = (rs > rng[i] - half_w) & (rs < rng[i] + half_w)
-            yield i, c, empty, occ
+        return self.lidar.beam_cells(theta, rng)
 
     def _grow_for_update(self, x, y, theta, rng):
         """Per-beam growth exactly in the reference's order (:147), returning the
         [beams, 2] low-side shifts that make the kernel reproduce its stale-index
         writes (:144-152), or None if nothing grew."""
-        W = self.lidar.width
-        xs = self.lidar.xs
-        shifts = np.zeros((self.numSamplesPerRev, 2), dtype=np.int32)
-        grew = False
-        for i, c, _, occ in self._beam_cells(theta, rng):
-            if not occ.any():
-                continue
-            ox, oy = x + xs[c[occ] % W], y + xs[c[occ] // W]
-            dc, dr = self.checkAndExapndOG(ox, oy)
-            if dc or dr:
-                shifts[i] = (dc, dr)
-                grew = True
-        return shifts if grew else None
+        before = len(self.map.growth_log)
+        shifts = self.lidar.grow_for_update(self.map, x, y, theta, rng)
+        if len(self.map.growth_log) != before:
+            self.version += 1
+        return shifts
 
     def updateOccupancyGrid(self, reading, dTheta=0, update=True):
         x, y, theta = reading['x'], reading['y'], reading['theta'] + dTheta

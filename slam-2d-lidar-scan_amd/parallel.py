@@ -164,3 +164,89 @@ def migrate(tensors, indices, total, world, rank, group=None):
         new[d] = buf.to(dev)
     assert all(t is not None for t in new)
     return new
+
+
+def _gather_sizes(sizes, total, world, rank, group=None):
+    """[total, k] int64 table of every particle's size record, from this rank's [count, k] rows
+    (one small all-gather, padded to the largest shard)."""
+    counts = [shard_range(total, world, r)[1] for r in range(world)]
+    cap, k = max(counts), sizes.shape[1]
+    mine = torch.zeros((cap, k), dtype=torch.int64)
+    mine[:sizes.shape[0]] = sizes
+    if not dist.is_initialized() or world == 1:
+        return mine[:counts[0]]
+    dev = None
+    if dist.get_backend(group) != "gloo":                   # nccl moves device tensors only
+        dev = torch.device("cuda", torch.cuda.current_device())
+        mine = mine.to(dev)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    return torch.cat([p[:c] for p, c in zip(parts, counts)]).cpu()
+
+
+def migrate_ragged(cells, aux, indices, total, world, rank, group=None):
+    """``migrate`` for particles whose state differs in size: the reference's resample deep-copies whatever
+    shape a particle's map has grown to (Algorithm/FastSlam.py:50-62, Utils/OccupancyGrid.py:59-100).
+
+    cells[i]: 2-D tensor (this rank's particle i's map, any [rows, pitch]); aux[i]: 1-D float64 tensor of any
+    length (coordinate vectors, growth log, pose, trajectory -- whatever else has to travel with the map).
+    Every rank first learns every particle's (rows, pitch, len(aux)) through one small all-gather, so a
+    receiver allocates its landing buffers from the SENDER's shapes; then two point-to-point messages per
+    moved particle (map, aux), issued in ascending destination order on both sides (NCCL matches by order, not
+    by tag).  Returns (new_cells, new_aux) for this rank's slots."""
+    first, count = shard_range(total, world, rank)
+    assert len(cells) == count and len(aux) == count
+    sizes = torch.tensor([[c.shape[0], c.shape[1], a.numel()] for c, a in zip(cells, aux)], dtype=torch.int64).reshape(count, 3)
+    table = _gather_sizes(sizes, total, world, rank, group)
+    local, sends, recvs = resample_plan(indices, total, world, rank)
+    new_cells, new_aux = [None] * count, [None] * count
+    for d, s in local:
+        new_cells[d], new_aux[d] = cells[s].clone(), aux[s].clone()
+    ops, landing = [], []
+    dev = cells[0].device if count else None
+    for dst_rank, s, tag in sends:
+        ops.append(dist.P2POp(dist.isend, _stage(cells[s].contiguous(), group), dst_rank, group=group, tag=2 * tag))
+        ops.append(dist.P2POp(dist.isend, _stage(aux[s].contiguous(), group), dst_rank, group=group, tag=2 * tag + 1))
+    for src_rank, d, tag in recvs:
+        rows, pitch, naux = (int(v) for v in table[int(indices[tag])])
+        like = cells[0] if count else None
+        cbuf = _stage(torch.empty((rows, pitch), dtype=like.dtype, device=like.device), group)
+        abuf = _stage(torch.empty(naux, dtype=torch.float64, device=like.device), group)
+        landing.append((d, cbuf, abuf))
+        ops.append(dist.P2POp(dist.irecv, cbuf, src_rank, group=group, tag=2 * tag))
+        ops.append(dist.P2POp(dist.irecv, abuf, src_rank, group=group, tag=2 * tag + 1))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    for d, cbuf, abuf in landing:
+        new_cells[d], new_aux[d] = cbuf.to(dev), abuf.to(dev)
+    assert all(t is not None for t in new_cells)
+    return new_cells, new_aux
+
+
+def pack_particle(X, Y, growth_log, pose, heading, trajectory):
+    """Everything of one particle except its count map, as one float64 vector (the ``aux`` of
+    ``migrate_ragged``): [cols, rows, len(growth_log), T, pose(3), heading, trajectory (T x 2), X (cols),
+    Y (rows), growth log (n x 2)].  Small integers are exact in float64."""
+    import numpy as np
+    X, Y = np.asarray(X, dtype=np.float64), np.asarray(Y, dtype=np.float64)
+    log = np.asarray(growth_log, dtype=np.float64).reshape(-1, 2)
+    traj = np.asarray(trajectory, dtype=np.float64).reshape(-1, 2)
+    head = np.array([len(X), len(Y), len(log), len(traj)], dtype=np.float64)
+    return torch.from_numpy(np.concatenate((head, np.asarray(pose, dtype=np.float64).reshape(3),
+                                            [float(heading)], traj.ravel(), X, Y, log.ravel())))
+
+
+def unpack_particle(aux):
+    """Inverse of ``pack_particle``: dict(X, Y, growth_log, pose, heading, trajectory) of NumPy values."""
+    a = aux.detach().cpu().numpy()
+    cols, rows, nlog, T = (int(v) for v in a[:4])
+    o = 4
+    pose = a[o:o + 3].copy(); o += 3
+    heading = float(a[o]); o += 1
+    traj = a[o:o + 2 * T].reshape(T, 2).copy(); o += 2 * T
+    X = a[o:o + cols].copy(); o += cols
+    Y = a[o:o + rows].copy(); o += rows
+    log = [(int(s), int(n)) for s, n in a[o:o + 2 * nlog].reshape(nlog, 2)]
+    assert o + 2 * nlog == a.size
+    return dict(X=X, Y=Y, growth_log=log, pose=pose, heading=heading, trajectory=traj)

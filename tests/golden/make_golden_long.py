@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Long closed-loop golden runs of the reference's FastSLAM (development container only:
+needs /root/reference).  Companion of make_golden.py; writes
+
+  flow_fastslam_long.npz    6 particles x 910 scans (the whole Intel log), seed 0, 50 m map
+                            (Algorithm/FastSlam.py:197-207 defaults): the NATURAL
+                            weightUnbalanced() trigger (:37) fires and the maps grow.
+  flow_fastslam_growth.npz  3 particles x 150 scans, seed 1, 10 m initial map: per-beam growth
+                            inside the first update (Utils/OccupancyGrid.py:144-147), heavy
+                            search-window growth, forced resamples between particles whose maps
+                            have grown differently.
+
+    python tests/golden/make_golden_long.py [long|growth|all]
+
+Per scan and particle the fixtures hold the uniform consumed by the soft-max draw, the matched
+pose, the raw and the normalised weight, the variance / unbalanced decision, the resample
+draws, every change of a particle's map shape, and the SHA-256 + limits of the final maps.
+Data only -- no reference source text.
+"""
+import hashlib
+import io
+import sys
+import time
+
+import numpy as np
+
+import make_golden as mg       # imports the reference (sys.path set up there)
+
+ref_fs = mg.ref_fs
+codec = mg.codec
+
+
+def run(name, readings, n_particles, n_scans, seed, map_m, force_resample=()):
+    u = 0.02
+    ogP = [map_m, map_m, readings[0], u, np.pi, 10, 180, 5 * u]      # Algorithm/FastSlam.py:204 order
+    smP = list(mg.REF_DEFAULT_SM)
+    np.random.seed(seed)
+    with mg.quiet():
+        pf = ref_fs.ParticleFilter(n_particles, ogP, smP)
+    W, V, M, C, U, RS, UNB, SHAPES = [], [], [], [], [], [], [], []
+    last_shape = [None] * n_particles
+    t = time.time()
+    for count, raw in enumerate(readings[:n_scans], start=1):
+        us = []
+        for p in pf.particles:
+            st = np.random.get_state()
+            with mg.quiet():
+                p.update(raw, count)
+            probe = np.random.RandomState(); probe.set_state(st)
+            now = np.random.get_state()
+            changed = now[2] != st[2] or not np.array_equal(now[1], st[1])
+            us.append(probe.random_sample() if changed else np.nan)
+        C.append([p.weight for p in pf.particles])        # pre-normalisation weights
+        with mg.quiet():
+            unb = pf.weightUnbalanced()
+        n = pf.numParticles
+        V.append(sum((p.weight - 1 / n) ** 2 for p in pf.particles))
+        W.append([p.weight for p in pf.particles])
+        M.append([[p.prevMatchedReading["x"], p.prevMatchedReading["y"], p.prevMatchedReading["theta"]]
+                  for p in pf.particles])
+        U.append(us); UNB.append(unb)
+        for i, p in enumerate(pf.particles):             # shape after this scan's update, before a resample
+            sh = p.og.occupancyGridVisited.shape
+            if sh != last_shape[i]:
+                SHAPES.append([count, i, sh[0], sh[1]])
+                last_shape[i] = sh
+        if unb or count in force_resample:
+            st = np.random.get_state()
+            with mg.quiet():
+                pf.resample()
+            probe = np.random.RandomState(); probe.set_state(st)
+            draw = probe.choice(np.arange(n), n, p=np.array(W[-1]))
+            RS.append(np.concatenate(([count], draw)))
+            last_shape = [last_shape[j] for j in draw]
+        if count % 50 == 0:
+            print(f"    {name}: scan {count}/{n_scans}, {time.time() - t:.0f} s, resamples {[int(r[0]) for r in RS]}",
+                  flush=True)
+    print(f"  reference FastSLAM {n_particles} x {n_scans}: {time.time() - t:.1f} s")
+    maps_sha = [np.frombuffer(hashlib.sha256(codec.pack_counts(
+        p.og.occupancyGridVisited, p.og.occupancyGridTotal).tobytes()).digest(), dtype=np.uint8)
+        for p in pf.particles]
+    lims = [[p.og.mapXLim[0], p.og.mapXLim[1], p.og.mapYLim[0], p.og.mapYLim[1]] for p in pf.particles]
+    shapes = [list(p.og.occupancyGridVisited.shape) for p in pf.particles]
+    mg.save(name, weights=np.array(W, dtype=np.float64), raw_weights=np.array(C, dtype=np.float64),
+            variance=np.array(V), matched=np.array(M), uniforms=np.array(U), unbalanced=np.array(UNB),
+            resamples=np.array(RS).reshape(-1, n_particles + 1).astype(np.int64),
+            cfg=np.array([n_particles, n_scans, seed, map_m]),
+            force_resample=np.array(force_resample, dtype=np.int64), maps_sha=np.array(maps_sha),
+            final_lims=np.array(lims), final_shapes=np.array(shapes), shape_events=np.array(SHAPES, dtype=np.int64))
+
+
+def main():
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    readings = mg.load_intel()
+    if what in ("growth", "all"):
+        run("flow_fastslam_growth.npz", readings, 3, 150, 1, 10, force_resample=(30, 75, 120))
+    if what in ("long", "all"):
+        run("flow_fastslam_long.npz", readings, 6, len(readings), 0, 50)
+
+
+if __name__ == "__main__":
+    main()

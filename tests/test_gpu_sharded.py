@@ -1,7 +1,9 @@
 """The sharded particle filter end to end on one GPU box: two ranks (gloo; they share cuda:0, so the
-collectives hop through host memory) each own 2 of the 4 particles of the golden FastSLAM run and must
-reproduce it -- matched poses, weights, variance, resample draws and the maps that migrated between
-ranks at the two resamples."""
+collectives hop through host memory) split the particles of a golden FastSLAM run of the reference and must
+reproduce it -- matched poses, weights, variance, resample draws and the maps that migrated between ranks
+at the resamples.  Two runs: 4 particles on pre-sized maps (2 + 2), and the 3-particle run from a 10 m map
+(2 + 1: ragged shards, maps that grow differently on the two ranks, resamples that move maps of different
+extents across ranks -- parallel.migrate_ragged)."""
 import hashlib
 import importlib
 import os
@@ -22,7 +24,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n_scans, out_dir):
+def _worker(rank, world, port, golden, n_scans, out_dir):
     import torch.distributed as dist
     here = os.path.dirname(os.path.abspath(__file__))
     for pth in (os.path.dirname(here), os.path.join(here, "golden")):
@@ -34,7 +36,7 @@ def _worker(rank, world, port, n_scans, out_dir):
     try:
         pkg = importlib.import_module("slam-2d-lidar-scan_amd")
         par = importlib.import_module("slam-2d-lidar-scan_amd.parallel")
-        z = np.load(os.path.join(here, "golden", "flow_fastslam.npz"))
+        z = np.load(os.path.join(here, "golden", golden))
         zi = np.load(os.path.join(here, "golden", "intel_gfs.npz"))
         rng_cm = zi["range_cm"].astype(np.float64) / 100.0
         readings = [{"x": float(p[0]), "y": float(p[1]), "theta": float(p[2]), "range": r} for p, r in zip(zi["pose"], rng_cm)]
@@ -44,27 +46,37 @@ def _worker(rank, world, port, n_scans, out_dir):
         ogP = [map_m, map_m, readings[0], u, np.pi, 10, 180, 5 * u]
         pf = pkg.ParticleFilter(count, ogP, list(REF_SM), rng=np.random.RandomState(seed), total_particles=n_particles,
                                 first_index=first)
-        resamples, ok = [], True
+        resamples, why = [], []
+
+        def expect(cond, what):
+            if not cond and len(why) < 5:
+                why.append(what)
         for c, raw in enumerate(readings[:n_scans], start=1):
             pf.updateParticles(raw, c)
             unb = pf.weightUnbalanced()
-            ok &= unb == bool(z["unbalanced"][c - 1])
-            ok &= bool(np.allclose(pf.all_weights, z["weights"][c - 1], rtol=1e-5, atol=0))
-            ok &= bool(np.isclose(pf.last_variance, z["variance"][c - 1], rtol=1e-5, atol=1e-12))
-            ok &= bool(np.array_equal(pf.prev_matched, z["matched"][c - 1][first:first + count]))
+            expect(unb == bool(z["unbalanced"][c - 1]), f"scan {c}: unbalanced {unb}")
+            expect(np.allclose(pf.weights, z["weights"][c - 1][first:first + count], rtol=1e-5, atol=1e-290), f"scan {c}: weights")
+            expect(np.isclose(pf.last_variance, z["variance"][c - 1], rtol=1e-5, atol=1e-12), f"scan {c}: variance {pf.last_variance}")
+            expect(np.array_equal(pf.prev_matched, z["matched"][c - 1][first:first + count]), f"scan {c}: matched poses")
             if unb or c in z["force_resample"]:
                 resamples.append(np.concatenate(([c], pf.resample())))
-        shas = [hashlib.sha256(codec.pack_counts(*m.download()).tobytes()).digest() for m in pf.engine.maps]
-        ok &= all(s == z["maps_sha"][first + i].tobytes() for i, s in enumerate(shas)) if n_scans == int(z["cfg"][1]) else True
-        ok &= bool(np.array_equal(np.array(resamples), z["resamples"][[r[0] <= n_scans for r in z["resamples"]]]))
-        open(os.path.join(out_dir, f"ok{rank}"), "w").write(str(bool(ok)))
+        if n_scans == int(z["cfg"][1]):
+            shas = [hashlib.sha256(codec.pack_counts(*m.download()).tobytes()).digest() for m in pf.engine.maps]
+            expect(all(s == z["maps_sha"][first + i].tobytes() for i, s in enumerate(shas)), "final maps")
+            if "final_lims" in z.files:
+                lims = [[m.lim_x[0], m.lim_x[1], m.lim_y[0], m.lim_y[1]] for m in pf.engine.maps]
+                expect(np.array_equal(np.array(lims), z["final_lims"][first:first + count]), "final map limits")
+        want = z["resamples"][[r[0] <= n_scans for r in z["resamples"]]]
+        expect(np.array_equal(np.array(resamples).reshape(-1, n_particles + 1), want), f"resample draws {resamples}")
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("True" if not why else "; ".join(why))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_filter_reproduces_the_golden_run(tmp_path):
+@pytest.mark.parametrize("golden,n_scans", [("flow_fastslam.npz", 40), ("flow_fastslam_growth.npz", 150)])
+def test_two_rank_filter_reproduces_the_golden_run(tmp_path, golden, n_scans):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import torch.multiprocessing as mp
-    mp.spawn(_worker, args=(2, _free_port(), 40, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), golden, n_scans, str(tmp_path)), nprocs=2, join=True)
     assert [open(os.path.join(str(tmp_path), f"ok{r}")).read() for r in range(2)] == ["True", "True"]

@@ -3,6 +3,7 @@
 reference's arithmetic is restated operation for operation; <= 1e-12 is never
 needed because the restatement keeps the reference's summation order."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -166,6 +167,62 @@ def test_fastslam_flow_exact(intel_readings):
         if unb or count in z["force_resample"]:
             resamples.append(np.concatenate(([count], pf.resample())))
     assert np.array_equal(np.array(resamples), z["resamples"])
+    for p, sha in zip(pf.particles, z["maps_sha"]):
+        assert hashlib.sha256(codec.pack_counts(p.og.visited, p.og.total).tobytes()).digest() == sha.tobytes()
+
+
+def _oracle_fastslam_against(z, readings, n_scans):
+    """ParticleFilterOracle replaying a golden FastSLAM run: raw / normalised weights, variance, the
+    unbalanced decision, matched poses, resample draws and every change of a map's shape, all exact."""
+    n_particles, _, seed, map_m = (int(v) for v in z["cfg"])
+    u = 0.02
+    ogP = [map_m, map_m, readings[0], u, np.pi, 10, 180, 5 * u]
+    rng = np.random.RandomState(seed)
+    pf = so.ParticleFilterOracle(n_particles, ogP, list(REF_SM), rng=rng)
+    resamples, events, last = [], [], [None] * n_particles
+    for count, raw in enumerate(readings[:n_scans], start=1):
+        pf.updateParticles(raw, count)
+        assert np.array_equal(np.array([p.weight for p in pf.particles], dtype=np.float64), z["raw_weights"][count - 1])
+        unb = pf.weightUnbalanced()
+        assert unb == bool(z["unbalanced"][count - 1])
+        assert np.array_equal(np.array([p.weight for p in pf.particles], dtype=np.float64), z["weights"][count - 1])
+        assert pf.last_variance == z["variance"][count - 1]
+        got = np.array([[p.prevMatchedReading[k] for k in ("x", "y", "theta")] for p in pf.particles])
+        assert np.array_equal(got, z["matched"][count - 1]), f"scan {count}"
+        for i, p in enumerate(pf.particles):
+            if p.og.visited.shape != last[i]:
+                last[i] = p.og.visited.shape
+                events.append([count, i, last[i][0], last[i][1]])
+        if unb or count in z["force_resample"]:
+            draw = pf.resample()
+            resamples.append(np.concatenate(([count], draw)))
+            last = [last[j] for j in draw]
+    want_rs = z["resamples"][z["resamples"][:, 0] <= n_scans] if len(z["resamples"]) else z["resamples"]
+    assert np.array_equal(np.array(resamples).reshape(-1, n_particles + 1), want_rs)
+    assert np.array_equal(np.array(events), z["shape_events"][z["shape_events"][:, 0] <= n_scans])
+    return pf
+
+
+def test_fastslam_growth_flow_exact(intel_readings):
+    """3 particles, 10 m initial map (per-beam growth inside the first update, search-window growth,
+    particles whose maps grow differently, a forced resample between them): first 40 scans here (the
+    GPU suite replays all 150; SLAM2D_LONG_ORACLE=1 does so for the oracle too)."""
+    z = load_golden("flow_fastslam_growth.npz")
+    full = os.environ.get("SLAM2D_LONG_ORACLE") == "1"
+    n = int(z["cfg"][1]) if full else 40
+    pf = _oracle_fastslam_against(z, intel_readings, n)
+    if full:
+        for p, sha, lim in zip(pf.particles, z["maps_sha"], z["final_lims"]):
+            assert hashlib.sha256(codec.pack_counts(p.og.visited, p.og.total).tobytes()).digest() == sha.tobytes()
+            assert [p.og.mapXLim[0], p.og.mapXLim[1], p.og.mapYLim[0], p.og.mapYLim[1]] == list(lim)
+
+
+@pytest.mark.skipif(os.environ.get("SLAM2D_LONG_ORACLE") != "1",
+                    reason="~10 min of CPU: the oracle over the reference's whole 6-particle x 910-scan run "
+                           "(set SLAM2D_LONG_ORACLE=1); run once when the fixture or the oracle changes")
+def test_fastslam_long_flow_exact(intel_readings):
+    z = load_golden("flow_fastslam_long.npz")
+    pf = _oracle_fastslam_against(z, intel_readings, int(z["cfg"][1]))
     for p, sha in zip(pf.particles, z["maps_sha"]):
         assert hashlib.sha256(codec.pack_counts(p.og.visited, p.og.total).tobytes()).digest() == sha.tobytes()
 

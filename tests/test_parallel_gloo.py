@@ -63,6 +63,62 @@ def test_sharded_normaliser_and_migration(tmp_path, world, total):
     assert seen == total
 
 
+def _uneven_particle(i, seed):
+    """Particle i of a seeded population whose maps have grown unevenly: its own extent, coordinate vectors
+    (high-side growth compresses the spacing, Utils/OccupancyGrid.py:79-80), growth log, pose, heading, trajectory."""
+    rs = np.random.RandomState(seed * 100003 + i)
+    rows, cols = 6 + int(rs.randint(0, 9)), 5 + int(rs.randint(0, 11))
+    pitch = -(-cols // 16) * 16
+    cells = rs.randint(0, 1 << 30, (rows, pitch)).astype(np.int32)
+    X = np.sort(rs.uniform(-30, 30, cols)); Y = np.sort(rs.uniform(-30, 30, rows))
+    log = [(int(rs.randint(1, 5)), int(rs.randint(1, 600))) for _ in range(int(rs.randint(0, 7)))]
+    pose = rs.uniform(-20, 20, 3)
+    heading = float("nan") if i % 7 == 0 else float(rs.uniform(-3, 3))
+    traj = rs.uniform(-20, 20, (4, 2))
+    return dict(cells=cells, X=X, Y=Y, log=log, pose=pose, heading=heading, traj=traj)
+
+
+def _ragged_worker(rank, world, port, total, seed, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rs = np.random.RandomState(seed)
+        # a near-degenerate weight vector, like the one that triggers the reference's resample: a handful of
+        # survivors are copied all over the node, so most copies cross ranks
+        w = rs.uniform(0, 1, total) ** 40
+        w /= w.sum()
+        idx = rs.choice(total, total, p=w)
+        first, count = par.shard_range(total, world, rank)
+        mine = [_uneven_particle(first + k, seed) for k in range(count)]
+        cells = [torch.from_numpy(m["cells"]) for m in mine]
+        aux = [par.pack_particle(m["X"], m["Y"], m["log"], m["pose"], m["heading"], m["traj"]) for m in mine]
+        new_cells, new_aux = par.migrate_ragged(cells, aux, idx, total, world, rank)
+        ok = True
+        for k, (c, a) in enumerate(zip(new_cells, new_aux)):
+            src = _uneven_particle(int(idx[first + k]), seed)
+            o = par.unpack_particle(a)
+            ok &= np.array_equal(c.numpy(), src["cells"]) and np.array_equal(o["X"], src["X"]) and np.array_equal(o["Y"], src["Y"])
+            ok &= o["growth_log"] == src["log"] and np.array_equal(o["pose"], src["pose"])
+            ok &= np.array_equal(o["trajectory"], src["traj"])
+            ok &= (np.isnan(o["heading"]) and np.isnan(src["heading"])) or o["heading"] == src["heading"]
+        moved = sum(par.owner_of(int(idx[first + k]), total, world) != rank for k in range(count))
+        open(os.path.join(out_dir, f"r{rank}"), "w").write(f"{bool(ok)} {moved}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,total", [(8, 512), (3, 10)])
+def test_ragged_resample_migration(tmp_path, world, total):
+    """BASELINE config 4's resample on CPU: 512 particles on 8 ranks (64 per rank) whose maps have grown
+    unevenly; every destination slot must receive its source particle whole -- map of the SENDER's shape,
+    coordinate vectors, growth log, pose, heading, trajectory (Algorithm/FastSlam.py:50-62 deep-copies
+    whatever a particle holds)."""
+    mp.spawn(_ragged_worker, args=(world, _free_port(), total, 5, str(tmp_path)), nprocs=world, join=True)
+    res = [open(os.path.join(str(tmp_path), f"r{r}")).read().split() for r in range(world)]
+    assert all(r[0] == "True" for r in res), res
+    assert sum(int(r[1]) for r in res) > total // 2          # the plan really moved particles across ranks
+
+
 def test_shard_bookkeeping():
     for total in (1, 7, 64, 513):
         for world in (1, 2, 3, 8):
