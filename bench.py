@@ -184,8 +184,14 @@ class HotPath:
                 continue
             f = int(2 * lv.reach / lv.step) + 1
             wm = int(2 * lv.reach / lid.unit)
+            nbt = (lv.nx + 3) // 4
             out[name] = dict(scatter=wm * wm // 8 + f * f, blur=f * f + 4 * f * f,      # map bits in, occupied image out / in, field out
-                             sweep=4 * f * f + 8 * lid.beams + 8 * lv.ntheta * lv.nx * lv.nx)
+                             sweep=4 * f * f + 8 * lid.beams + 8 * lv.ntheta * lv.nx * lv.nx,
+                             # branch and bound: pooled image (field in, pooled planes out); bounds (pooled planes in,
+                             # cell lists in, one double per pose tile out); surviving tiles (field in, cell lists in,
+                             # one partial per theta out)
+                             pool=8 * f * f, bound=4 * f * f + 4 * lid.beams * lv.ntheta + 8 * lv.ntheta * nbt * 4 * ((nbt + 3) // 4),
+                             exact=4 * f * f + 4 * lid.beams * lv.ntheta + 24 * lv.ntheta, bnb=bool(lv.bnb))
         # update: touched cells of one representative scan (cell-major classification on the host LUT)
         rng = scen.ranges[0]
         S, B = lid.num_spokes, lid.beams
@@ -264,7 +270,7 @@ def main():
     hot = HotPath(cfg, P, scen, device)
 
     stages = [E._lib.STAGE_SWEEP, E._lib.STAGE_BLUR, E._lib.STAGE_SCATTER, E._lib.STAGE_UPDATE,
-              E._lib.STAGE_SELECT, E._lib.STAGE_ENDPOINTS]
+              E._lib.STAGE_SELECT, E._lib.STAGE_ENDPOINTS, E._lib.STAGE_POOL, E._lib.STAGE_BOUND, E._lib.STAGE_EXACT]
 
     def collect():
         out = {}
@@ -338,9 +344,13 @@ def main():
         ab = hot.algorithmic_bytes(scen)
         # dominant kernel = largest measured total time over the timed region
         dom = max(stage_ms, key=lambda k: stage_ms[k]["total_ms"])
-        per_unit = {"k_sweep": sum(v["sweep"] for k, v in ab.items() if k != "update"),
-                    "k_blur_clamp": sum(v["blur"] for k, v in ab.items() if k != "update"),
-                    "k_occ_scatter": sum(v["scatter"] for k, v in ab.items() if k != "update"),
+        lev = {k: v for k, v in ab.items() if k != "update"}
+        per_unit = {"k_sweep": sum(v["sweep"] for v in lev.values() if not v["bnb"]),
+                    "k_blur_clamp": sum(v["blur"] for v in lev.values()),
+                    "k_occ_scatter": sum(v["scatter"] for v in lev.values()),
+                    "k_pool": sum(v["pool"] for v in lev.values() if v["bnb"]),
+                    "k_bound": sum(v["bound"] for v in lev.values() if v["bnb"]),
+                    "k_exact": sum(v["exact"] for v in lev.values() if v["bnb"]),
                     "k_grid_update": ab["update"]["per_particle"]}
         launches_per_step = stage_ms[dom]["launches"] / K
         bytes_per_launch = per_unit.get(dom, 0) * P / launches_per_step

@@ -139,7 +139,8 @@ __global__ void k_frame_axis(Slam2dLidar lid, Slam2dLevel lv, const Slam2dMap* _
     const Slam2dFrame fr = make_frame(lid, lv, m, centre[(size_t)p * cstride], centre[(size_t)p * cstride + 1], f);
     if (j == 0 && axis == 0) {
         lv.frames[p] = fr;
-        lv.tilecount[2 * p] = 0; lv.tilecount[2 * p + 1] = 0;
+        for (int i = 0; i < 4; ++i) lv.tilecount[4 * p + i] = 0;
+        if (lv.bnb) lv.bnb_best[p] = order_bits(-INFINITY);
         if (f) atomicOr(&flags[p], f);
     }
     const int n = axis == 0 ? fr.mx1 - fr.mx0 : fr.my1 - fr.my0;
@@ -473,67 +474,87 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
 // ONE tile of the frame is free (every cell of such a tile equals the floor and no blurred value is
 // below it).  A frame without any free tile falls back to the full build.
 #define TRIAGE_THREADS 1024
+// Branch and bound (lv.bnb): the triage also lists the tiles of the POOLED image (4x4 min-pooled cost, k_pool).
+// Pooled tile t reads field tiles t, t+(0,1), t+(1,0), t+(1,1); it differs from the free-space constant only if one
+// of those holds a wall nearby, i.e. an occupied cell in tile rows ty-1..ty+2, columns tx-1..tx+2.  Lists 2 / 3:
+// pooled tiles to compute / to fill with the constant (lv.poolstate remembers the constant ones across scans).
 __global__ __launch_bounds__(TRIAGE_THREADS) void k_tile_triage(Slam2dLevel lv, int lazy) {
     // tile flags, tile states and the needed-tile bitmap of the particle are staged in LDS with one batch
     // of coalesced loads; everything after that runs out of LDS (the kernel is pure latency otherwise)
-    extern __shared__ __attribute__((aligned(16))) uint8_t tri_lds[];     // [ntile4] flags, [ntile4] states, [nneed] words
-    __shared__ int base[2];
+    extern __shared__ __attribute__((aligned(16))) uint8_t tri_lds[];     // [ntile4] flags, [ntile4] states, [ntile4] pool states, [nneed] words
+    __shared__ int base[4];
     const int p = blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const Slam2dFrame fr = lv.frames[p];
     const int nty = (fr.fh + BLUR_TILE - 1) >> BLUR_SHIFT, ntx = (fr.fw + BLUR_TILE - 1) >> BLUR_SHIFT;
     const int ntile = lv.tmax * lv.tmax, ntile4 = (ntile + 3) & ~3, nneed = (ntile + 31) >> 5;
     const int iters = (ntile + TRIAGE_THREADS - 1) / TRIAGE_THREADS;          // <= 32 (checked by the host)
+    const bool bnb = lv.bnb != 0;
     uint8_t* tiles_s = tri_lds;
     uint8_t* state_s = tri_lds + ntile4;
-    uint32_t* need_s = reinterpret_cast<uint32_t*>(tri_lds + 2 * ntile4);
+    uint8_t* pstate_s = tri_lds + 2 * ntile4;                                // only with bnb
+    uint32_t* need_s = reinterpret_cast<uint32_t*>(tri_lds + (bnb ? 3 : 2) * ntile4);
     const uint8_t stamp = occ_stamp(lv);
     uint8_t* state = lv.tilestate + (size_t)p * ntile;
+    uint8_t* pstate = bnb ? lv.poolstate + (size_t)p * ntile : nullptr;
     {
         const uint8_t* tiles = lv.tilemask + (size_t)p * ntile;
-        for (int t = tid; t < ntile; t += TRIAGE_THREADS) { tiles_s[t] = tiles[t] == stamp; state_s[t] = state[t]; }
+        for (int t = tid; t < ntile; t += TRIAGE_THREADS) {
+            tiles_s[t] = tiles[t] == stamp; state_s[t] = state[t];
+            if (bnb) pstate_s[t] = pstate[t];
+        }
         if (lazy) for (int w = tid; w < nneed; w += TRIAGE_THREADS) need_s[w] = lv.tileneed[(size_t)p * nneed + w];
     }
-    if (tid < 2) base[tid] = 0;
+    if (tid < 4) base[tid] = 0;
     __syncthreads();
-    uint32_t liveb = 0u, anyb = 0u;
+    uint32_t liveb = 0u, anyb = 0u, panyb = 0u;
     int has_free = 0;
     for (int it = 0; it < iters; ++it) {
         const int t = it * TRIAGE_THREADS + tid;
         const int ty = t / lv.tmax, tx = t - ty * lv.tmax;
         if (t < ntile && ty < nty && tx < ntx) {
-            int any = 0;
+            int any = 0, pany = 0;
 #pragma unroll
-            for (int dy = -1; dy <= 1; ++dy)
+            for (int dy = -1; dy <= 2; ++dy)
 #pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
+                for (int dx = -1; dx <= 2; ++dx) {
                     const int yy = ty + dy, xx = tx + dx;
-                    if (yy >= 0 && yy < nty && xx >= 0 && xx < ntx) any |= tiles_s[yy * lv.tmax + xx];
+                    if (yy >= 0 && yy < nty && xx >= 0 && xx < ntx) {
+                        const int o = tiles_s[yy * lv.tmax + xx];
+                        pany |= o;
+                        if (dy <= 1 && dx <= 1) any |= o;
+                    }
                 }
             liveb |= 1u << it;
             if (any) anyb |= 1u << it; else has_free = 1;
+            if (pany) panyb |= 1u << it;
         }
     }
     has_free = __syncthreads_or(has_free);
     // one free tile pins the field minimum (:43) to the analytic floor: k_blur_check_redo has nothing to do
     if (tid == 0) lv.frames[p].min_known = has_free;
     const bool everything = !lazy || !has_free;
-    int* list = lv.tilelist + (size_t)p * 2 * ntile;
+    int* list = lv.tilelist + (size_t)p * 4 * ntile;
     // list positions from LDS counters (one aggregated atomic per wave and list): the order of a list does not
     // matter -- every tile is blurred / filled independently -- and the loop needs no barrier
     const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
     for (int it = 0; it < iters; ++it) {
         const int t = it * TRIAGE_THREADS + tid;
-        const bool live = (liveb >> it) & 1u, any = (anyb >> it) & 1u;
+        const bool live = (liveb >> it) & 1u, any = (anyb >> it) & 1u, pany = (panyb >> it) & 1u;
         const bool wanted = live && (everything || ((need_s[t >> 5] >> (t & 31)) & 1u));
-        bool to_fill = false;
+        bool to_fill = false, p_fill = false;
         if (live && !any) {
             lv.tilemin[(size_t)p * ntile + t] = lv.floor_value;
             if (wanted && state_s[t] != 0) { to_fill = true; state[t] = 0; }
         }
-        const bool mine[2] = {wanted && any, to_fill};
+        if (bnb && wanted) {
+            if (pany) pstate[t] = 1;
+            else if (pstate_s[t] != 0) { p_fill = true; pstate[t] = 0; }      // (pstate_s is read only under bnb)
+        }
+        const bool mine[4] = {wanted && any, to_fill, bnb && wanted && pany, p_fill};
 #pragma unroll
-        for (int which = 0; which < 2; ++which) {
+        for (int which = 0; which < 4; ++which) {
+            if (which >= 2 && !bnb) break;
             const unsigned long long mask = __ballot(mine[which]);
             if (!mask) continue;
             int start = 0;
@@ -543,19 +564,93 @@ __global__ __launch_bounds__(TRIAGE_THREADS) void k_tile_triage(Slam2dLevel lv, 
         }
     }
     __syncthreads();
-    if (tid < 2) lv.tilecount[2 * p + tid] = base[tid];
+    if (tid < 4) lv.tilecount[4 * p + tid] = base[tid];
     // fill: one wave per tile, 64 lanes x 16 bytes = the tile's 256 cells (the whole tile, also beyond the
     // current frame, so that the tile stays valid when the frame grows by its +-1 jitter)
-    const int nfill = base[1];
     const double v = lv.floor_value;
     const uint32_t c = v > 0.5 * v ? 0u : (uint32_t)rint(-v * lv.cost_scale);
     uint32_t* field = lv.field + (size_t)p * lv.fmax * lv.fpitch;
-    for (int b = wave; b < nfill; b += TRIAGE_THREADS / 64) {
+    for (int b = wave; b < base[1]; b += TRIAGE_THREADS / 64) {
         const int t = list[ntile + b];
         const int ty0 = (t / lv.tmax) * BLUR_TILE, tx0 = (t % lv.tmax) * BLUR_TILE;
         const int y = lane >> 2, x = (lane & 3) * 4;
         if (ty0 + y < lv.fmax && tx0 + x + 3 < lv.fpitch)
             *reinterpret_cast<uint4*>(field + (size_t)(ty0 + y) * lv.fpitch + tx0 + x) = make_uint4(c, c, c, c);
+    }
+    if (!bnb) return;
+    // pooled image: lane = (row y, x-phase ph) writes elements 4*tx .. 4*tx+3 of plane ph
+    const int ppitch = lv.fpitch >> 2;
+    uint32_t* pool = lv.pool + (size_t)p * lv.fmax * lv.fpitch;
+    for (int b = wave; b < base[3]; b += TRIAGE_THREADS / 64) {
+        const int t = list[3 * ntile + b];
+        const int ty0 = (t / lv.tmax) * BLUR_TILE, tx = t % lv.tmax;
+        const int y = lane >> 2, ph = lane & 3;
+        if (ty0 + y < lv.fmax && 4 * tx + 3 < ppitch)
+            *reinterpret_cast<uint4*>(pool + ((size_t)ph * lv.fmax + ty0 + y) * ppitch + 4 * tx) = make_uint4(c, c, c, c);
+    }
+}
+
+// 4x4 min-pooled cost image for the branch and bound (lv.pool): one wave per listed tile; the 19 x 19 cost
+// window (the tile + 3 cells to the right / below, clamped to the buffer: duplicates only loosen a minimum) goes
+// through LDS, separable minimum (4 columns, then 4 rows).  The values were written by k_blur_clamp / the
+// triage a moment ago and come out of L2.
+#define POOL_W (BLUR_TILE + 3)
+__global__ __launch_bounds__(64) void k_pool(Slam2dLevel lv) {
+    __shared__ uint32_t win[POOL_W][POOL_W + 1];
+    __shared__ uint32_t hm[POOL_W][BLUR_TILE + 1];
+    const int p = blockIdx.y, lane = threadIdx.x;
+    const int ntile = lv.tmax * lv.tmax;
+    const int n = lv.tilecount[4 * p + 2];
+    if ((int)blockIdx.x >= n) return;
+    const int* list = lv.tilelist + (size_t)p * 4 * ntile + 2 * ntile;
+    const uint32_t* __restrict__ field = lv.field + (size_t)p * lv.fmax * lv.fpitch;
+    uint32_t* pool = lv.pool + (size_t)p * lv.fmax * lv.fpitch;
+    const int ppitch = lv.fpitch >> 2;
+    for (int b = blockIdx.x; b < n; b += gridDim.x) {
+        const int t = list[b];
+        const int ty0 = (t / lv.tmax) * BLUR_TILE, tx0 = (t % lv.tmax) * BLUR_TILE;
+        // 19 rows x 5 quads of 4 cells (the last quad clamped element-wise)
+        uint4 q[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = min(lane + 64 * i, POOL_W * 5 - 1);
+            const int r = idx / 5, c4 = idx - r * 5;
+            const int gy = min(ty0 + r, lv.fmax - 1), gx = tx0 + 4 * c4;
+            if (gx + 3 < lv.fpitch) q[i] = *reinterpret_cast<const uint4*>(field + (size_t)gy * lv.fpitch + gx);
+            else {
+                const uint32_t* row = field + (size_t)gy * lv.fpitch;
+                q[i] = make_uint4(row[min(gx, lv.fpitch - 1)], row[min(gx + 1, lv.fpitch - 1)], row[min(gx + 2, lv.fpitch - 1)], row[min(gx + 3, lv.fpitch - 1)]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = lane + 64 * i;
+            if (idx < POOL_W * 5) {
+                const int r = idx / 5, c = (idx - r * 5) * 4;
+                win[r][c] = q[i].x;
+                if (c + 1 < POOL_W) win[r][c + 1] = q[i].y;
+                if (c + 2 < POOL_W) win[r][c + 2] = q[i].z;
+                if (c + 3 < POOL_W) win[r][c + 3] = q[i].w;
+            }
+        }
+        __syncthreads();
+        for (int idx = lane; idx < POOL_W * BLUR_TILE; idx += 64) {
+            const int r = idx >> BLUR_SHIFT, c = idx & (BLUR_TILE - 1);
+            hm[r][c] = min(min(win[r][c], win[r][c + 1]), min(win[r][c + 2], win[r][c + 3]));
+        }
+        __syncthreads();
+        {
+            const int y = lane >> 2, ph = lane & 3;
+            uint32_t o[4];
+#pragma unroll
+            for (int X = 0; X < 4; ++X) {
+                const int c = 4 * X + ph;
+                o[X] = min(min(hm[y][c], hm[y + 1][c]), min(hm[y + 2][c], hm[y + 3][c]));
+            }
+            if (ty0 + y < lv.fmax && (tx0 >> 2) + 3 < ppitch)
+                *reinterpret_cast<uint4*>(pool + ((size_t)ph * lv.fmax + ty0 + y) * ppitch + (tx0 >> 2)) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        __syncthreads();
     }
 }
 
@@ -564,10 +659,10 @@ template <int RAD>
 __global__ __launch_bounds__(BLUR_THREADS) void k_blur_clamp(Slam2dLevel lv) {
     __shared__ BlurLds<RAD> sm;
     const int p = blockIdx.y;
-    const int n = lv.tilecount[2 * p];
+    const int n = lv.tilecount[4 * p];
     if ((int)blockIdx.x >= n) return;
     const Slam2dFrame fr = lv.frames[p];
-    const int* list = lv.tilelist + (size_t)p * 2 * lv.tmax * lv.tmax;
+    const int* list = lv.tilelist + (size_t)p * 4 * lv.tmax * lv.tmax;
     for (int b = blockIdx.x; b < n; b += gridDim.x) {
         const int t = list[b];
         blur_tile<RAD>(lv, sm, p, fr, t / lv.tmax, t % lv.tmax, 0, false);
@@ -583,8 +678,8 @@ __global__ __launch_bounds__(256) void k_blur_check_redo(Slam2dLevel lv, uint32_
     const int p = blockIdx.x, tid = threadIdx.x;
     Slam2dFrame fr = lv.frames[p];
     {   // largest value any pose can read: free tiles hold the floor, the blurred ones recorded theirs
-        const int n = lv.tilecount[2 * p];
-        const int* list = lv.tilelist + (size_t)p * 2 * lv.tmax * lv.tmax;
+        const int n = lv.tilecount[4 * p];
+        const int* list = lv.tilelist + (size_t)p * 4 * lv.tmax * lv.tmax;
         double mx = lv.floor_value > 0.5 * lv.floor_value ? 0.0 : lv.floor_value;
         for (int i = tid; i < n; i += 256) mx = fmax(mx, lv.tilemax[(size_t)p * lv.tmax * lv.tmax + list[i]]);
         for (int o = 1; o < WAVE; o <<= 1) mx = fmax(mx, __shfl_xor(mx, o));
@@ -670,6 +765,25 @@ __device__ __forceinline__ void write_priors(const Slam2dLevel& lv, const int p,
         }
         out[q] = rv;
         out[np_ + q] = tw;
+    }
+    if (lv.bnb) {
+        // largest rv + thetaWeight of every 4x4 pose tile (+inf when one of them is NaN: np.argmax returns the first
+        // NaN, so such a tile is always scored); padding tiles get -inf
+        __syncthreads();                                   // the planes above were written by this block
+        const int nbt = (nx + 3) >> 2, nbq4 = ((nbt + 3) >> 2) << 2;
+        double* pm = lv.tile_pmax + (size_t)p * nbt * nbq4;
+        for (int t = threadIdx.x; t < nbt * nbq4; t += blockDim.x) {
+            const int by = t / nbq4, bx = t - by * nbq4;
+            double m = -INFINITY;
+            if (bx < nbt)
+                for (int r = 0; r < 4 && 4 * by + r < nx; ++r)
+                    for (int e = 0; e < 4 && 4 * bx + e < nx; ++e) {
+                        const int q = (4 * by + r) * nx + 4 * bx + e;
+                        const double v = out[q] + out[np_ + q];
+                        m = isnan(v) ? INFINITY : fmax(m, v);
+                    }
+            pm[t] = m;
+        }
     }
     if (!prune) return;
     need_full = __syncthreads_or(need_full);
@@ -780,8 +894,10 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
         atomicMin(&hown[h], tid * per + q);
         if (mark) {                                        // tiles of the (2 nc + 1)^2 patch at (x0, y0)
             const int y0 = key[q] / lv.fpitch, x0 = key[q] - y0 * lv.fpitch;
-            const int tx0 = x0 >> BLUR_SHIFT, tx1 = (x0 + 2 * nc) >> BLUR_SHIFT;
-            for (int ty = y0 >> BLUR_SHIFT; ty <= (y0 + 2 * nc) >> BLUR_SHIFT; ++ty)
+            // branch and bound: the last pose tile's 4x4 pooling window reaches up to 3 cells beyond the patch
+            const int span = lv.bnb ? 4 * ((2 * nc + 4) >> 2) - 1 : 2 * nc;
+            const int tx0 = x0 >> BLUR_SHIFT, tx1 = min((x0 + span) >> BLUR_SHIFT, lv.tmax - 1);
+            for (int ty = y0 >> BLUR_SHIFT; ty <= min((y0 + span) >> BLUR_SHIFT, lv.tmax - 1); ++ty)
                 for (int tx = tx0; tx <= tx1;) {           // runs of bits inside one 32-bit word
                     const int bit = ty * lv.tmax + tx;
                     const int len = min(tx1 - tx + 1, 32 - (bit & 31));
@@ -814,9 +930,20 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
     int pos = incl - mine;                                 // ... plus the waves before
     for (int w2 = 1; w2 <= wv; ++w2) pos += cnt_s[w2];
     int* out = lv.cells + ((size_t)p * lv.ntheta + it) * lv.kmax;
+    int* pout = lv.bnb ? lv.pcells + ((size_t)p * lv.ntheta + it) * lv.kmax : nullptr;
+    const int ppitch = lv.fpitch >> 2;
 #pragma unroll
     for (int q = 0; q < SLAM2D_MAX_BEAMS / 256; ++q)
-        if ((keep >> q) & 1) { if (pos < lv.kmax) out[pos] = key[q]; ++pos; }
+        if ((keep >> q) & 1) {
+            if (pos < lv.kmax) {
+                out[pos] = key[q];
+                if (pout) {                                    // the same cell as a byte offset into the pooled planes
+                    const int y0 = key[q] / lv.fpitch, x0 = key[q] - y0 * lv.fpitch;
+                    pout[pos] = (((x0 & 3) * lv.fmax + y0) * ppitch + (x0 >> 2)) * 4;
+                }
+            }
+            ++pos;
+        }
     if (tid == 255) {
         int K = pos;                                       // the last thread ends at the total
         if (K > lv.kmax) { K = lv.kmax; bad = true; }
@@ -1230,6 +1357,342 @@ __global__ __launch_bounds__(64) void k_select(Slam2dLevel lv, int chunks, int R
 }
 
 // ------------------------------------------------------------------------------------
+// K1e  branch and bound over 4x4 pose tiles (include/slam2d.h, "Branch and bound"): the same scores as k_sweep
+//      for every pose that can matter, from 1/16 of the gathers plus the exact scores of a few per cent of the tiles.
+//        k_bound   block = (particle, theta): upper bound U of every tile from the pooled cost planes (lane = one
+//                  pose-tile row x 4 consecutive tiles: one 16-byte load per cell and lane, the 4 waves split the
+//                  cell list); then the tile with the largest U is scored exactly and its best score raises
+//                  lv.bnb_best[p] (atomic max: order-independent, deterministic).
+//        k_exact   block = (particle, theta): every tile with U >= bnb_best - SLAM2D_PRUNE_MARGIN is scored exactly,
+//                  one wave per tile (lane = pose row x 1/16 of the cell list); the block leaves ONE partial
+//                  {max, argmax, sum exp} for its theta.
+//        k_select_bnb  arg-max / soft-max draw / confidence from the per-theta partials; the draw walks theta, then
+//                  pose rows, then the poses of a row -- the cube's C order, as np.random.choice's cdf does.
+// ------------------------------------------------------------------------------------
+struct Running { double m, s; int arg, nan; };
+__device__ __forceinline__ void running_merge(Running& a, const double tm, const double ts, const int targ, const int tnan) {
+    if (a.nan || tnan) {
+        const int arg = (a.nan && tnan) ? min(a.arg, targ) : (tnan ? targ : a.arg);
+        a.nan = 1; a.arg = arg; a.m = NAN; a.s = NAN;
+        return;
+    }
+    if (tm == -INFINITY) return;
+    if (tm > a.m) { a.s = a.s * exp(a.m - tm) + ts; a.m = tm; a.arg = targ; }
+    else { a.s += ts * exp(tm - a.m); if (tm == a.m && targ < a.arg) a.arg = targ; }
+}
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int o) {
+    const unsigned lo = __shfl_xor((unsigned)v, o), hi = __shfl_xor((unsigned)(v >> 32), o);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// exact cost sums of the 16 poses of tile (by, bx): lane = (pose row r = lane / 16, cell slice s = lane % 16) scores
+// the 4 poses (4 by + r, 4 bx .. 4 bx + 3) against cells k0 + s, k0 + s + kstep, ...; on return every lane of a
+// row group holds the row's 4 sums over ALL the cells this wave walked (reduced over the 16 slices).
+#define EXACT_DEPTH 4
+__device__ __forceinline__ void tile_exact(const Slam2dLevel& lv, const __amdgpu_buffer_rsrc_t rsrc, const int* __restrict__ cl,
+                                           const int K, const int by, const int bx, const int k0, const int kstep,
+                                           unsigned long long (&acc)[4]) {
+    const int lane = threadIdx.x & 63, r = lane >> 4, s = lane & 15;
+    const int lanepart = ((4 * by + r) * lv.fpitch + 4 * bx) * 4;
+    unsigned lo[4] = {0u, 0u, 0u, 0u}, hi[4] = {0u, 0u, 0u, 0u};
+    for (int k = k0 + s; k < K; k += EXACT_DEPTH * kstep) {
+        int off[EXACT_DEPTH];
+#pragma unroll
+        for (int i = 0; i < EXACT_DEPTH; ++i) {
+            const int kk = k + i * kstep;
+            off[i] = kk < K ? lanepart + cl[kk] * 4 : 0x7ffffff0;      // beyond the buffer: reads zeros
+        }
+        u32x4 v[EXACT_DEPTH];
+#pragma unroll
+        for (int i = 0; i < EXACT_DEPTH; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i], 0, 0);
+#pragma unroll
+        for (int i = 0; i < EXACT_DEPTH; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned s2 = lo[e] + v[i][e];
+                hi[e] += s2 < v[i][e] ? 1u : 0u;
+                lo[e] = s2;
+            }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        unsigned long long t = ((unsigned long long)hi[e] << 32) | lo[e];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) t += shfl_xor_u64(t, o);
+        acc[e] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bound(Slam2dLevel lv, int P) {
+    __shared__ unsigned long long part_s[3][4][WAVE];
+    __shared__ unsigned long long ex_s[4][16];
+    __shared__ int seed_s;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int p = (slot / lv.ntheta) * 8 + xcd, it = slot % lv.ntheta;
+    if (p >= P) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int nx = 2 * lv.ncell + 1, npose = nx * nx;
+    const int nbt = (nx + 3) >> 2, nq = (nbt + 3) >> 2, nbq4 = nq << 2;
+    const int ppitch = lv.fpitch >> 2;
+    const int K = lv.kcount[p * lv.ntheta + it];
+    const size_t image = (size_t)lv.fmax * lv.fpitch;
+    const int* __restrict__ pcl = lv.pcells + ((size_t)p * lv.ntheta + it) * lv.kmax;
+    const __amdgpu_buffer_rsrc_t rpool = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(lv.pool + (size_t)p * image), (short)0, (int)(image * sizeof(uint32_t)), 0x00020000);
+    const bool active = lane < nbt * nq;
+    const int by = lane / nq, q = lane - by * nq;
+    const int voff = active ? ((4 * by) * ppitch + 4 * q) * 4 : 0x7ffffff0;
+    unsigned lo[4] = {0u, 0u, 0u, 0u}, hi[4] = {0u, 0u, 0u, 0u};
+    int k = wave;
+    for (; k + 12 < K; k += 16) {                          // 4 loads in flight per wave
+        const int c0 = pcl[k], c1 = pcl[k + 4], c2 = pcl[k + 8], c3 = pcl[k + 12];
+        const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rpool, voff, c0, 0);
+        const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rpool, voff, c1, 0);
+        const u32x4 v2 = __builtin_amdgcn_raw_buffer_load_b128(rpool, voff, c2, 0);
+        const u32x4 v3 = __builtin_amdgcn_raw_buffer_load_b128(rpool, voff, c3, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            unsigned s2 = lo[e] + v0[e]; hi[e] += s2 < v0[e] ? 1u : 0u; lo[e] = s2;
+            s2 = lo[e] + v1[e]; hi[e] += s2 < v1[e] ? 1u : 0u; lo[e] = s2;
+            s2 = lo[e] + v2[e]; hi[e] += s2 < v2[e] ? 1u : 0u; lo[e] = s2;
+            s2 = lo[e] + v3[e]; hi[e] += s2 < v3[e] ? 1u : 0u; lo[e] = s2;
+        }
+    }
+    for (; k < K; k += 4) {
+        const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rpool, voff, pcl[k], 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const unsigned s2 = lo[e] + v0[e]; hi[e] += s2 < v0[e] ? 1u : 0u; lo[e] = s2; }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part_s[wave - 1][e][lane] = ((unsigned long long)hi[e] << 32) | lo[e];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const double inv = 1.0 / lv.cost_scale;
+        const double* __restrict__ pm = lv.tile_pmax + (size_t)p * nbt * nbq4;
+        double* __restrict__ bnd = lv.bounds + ((size_t)p * lv.ntheta + it) * nbt * nbq4;
+        Best me{-INFINITY, INT_MAX, 0};
+        if (active) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned long long L = (((unsigned long long)hi[e] << 32) | lo[e]) + part_s[0][e][lane] + part_s[1][e][lane] + part_s[2][e][lane];
+                const int t = by * nbq4 + 4 * q + e;
+                // every pose of the tile scores (-(cost sum) / scale + rv) + thetaWeight <= -L / scale + max(rv + thetaWeight);
+                // 1e-9 covers the different association of the two roundings (scores are O(100))
+                const double U = (-((double)L * inv) + pm[t]) + 1e-9;
+                bnd[t] = U;
+                Best cand{U, t, 0};
+                if (4 * q + e < nbt && better(cand, me)) me = cand;
+            }
+        }
+        me = wave_best(me);
+        if (lane == 0) seed_s = me.i;
+    }
+    __syncthreads();
+    // the seed tile, exactly: its best score is a lower bound of the cube's maximum
+    const int seed = seed_s;
+    const int sby = seed / nbq4, sbx = seed - sby * nbq4;
+    const uint32_t* __restrict__ F = lv.field + (size_t)p * image;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)F, (short)0, (int)(image * sizeof(uint32_t)), 0x00020000);
+    const int* __restrict__ cl = lv.cells + ((size_t)p * lv.ntheta + it) * lv.kmax;
+    unsigned long long acc[4];
+    tile_exact(lv, rsrc, cl, K, sby, sbx, wave * 16, 64, acc);
+    if ((lane & 15) == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ex_s[wave][(lane >> 4) * 4 + e] = acc[e];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double val = -INFINITY;
+        if (lane < 16) {
+            const int dy = 4 * sby + (lane >> 2), dx = 4 * sbx + (lane & 3);
+            if (dy < nx && dx < nx) {
+                const unsigned long long tot = ex_s[0][lane] + ex_s[1][lane] + ex_s[2][lane] + ex_s[3][lane];
+                const double* __restrict__ pr = lv.prior + (size_t)p * 2 * npose;
+                const int qq = dy * nx + dx;
+                const double sc = (-((double)tot * (1.0 / lv.cost_scale)) + pr[qq]) + pr[npose + qq];
+                if (!isnan(sc)) val = sc;
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) val = fmax(val, __shfl_xor(val, o));
+        if (lane == 0 && val > -INFINITY) atomicMax(&lv.bnb_best[p], order_bits(val));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_exact(Slam2dLevel lv, int P) {
+    __shared__ short kept_s[256];
+    __shared__ int cnt_s[4];
+    __shared__ Running run_s[4];
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int p = (slot / lv.ntheta) * 8 + xcd, it = slot % lv.ntheta;
+    if (p >= P) return;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int nx = 2 * lv.ncell + 1, npose = nx * nx;
+    const int nbt = (nx + 3) >> 2, nbq4 = ((nbt + 3) >> 2) << 2;
+    const double thr = unorder_bits(lv.bnb_best[p]) - SLAM2D_PRUNE_MARGIN;
+    const double* __restrict__ bnd = lv.bounds + ((size_t)p * lv.ntheta + it) * nbt * nbq4;
+    bool keep = false;
+    if (tid < nbt * nbq4) keep = (tid % nbq4) < nbt && bnd[tid] >= thr;
+    const unsigned long long mask = __ballot(keep);
+    if (lane == 0) cnt_s[wave] = __popcll(mask);
+    __syncthreads();
+    int pos = __popcll(mask & (lane ? (~0ull >> (64 - lane)) : 0ull));
+    for (int w2 = 0; w2 < wave; ++w2) pos += cnt_s[w2];
+    if (keep) kept_s[pos] = (short)tid;
+    const int nk = cnt_s[0] + cnt_s[1] + cnt_s[2] + cnt_s[3];
+    __syncthreads();
+    const int K = lv.kcount[p * lv.ntheta + it];
+    const size_t image = (size_t)lv.fmax * lv.fpitch;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(lv.field + (size_t)p * image), (short)0, (int)(image * sizeof(uint32_t)), 0x00020000);
+    const int* __restrict__ cl = lv.cells + ((size_t)p * lv.ntheta + it) * lv.kmax;
+    const double* __restrict__ pr = lv.prior + (size_t)p * 2 * npose;
+    double* __restrict__ cube = lv.cube + ((size_t)p * lv.ntheta + it) * npose;
+    const double inv = 1.0 / lv.cost_scale;
+    Running run{-INFINITY, 0.0, INT_MAX, 0};
+    for (int j = wave; j < nk; j += 4) {
+        const int t = kept_s[j];
+        const int by = t / nbq4, bx = t - by * nbq4;
+        unsigned long long acc[4];
+        tile_exact(lv, rsrc, cl, K, by, bx, 0, 16, acc);
+        const int dy = 4 * by + (lane >> 4);
+        double sc[4];
+        Best me{-INFINITY, INT_MAX, 0};
+        const bool leader = (lane & 15) == 0 && dy < nx;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sc[e] = -INFINITY;
+            const int dx = 4 * bx + e;
+            if (leader && dx < nx) {
+                const int qq = dy * nx + dx;
+                sc[e] = (-((double)acc[e] * inv) + pr[qq]) + pr[npose + qq];              // :131, as k_sweep
+                cube[qq] = sc[e];
+                Best cand{sc[e], it * npose + qq, isnan(sc[e]) ? 1 : 0};
+                if (better(cand, me)) me = cand;
+            }
+        }
+        me = wave_best(me);
+        double ex = 0.0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (leader && 4 * bx + e < nx) ex += exp(sc[e] - me.v);
+        ex = wave_sum(ex);
+        running_merge(run, me.v, ex, me.i, me.nan);
+    }
+    if (lane == 0) run_s[wave] = run;
+    __syncthreads();
+    if (tid == 0) {
+        Running r = run_s[0];
+        for (int w2 = 1; w2 < 4; ++w2) running_merge(r, run_s[w2].m, run_s[w2].s, run_s[w2].arg, run_s[w2].nan);
+        Slam2dPartial pt;
+        pt.max = r.m; pt.sumexp = r.s; pt.argmax = r.arg; pt.has_nan = r.nan;
+        lv.partials[(size_t)p * lv.npartial + it] = pt;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_select_bnb(Slam2dLevel lv, const double* __restrict__ est, int estride,
+                                                   const double* __restrict__ uniform, Slam2dMatch* out) {
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int nx = 2 * lv.ncell + 1, npose = nx * nx;
+    const int nbt = (nx + 3) >> 2, nbq4 = ((nbt + 3) >> 2) << 2;
+    const int nW = lv.ntheta;
+    const Slam2dPartial* __restrict__ pt = lv.partials + (size_t)p * lv.npartial;
+    Best me{-INFINITY, INT_MAX, 0};
+    for (int w = lane; w < nW; w += WAVE) {
+        Best cand{pt[w].max, pt[w].argmax, pt[w].has_nan};
+        if (pt[w].argmax != INT_MAX && better(cand, me)) me = cand;
+    }
+    me = wave_best(me);
+    const double M = me.v;
+    const int per = (nW + WAVE - 1) / WAVE;
+    const int w0 = lane * per, w1 = min(nW, w0 + per);
+    double mine = 0.0;
+    for (int w = w0; w < w1; ++w) if (pt[w].argmax != INT_MAX) mine += pt[w].sumexp * exp(pt[w].max - M);
+    double incl = mine;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const double up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+    }
+    const double total = __shfl(incl, WAVE - 1);
+    int pick = me.i;
+    if (uniform != nullptr && !isnan(total)) {
+        // np.random.choice(n, 1, p): first index whose normalised cdf exceeds u (:137-138); the poses that were not
+        // scored carry < 1e-12 of the mass
+        const double target = uniform[p] * total;
+        const unsigned long long ahead = __ballot(incl > target);
+        const int lsel = ahead ? __ffsll((long long)ahead) - 1 : WAVE - 1;
+        double run = __shfl(incl - mine, lsel);
+        const int s0 = min(lsel * per, nW - 1), s1 = max(s0 + 1, min(nW, lsel * per + per));
+        int it = s1 - 1;
+        for (int w = s0; w < s1; ++w) {                           // wave-uniform loop
+            const double t = pt[w].argmax != INT_MAX ? pt[w].sumexp * exp(pt[w].max - M) : 0.0;
+            if (run + t > target || w == s1 - 1) { it = w; break; }
+            run += t;
+        }
+        while (it > 0 && pt[it].argmax == INT_MAX) --it;         // rounding fallback landed on an empty theta
+        const double thr = unorder_bits(lv.bnb_best[p]) - SLAM2D_PRUNE_MARGIN;
+        const double* __restrict__ bnd = lv.bounds + ((size_t)p * lv.ntheta + it) * nbt * nbq4;
+        const double* __restrict__ c = lv.cube + ((size_t)p * lv.ntheta + it) * npose;
+        // lane = pose row dy (nx <= 64): the row's scored poses in dx order
+        double lsum = 0.0;
+        bool has = false;
+        if (lane < nx) {
+            const int by = lane >> 2;
+            for (int bx = 0; bx < nbt; ++bx)
+                if (bnd[by * nbq4 + bx] >= thr) {
+                    has = true;
+                    for (int e = 0; e < 4 && 4 * bx + e < nx; ++e) lsum += exp(c[lane * nx + 4 * bx + e] - M);
+                }
+        }
+        double linc = lsum;
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const double up = __shfl_up(linc, o);
+            if (lane >= o) linc += up;
+        }
+        const unsigned long long hit = __ballot(has && run + linc > target);
+        const unsigned long long have = __ballot(has);
+        if (have) {
+            const int l2 = hit ? __ffsll((long long)hit) - 1 : 63 - __clzll((long long)have);
+            double r2 = run + __shfl(linc - lsum, l2);
+            int found = -1, last = -1;
+            if (lane == l2) {
+                const int by = lane >> 2;
+                for (int bx = 0; bx < nbt && found < 0; ++bx)
+                    if (bnd[by * nbq4 + bx] >= thr)
+                        for (int e = 0; e < 4 && 4 * bx + e < nx; ++e) {
+                            last = it * npose + lane * nx + 4 * bx + e;
+                            r2 += exp(c[lane * nx + 4 * bx + e] - M);
+                            if (r2 > target) { found = last; break; }
+                        }
+                if (found < 0) found = last;                      // rounding fallback: the row's last scored pose
+            }
+            pick = __shfl(found, l2);
+        }
+    }
+    if (lane == 0) {
+        Slam2dMatch m;
+        const int it = pick / npose, rem = pick - it * npose;
+        const int iy = rem / nx, ix = rem - iy * nx;
+        const double ex = est[(size_t)p * estride], ey = est[(size_t)p * estride + 1], eth = est[(size_t)p * estride + 2];
+        m.x = ex + (double)(ix - lv.ncell) * lv.step;                               // :142-143
+        m.y = ey + (double)(iy - lv.ncell) * lv.step;
+        m.theta = eth + lv.thetas[it];
+        m.confidence = exp(M) * total;                                              // :141
+        m.log_confidence = M + log(total);
+        m.best_score = M;
+        m.pick = pick;
+        m.argmax = me.i;
+        out[p] = m;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // K3  occupancy-grid update                         (Utils/OccupancyGrid.py:127-152)
 // ------------------------------------------------------------------------------------
 // Beam-major update: the reference's own formulation (:134-152 walks the cells of each beam's spoke).
@@ -1586,6 +2049,13 @@ static int check_field_args(const Slam2dLevel& lv, int P, bool lazy) {
         return SLAM2D_E_BADARG;
     if (lazy && !lv.tileneed) return SLAM2D_E_BADARG;
     if (lv.tmax * lv.tmax > 28000) return SLAM2D_E_TOOLARGE;        // k_tile_triage: 32 passes, 64 KB of LDS
+    if (lv.bnb) {
+        const int nx = 2 * lv.ncell + 1;
+        if (!lazy || !lv.pool || !lv.poolstate || !lv.pcells || !lv.bounds || !lv.tile_pmax || !lv.bnb_best) return SLAM2D_E_BADARG;
+        if (nx < 9 || nx > 64 || (lv.fpitch & 15) || lv.tmax * 16 != lv.fpitch) return SLAM2D_E_BADARG;
+        if (lv.tmax * lv.tmax > 20000) return SLAM2D_E_TOOLARGE;    // a third byte per tile in the triage's LDS
+        if (lv.npartial < lv.ntheta) return SLAM2D_E_BADARG;
+    }
     return 0;
 }
 
@@ -1605,7 +2075,7 @@ static void launch_field(const Slam2dLevel& lv, const Slam2dMap* d_maps, int P, 
         k_occ_scatter<<<dim3(cdiv(cdiv(lv.wmax, 32) + 1, 64), cdiv(lv.wmax, SCATTER_ROWS), P), dim3(64, 4), (size_t)lv.wmax * sizeof(int32_t), s>>>(lv, d_maps);
     }
     const int ntile = lv.tmax * lv.tmax;
-    k_tile_triage<<<P, TRIAGE_THREADS, (size_t)2 * ((ntile + 3) & ~3) + 4 * ((ntile + 31) / 32), s>>>(lv, lazy ? 1 : 0);
+    k_tile_triage<<<P, TRIAGE_THREADS, (size_t)(lv.bnb ? 3 : 2) * ((ntile + 3) & ~3) + 4 * ((ntile + 31) / 32), s>>>(lv, lazy ? 1 : 0);
     {
         StageScope prof(SLAM2D_STAGE_BLUR, s);
         static const int blur_blocks = [] { const char* e = getenv("SLAM2D_BLUR_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : SLAM2D_BLUR_BLOCKS_PER_PARTICLE; }();
@@ -1707,10 +2177,12 @@ int slam2d_field_build(const Slam2dLidar* lidar, const Slam2dLevel* level, const
     int rc = check_level(lidar, level, P);
     if (rc) return rc;
     if (!d_maps || !d_centre || !d_flags || centre_stride < 2) return SLAM2D_E_BADARG;
-    if ((rc = check_field_args(*level, P, false))) return rc;
+    { Slam2dLevel chk = *level; chk.bnb = 0; if ((rc = check_field_args(chk, P, false))) return rc; }
     hipStream_t s = (hipStream_t)stream;
-    if ((rc = launch_frames(*lidar, *level, d_maps, P, d_centre, centre_stride, d_flags, false, s))) return rc;
-    launch_field(*level, d_maps, P, d_flags, false, s);
+    Slam2dLevel lv = *level;
+    lv.bnb = 0;                                        // the full build has no pooled image
+    if ((rc = launch_frames(*lidar, lv, d_maps, P, d_centre, centre_stride, d_flags, false, s))) return rc;
+    launch_field(lv, d_maps, P, d_flags, false, s);
     return launch_status();
 }
 
@@ -1720,7 +2192,8 @@ int slam2d_sweep(const Slam2dLidar* lidar, const Slam2dLevel* level, int32_t P, 
     int rc = check_level(lidar, level, P);
     if (rc) return rc;
     if (!d_est || !d_ranges || !d_out || !d_flags || est_stride < 3) return SLAM2D_E_BADARG;
-    const Slam2dLevel& lv = *level;
+    Slam2dLevel lv = *level;
+    lv.bnb = 0;                                        // the whole cube, brute force
     if (lv.kmax < lidar->beams || !lv.partials) return SLAM2D_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     launch_endpoints(*lidar, lv, P, d_est, est_stride, d_ranges, est_moving_dist, d_psi_cs, d_flags, false, false, s);
@@ -1744,6 +2217,30 @@ int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2
         const int bound = ring_slot_bound(lv, est_moving_dist);
         const int nx = 2 * lv.ncell + 1, nslot = nx * ((nx + 3) / 4);
         if (bound > 0 && 2 * bound <= nslot) ring_chunks = cdiv(bound, WAVE);     // worth it only for a thin ring
+    }
+    if (lv.bnb) {
+        // branch and bound over 4x4 pose tiles: pooled cost planes, tile bounds + seed tiles, surviving tiles, selection
+        if ((rc = launch_frames(*lidar, lv, d_maps, P, d_est, est_stride, d_flags, true, s))) return rc;
+        launch_endpoints(*lidar, lv, P, d_est, est_stride, d_ranges, est_moving_dist, d_psi_cs, d_flags, true, false, s);
+        launch_field(lv, d_maps, P, d_flags, true, s);
+        const unsigned grid = (unsigned)cdiv(P, 8) * 8 * lv.ntheta;
+        {
+            StageScope prof(SLAM2D_STAGE_POOL, s);
+            k_pool<<<dim3(min(lv.tmax * lv.tmax, SLAM2D_BLUR_BLOCKS_PER_PARTICLE), P), 64, 0, s>>>(lv);
+        }
+        {
+            StageScope prof(SLAM2D_STAGE_BOUND, s);
+            k_bound<<<grid, 256, 0, s>>>(lv, P);
+        }
+        {
+            StageScope prof(SLAM2D_STAGE_EXACT, s);
+            k_exact<<<grid, 256, 0, s>>>(lv, P);
+        }
+        {
+            StageScope prof(SLAM2D_STAGE_SELECT, s);
+            k_select_bnb<<<P, WAVE, 0, s>>>(lv, d_est, est_stride, d_uniform, d_out);
+        }
+        return launch_status();
     }
     // the endpoints need only the frame, so they run first and tell the field build which tiles matter
     if ((rc = launch_frames(*lidar, lv, d_maps, P, d_est, est_stride, d_flags, true, s))) return rc;

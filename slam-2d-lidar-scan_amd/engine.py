@@ -88,6 +88,23 @@ def cost_scale_for(min_value):
     return float(2.0 ** k)
 
 
+def bnb_default(nx, ntheta, beams, tmax):
+    """Whether slam2d_match scores a level by branch and bound (include/slam2d.h): it pays once the cube is
+    large enough that 1/16 of the gathers + a few per cent of the tiles + three more launches beat the brute-force
+    sweep.  SLAM2D_BNB=0 / 1 forces it off / on wherever it is applicable (cube edge 9..64, <= 20000 field tiles)."""
+    import os
+    ok = 9 <= nx <= 64 and tmax * tmax <= 20000
+    env = os.environ.get("SLAM2D_BNB", "auto")
+    if env == "0" or not ok:
+        return False
+    if env == "1":
+        return True
+    return ntheta * nx * nx * beams >= BNB_MIN_WORK
+
+
+BNB_MIN_WORK = 4_000_000      # poses x beams per particle-scan; config 2: 10.9 M, reference coarse: 3.9 M, fine: 0.65 M
+
+
 def encode_cost(prob, scale):
     """probSP (values in [min, 0]) -> uint32 fixed-point cost, as the blur kernel stores it."""
     c = np.rint(-np.asarray(prob, dtype=np.float64) * scale)
@@ -386,7 +403,7 @@ class SearchLevel:
     """Parameters and device workspaces of one level for P particles."""
 
     def __init__(self, lidar, P, device, step, sigma, miss_prob, search_radius_ctor, radius, half_rad, fine,
-                 move_sigma, max_move_dev, turn_sigma):
+                 move_sigma, max_move_dev, turn_sigma, bnb=None):
         self.lidar, self.P, self.device = lidar, P, device
         self.step, self.sigma, self.miss_prob, self.fine = step, sigma, miss_prob, bool(fine)
         self.radius, self.half_rad = radius, half_rad
@@ -411,6 +428,9 @@ class SearchLevel:
         npose = self.nx * self.nx
         self.npartial = self.ntheta * (-(-npose // 64))
         self.tmax = -(-self.fmax // 16)             # 16x16-cell tiles of the blur
+        self.bnb = bnb_default(self.nx, self.ntheta, lidar.beams, self.tmax) if bnb is None else bool(bnb)
+        nbt = (self.nx + 3) // 4
+        nbq4 = 4 * ((nbt + 3) // 4)
         i32, f64 = torch.int32, torch.float64
         t = self.t = dict(
             blur_w=_dev(self.taps, device),
@@ -432,13 +452,22 @@ class SearchLevel:
             tilestate=torch.ones((P, self.tmax, self.tmax), dtype=torch.uint8, device=device),   # all dirty
             tilemin=torch.zeros((P, self.tmax, self.tmax), dtype=f64, device=device),
             tilemax=torch.zeros((P, self.tmax, self.tmax), dtype=f64, device=device),
-            tilelist=torch.zeros((P, 2, self.tmax * self.tmax), dtype=i32, device=device),
-            tilecount=torch.zeros((P, 2), dtype=i32, device=device),
+            tilelist=torch.zeros((P, 4, self.tmax * self.tmax), dtype=i32, device=device),
+            tilecount=torch.zeros((P, 4), dtype=i32, device=device),
             tileneed=torch.zeros((P, (self.tmax * self.tmax + 31) // 32), dtype=i32, device=device),
             freerow=torch.zeros((P, 64), dtype=torch.int64, device=device),
             ring=torch.zeros(1 + self.nx * ((self.nx + 3) // 4), dtype=i32, device=device),
             prune_state=torch.zeros(P, dtype=i32, device=device),
         )
+        if self.bnb:        # branch and bound over 4x4 pose tiles (include/slam2d.h)
+            t.update(
+                pool=torch.zeros((P, 4, self.fmax, self.fpitch // 4), dtype=i32, device=device),
+                poolstate=torch.ones((P, self.tmax, self.tmax), dtype=torch.uint8, device=device),   # all dirty
+                pcells=torch.zeros((P, self.ntheta, self.kmax), dtype=i32, device=device),
+                bounds=torch.zeros((P, self.ntheta, nbt, nbq4), dtype=f64, device=device),
+                tile_pmax=torch.zeros((P, nbt, nbq4), dtype=f64, device=device),
+                bnb_best=torch.zeros(P, dtype=torch.int64, device=device),
+            )
         self.c = Slam2dLevel(
             step=step, reach=self.reach, log_miss=self.log_miss, floor_value=self.floor_value,
             cost_scale=self.cost_scale, blur_radius=self.blur_radius, fmax=self.fmax, fpitch=self.fpitch, wmax=self.wmax,
@@ -453,7 +482,8 @@ class SearchLevel:
             tilemin=t["tilemin"].data_ptr(), tilemax=t["tilemax"].data_ptr(), tilelist=t["tilelist"].data_ptr(),
             tilecount=t["tilecount"].data_ptr(),
             tileneed=t["tileneed"].data_ptr(), freerow=t["freerow"].data_ptr(), ring=t["ring"].data_ptr(), prune_state=t["prune_state"].data_ptr(),
-            ring_cap=self.nx * ((self.nx + 3) // 4))
+            ring_cap=self.nx * ((self.nx + 3) // 4), bnb=int(self.bnb),
+            **({k: t[k].data_ptr() for k in ("pool", "poolstate", "pcells", "bounds", "tile_pmax", "bnb_best")} if self.bnb else {}))
 
     def next_generation(self):
         """Advance the occupancy-image generation stamp (Slam2dLevel.occ_gen) for the next build: the
@@ -486,6 +516,8 @@ class SearchLevel:
         fh, fw = prob.shape
         self.t["field"][p, :fh, :fw] = torch.from_numpy(cost.view(np.int32)).to(self.device)
         self.t["tilestate"][p].fill_(1)          # the buffer no longer holds what field_build left there
+        if self.bnb:
+            self.t["poolstate"][p].fill_(1)
         self.t["freerow"][p].zero_()             # ... and no tile of it is known to hold the constant
         return scale
 

@@ -84,10 +84,12 @@ class ParticleFilter:
     next scan needs the matched poses on the host); ``bench.py`` drives the same
     kernels without host round trips.
     ``total_particles`` / ``first_index`` describe this rank's slice when sharded;
-    ``rng`` defaults to the legacy global NumPy stream like the reference."""
+    ``rng`` defaults to the legacy global NumPy stream like the reference.
+    ``bnb``: score the pose cubes by branch and bound over 4x4 pose tiles (include/slam2d.h) -- None: wherever
+    the cube is large enough for it to pay (engine.bnb_default), True / False: wherever applicable / nowhere."""
 
     def __init__(self, numParticles, ogParameters, smParameters, device=None, growable=True, rng=None,
-                 total_particles=None, first_index=0, group=None):
+                 total_particles=None, first_index=0, group=None, bnb=None):
         (mapX, mapY, initXY, unit, fov, max_range, beams, wall) = ogParameters            # :66
         (sr, half_rad, sigma, move_sigma, max_dev, turn_sigma, miss, cf) = smParameters   # :67-68
         self.device = require_gpu(device or "cuda:0")
@@ -114,7 +116,7 @@ class ParticleFilter:
         self.engine = ParticleEngine(self.lidar, maps, self.device)
         P, dev = numParticles, self.device
         common = dict(search_radius_ctor=sr, half_rad=half_rad, move_sigma=move_sigma, max_move_dev=max_dev,
-                      turn_sigma=turn_sigma)
+                      turn_sigma=turn_sigma, bnb=bnb)
         cstep = cf * unit                                                                 # ScanMatcher_OGBased.py:54
         self.coarse = SearchLevel(self.lidar, P, dev, step=cstep, sigma=sigma / cf, miss_prob=miss, radius=sr,
                                   fine=False, **common)

@@ -23,7 +23,7 @@ def _shared_level(og, key_extra, **kw):
     calls are synchronous and sequential, so nothing is live between calls."""
     key = (str(og.device), id(og.lidar)) + key_extra
     if key not in _level_cache:
-        _level_cache[key] = SearchLevel(og.lidar, 1, og.device, **kw)
+        _level_cache[key] = SearchLevel(og.lidar, 1, og.device, bnb=False, **kw)     # whole cubes: brute-force sweep
     return _level_cache[key]
 
 
