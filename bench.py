@@ -187,10 +187,10 @@ class HotPath:
             nbt = (lv.nx + 3) // 4
             out[name] = dict(scatter=wm * wm // 8 + f * f, blur=f * f + 4 * f * f,      # map bits in, occupied image out / in, field out
                              sweep=4 * f * f + 8 * lid.beams + 8 * lv.ntheta * lv.nx * lv.nx,
-                             # branch and bound: pooled image (field in, pooled planes out); bounds (pooled planes in,
-                             # cell lists in, one double per pose tile out); surviving tiles (field in, cell lists in,
-                             # one partial per theta out)
-                             pool=8 * f * f, bound=4 * f * f + 4 * lid.beams * lv.ntheta + 8 * lv.ntheta * nbt * 4 * ((nbt + 3) // 4),
+                             # branch and bound: tile bounds (gmin2, 1/16 of the field's cells, in; cell lists in; one
+                             # double per pose tile out); surviving tiles + selection (field in, cell lists in, one
+                             # partial per theta out)
+                             bound=f * f // 4 + 4 * lid.beams * lv.ntheta + 8 * lv.ntheta * nbt * 4 * ((nbt + 3) // 4),
                              exact=4 * f * f + 4 * lid.beams * lv.ntheta + 24 * lv.ntheta, bnb=bool(lv.bnb))
         # update: touched cells of one representative scan (cell-major classification on the host LUT)
         rng = scen.ranges[0]
@@ -270,7 +270,7 @@ def main():
     hot = HotPath(cfg, P, scen, device)
 
     stages = [E._lib.STAGE_SWEEP, E._lib.STAGE_BLUR, E._lib.STAGE_SCATTER, E._lib.STAGE_UPDATE,
-              E._lib.STAGE_SELECT, E._lib.STAGE_ENDPOINTS, E._lib.STAGE_POOL, E._lib.STAGE_BOUND, E._lib.STAGE_EXACT]
+              E._lib.STAGE_SELECT, E._lib.STAGE_ENDPOINTS, E._lib.STAGE_BOUND, E._lib.STAGE_EXACT]
 
     def collect():
         out = {}
@@ -348,7 +348,6 @@ def main():
         per_unit = {"k_sweep": sum(v["sweep"] for v in lev.values() if not v["bnb"]),
                     "k_blur_clamp": sum(v["blur"] for v in lev.values()),
                     "k_occ_scatter": sum(v["scatter"] for v in lev.values()),
-                    "k_pool": sum(v["pool"] for v in lev.values() if v["bnb"]),
                     "k_bound": sum(v["bound"] for v in lev.values() if v["bnb"]),
                     "k_exact": sum(v["exact"] for v in lev.values() if v["bnb"]),
                     "k_grid_update": ab["update"]["per_particle"]}
@@ -383,6 +382,8 @@ def main():
             "algorithmic_bytes_per_particle_scan": ab,
             "fault_flags": int(np.bitwise_or.reduce(flags)) if len(flags) else 0,
         }
+        out["tile_stats"] = {k: {a: round(float(b), 4) for a, b in lv.bnb_stats().items()}
+                             for k, lv in (("coarse", hot.coarse), ("fine", hot.fine)) if lv is not None}
         if variant is not None:
             out["variants"] = {"prior_pruned": variant}
         if not args.no_cpu_baseline and world == 1:

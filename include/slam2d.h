@@ -177,9 +177,8 @@ typedef struct {
                                 anything other than slam2d_field_build */
     double*  tilemin;        /* [P][tmax][tmax] scratch: per-tile minimum of the blurred field */
     double*  tilemax;        /* [P][tmax][tmax] scratch: per-tile maximum of the field as stored */
-    int32_t* tilelist;       /* [P][4][tmax*tmax] scratch: work lists (field tiles to blur, to fill; pooled tiles to
-                                compute, to fill -- the last two only when bnb != 0) */
-    int32_t* tilecount;      /* [P][4] scratch: their lengths */
+    int32_t* tilelist;       /* [P][2][tmax*tmax] scratch: work lists (tiles to blur, tiles to fill) */
+    int32_t* tilecount;      /* [P][2] scratch: their lengths */
     uint32_t* tileneed;      /* [P][ceil(tmax*tmax/32)] scratch of slam2d_match: bit t set = the sweep reads
                                 field tile t (may be NULL when only slam2d_field_build is used) */
     unsigned long long* freerow; /* [P][64] scratch (used when tmax <= 64): bit tx of word ty = field tile (ty, tx)
@@ -189,13 +188,13 @@ typedef struct {
                                 NULL disables the option */
     int32_t* prune_state;    /* [P] scratch of the same option: 1 = particle needs the full sweep */
     int32_t ring_cap;        /* capacity of ring (ny * ceil(nx / 4) always suffices) */
-    /* ---- branch and bound over 4x4 pose tiles (slam2d_match with bnb != 0; see SLAM2D_BNB below) ---- */
-    uint32_t* pool;          /* [P][4][fmax][fpitch/4] min-pooled cost: plane ph, row y, element X holds the minimum of
-                                field[y..y+3][4X+ph .. 4X+ph+3] (x-phase planes: the tile bounds of one pose row are
-                                contiguous) */
-    uint8_t* poolstate;      /* [P][tmax][tmax] PERSISTENT like tilestate, for the pooled image: 0 = the pooled tile
-                                holds the free-space constant.  Initialise to 1 */
-    int32_t* pcells;         /* [P][ntheta][kmax] the endpoint cells again, as byte offsets into `pool` */
+    /* ---- branch and bound over 4x4 pose tiles (slam2d_match with bnb != 0; see "Branch and bound" below) ---- */
+    uint32_t* gmin;          /* [P][4*tmax][4*tmax] minimum cost of every ALIGNED 4x4 block of field cells; written with the
+                                field tiles (k_blur_clamp, the triage's constant fill), so it shares tilestate */
+    uint32_t* gmin2;         /* [P][4*tmax][4*tmax] element [Y][X] = min(gmin[Y..Y+1][X..X+1]) >> 12: a lower bound of the
+                                cost of every field cell in rows 4Y..4Y+7, columns 4X..4X+7 -- whatever 4x4 window starts in
+                                block (Y, X) lies inside.  20-bit values: a sum over <= 2048 cells fits 32 bits */
+    int32_t* pcells;         /* [P][ntheta][kmax] the endpoint cells again, as byte offsets into a particle's gmin2 */
     double*  bounds;         /* [P][ntheta][nb][4*ceil(nb/4)] upper bound of the score of every pose tile, nb = ceil(nx/4) */
     double*  tile_pmax;      /* [P][nb][4*ceil(nb/4)] largest rv + thetaWeight of a pose tile (+inf if one is NaN) */
     unsigned long long* bnb_best; /* [P] order-preserving bits of the best exact score of the seed tiles */
@@ -270,16 +269,20 @@ int slam2d_sweep(const Slam2dLidar* lidar, const Slam2dLevel* level, int32_t P,
  * unpruned result. */
 #define SLAM2D_MATCH_PRUNE_BY_PRIOR 1u
 #define SLAM2D_PRUNE_MARGIN 40.0
+#define SLAM2D_BNB_MARGIN 30.0
 /* Branch and bound (Slam2dLevel.bnb != 0; every level whose cube has 2*ncell+1 in [9, 64] may use it).
- * The cube is cut into tiles of 4 x 4 poses (dy, dx) of one theta.  No pose of a tile can score more than
- *     U = sum_k max(field over the 4 x 4 window the tile's poses read at cell k) + max(rv + thetaWeight over the tile)
- * (in cost terms: the 4 x 4 min-pooled cost image `pool`, built from the field tiles this call blurred).  One
- * launch computes U for every tile -- 1/16 of the brute-force gathers -- and scores exactly, per theta, the tile
- * with the largest U; the best of those exact scores, M0, is a lower bound of the cube's maximum.  A second launch
- * scores exactly every tile with U >= M0 - SLAM2D_PRUNE_MARGIN (typically 1-5 % of the tiles).  A pose that is
- * skipped scores < max - 40: it cannot be the arg-max, and all skipped poses together change confidence and the
- * soft-max draw by < 1e-12 relative.  A tile holding a NaN prior is always scored (np.argmax returns the first
- * NaN).  level->cube then holds only the scored tiles. */
+ * The cube is cut into tiles of 4 x 4 poses (dy, dx) of one theta.  The poses of a tile read, at endpoint cell k,
+ * a 4 x 4 window of the field; that window lies inside the 8 x 8 block of cells gmin2 summarises, so no pose of
+ * the tile can score more than
+ *     U = -(sum_k gmin2[block of cell k's window] << 12) / cost_scale + max(rv + thetaWeight over the tile).
+ * One launch computes U for every tile -- 1/16 of the brute-force gathers, from an image 1/16 the size of the
+ * field -- and scores exactly, per theta, the tile with the largest U; the best of those exact scores, M0, is a
+ * lower bound of the cube's maximum.  A second launch scores exactly every tile with U >= M0 -
+ * SLAM2D_BNB_MARGIN (a fraction of a per cent to a few per cent of the tiles) and selects the pose.  A pose that is
+ * skipped scores < max - 30: it cannot be the arg-max, and all skipped poses together (<= 2.4e5 of them at the
+ * largest configuration) change confidence and the soft-max draw by < 2.4e5 * exp(-30) = 2.2e-8 relative -- the bar
+ * is 1e-5.  A tile holding a NaN prior is always scored (np.argmax returns the first NaN).  level->cube
+ * then holds only the scored tiles. */
 int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2dMap* d_maps, int32_t P,
                  const double* d_est, int32_t est_stride, const double* d_ranges,
                  double est_moving_dist, const double* d_psi_cs, const double* d_uniform,
@@ -362,10 +365,9 @@ int slam2d_map_fill(uint32_t* d_cells, int64_t n, uint32_t value, void* stream);
 #define SLAM2D_STAGE_UPDATE    3   /* k_grid_update: occupancy-grid update */
 #define SLAM2D_STAGE_SELECT    4   /* k_select: argmax / soft-max draw / confidence */
 #define SLAM2D_STAGE_ENDPOINTS 5   /* k_endpoints: unique endpoint cells */
-#define SLAM2D_STAGE_POOL      6   /* k_pool: 4x4 min-pooled cost image (branch and bound) */
-#define SLAM2D_STAGE_BOUND     7   /* k_bound: tile upper bounds + seed tiles */
-#define SLAM2D_STAGE_EXACT     8   /* k_exact: exact scores of the surviving tiles */
-#define SLAM2D_STAGE_COUNT     9
+#define SLAM2D_STAGE_BOUND     6   /* k_bound: tile upper bounds + seed tiles (branch and bound) */
+#define SLAM2D_STAGE_EXACT     7   /* k_exact: exact scores of the surviving tiles + selection */
+#define SLAM2D_STAGE_COUNT     8
 int  slam2d_prof_enable(uint32_t stage_mask, int32_t capacity);
 int  slam2d_prof_collect(int32_t stage, double* total_ms, int32_t* launches);
 void slam2d_prof_disable(void);

@@ -39,11 +39,12 @@ MAX_BEAMS = 2048
 SPOKE_BAND = 16
 MATCH_PRUNE_BY_PRIOR = 1
 PRUNE_MARGIN = 40.0
+BNB_MARGIN = 30.0
 
-STAGE_SWEEP, STAGE_BLUR, STAGE_SCATTER, STAGE_UPDATE, STAGE_SELECT, STAGE_ENDPOINTS, STAGE_POOL, STAGE_BOUND, STAGE_EXACT = range(9)
+STAGE_SWEEP, STAGE_BLUR, STAGE_SCATTER, STAGE_UPDATE, STAGE_SELECT, STAGE_ENDPOINTS, STAGE_BOUND, STAGE_EXACT = range(8)
 STAGE_NAMES = {STAGE_SWEEP: "k_sweep", STAGE_BLUR: "k_blur_clamp", STAGE_SCATTER: "k_occ_scatter",
                STAGE_UPDATE: "k_grid_update", STAGE_SELECT: "k_select", STAGE_ENDPOINTS: "k_endpoints",
-               STAGE_POOL: "k_pool", STAGE_BOUND: "k_bound", STAGE_EXACT: "k_exact"}
+               STAGE_BOUND: "k_bound", STAGE_EXACT: "k_exact"}
 
 _vp = C.c_void_p
 
@@ -89,7 +90,7 @@ class Slam2dLevel(C.Structure):
                 ("tilestate", _vp), ("tilemin", _vp), ("tilemax", _vp),
                 ("tilelist", _vp), ("tilecount", _vp), ("tileneed", _vp), ("freerow", _vp),
                 ("ring", _vp), ("prune_state", _vp), ("ring_cap", C.c_int32),
-                ("pool", _vp), ("poolstate", _vp), ("pcells", _vp), ("bounds", _vp), ("tile_pmax", _vp), ("bnb_best", _vp),
+                ("gmin", _vp), ("gmin2", _vp), ("pcells", _vp), ("bounds", _vp), ("tile_pmax", _vp), ("bnb_best", _vp),
                 ("bnb", C.c_int32), ("_pad_bnb", C.c_int32), ("occ_gen", C.c_int32)]
 
 

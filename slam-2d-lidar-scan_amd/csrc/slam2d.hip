@@ -56,6 +56,15 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace
 
+// Phase timing inside a kernel (development aid, -DSLAM2D_DEBUG_CLOCK): thread 0 of one block stamps the
+// 100 MHz wall clock at numbered points; slam2d_debug_clock() copies the stamps out.
+#ifdef SLAM2D_DEBUG_CLOCK
+__device__ long long g_dbg_clock[64];
+#define DBG_CLOCK(i, blk) do { if ((blk) && threadIdx.x == 0) g_dbg_clock[i] = wall_clock64(); } while (0)
+#else
+#define DBG_CLOCK(i, blk) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------
@@ -139,7 +148,7 @@ __global__ void k_frame_axis(Slam2dLidar lid, Slam2dLevel lv, const Slam2dMap* _
     const Slam2dFrame fr = make_frame(lid, lv, m, centre[(size_t)p * cstride], centre[(size_t)p * cstride + 1], f);
     if (j == 0 && axis == 0) {
         lv.frames[p] = fr;
-        for (int i = 0; i < 4; ++i) lv.tilecount[4 * p + i] = 0;
+        lv.tilecount[2 * p] = 0; lv.tilecount[2 * p + 1] = 0;
         if (lv.bnb) lv.bnb_best[p] = order_bits(-INFINITY);
         if (f) atomicOr(&flags[p], f);
     }
@@ -386,6 +395,9 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
         for (int idx = tid; idx < BLUR_TILE * BLUR_TILE; idx += BLUR_THREADS) {
             const int y = idx / BLUR_TILE, x = idx - y * BLUR_TILE;
             if (tx0 + x < lv.fpitch && ty0 + y < lv.fmax) field[(size_t)(ty0 + y) * lv.fpitch + tx0 + x] = c;
+            // the tile's 4 x 4 block minima, from inside this loop (a separate store after it costs the kernel 17
+            // VGPRs and a third of its waves)
+            if (lv.bnb && ((y | x) & 3) == 0) lv.gmin[((size_t)p * (lv.tmax << 2) + ((ty0 + y) >> 2)) * (lv.tmax << 2) + ((tx0 + x) >> 2)] = c;
         }
         if (tid == 0) *state = mode == 0 ? 0 : 1;
         return;
@@ -417,6 +429,7 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
             double mrow[4 + 2 * RAD];
 #pragma unroll
             for (int k = 0; k < 4 + 2 * RAD; ++k) mrow[k] = sm.mid[y][x0 + k];
+            uint32_t cmin = 0xffffffffu;                   // of the lane's 4 stored costs: one row of an aligned 4x4 block
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
                 double acc = mrow[o + RAD] * w[RAD];
@@ -426,7 +439,17 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
                 if (gy < fh && gx < fw) {
                     lmin = fmin(lmin, acc);
                     lmax = fmax(lmax, acc > thr ? 0.0 : acc);
-                    field[(size_t)gy * lv.fpitch + gx] = acc > thr ? 0u : (uint32_t)rint(-acc * lv.cost_scale);
+                    const uint32_t cst = acc > thr ? 0u : (uint32_t)rint(-acc * lv.cost_scale);
+                    field[(size_t)gy * lv.fpitch + gx] = cst;
+                    cmin = min(cmin, cst);
+                }
+            }
+            if (lv.bnb) {                                  // rows y, y^1, y^2, y^3 of the block sit in lanes tid ^ 4, ^ 8
+                cmin = min(cmin, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)cmin, 0x124, 0xF, 0xF, false));   // row_ror:4
+                cmin = min(cmin, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)cmin, 0x128, 0xF, 0xF, false));   // row_ror:8
+                if ((y & 3) == 0) {
+                    const int gp = lv.tmax << 2;
+                    lv.gmin[((size_t)p * gp + (ty0 >> 2) + (y >> 2)) * gp + (tx0 >> 2) + (tid & 3)] = cmin;
                 }
             }
         }
@@ -447,10 +470,22 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
             double acc = sm.mid[y][x + r] * w[r];
             for (int j = -r; j < 0; ++j) acc = acc + (sm.mid[y][x + r + j] + sm.mid[y][x + r - j]) * w[r + j];
             const int gy = ty0 + y, gx = tx0 + x;
+            uint32_t cmin = 0xffffffffu;
             if (gy < fh && gx < fw) {
                 lmin = fmin(lmin, acc);
                 lmax = fmax(lmax, acc > thr ? 0.0 : acc);
-                field[(size_t)gy * lv.fpitch + gx] = acc > thr ? 0u : (uint32_t)rint(-acc * lv.cost_scale);
+                cmin = acc > thr ? 0u : (uint32_t)rint(-acc * lv.cost_scale);
+                field[(size_t)gy * lv.fpitch + gx] = cmin;
+            }
+            if (lv.bnb) {        // this pass covers rows 4i .. 4i+3 (i = idx / 64): lane = (row tid >> 4, column tid & 15)
+                cmin = min(cmin, (uint32_t)__shfl_xor((int)cmin, 1));
+                cmin = min(cmin, (uint32_t)__shfl_xor((int)cmin, 2));
+                cmin = min(cmin, (uint32_t)__shfl_xor((int)cmin, 16));
+                cmin = min(cmin, (uint32_t)__shfl_xor((int)cmin, 32));
+                if ((tid & 0x33) == 0) {
+                    const int gp = lv.tmax << 2;
+                    lv.gmin[((size_t)p * gp + (ty0 >> 2) + (idx >> 6)) * gp + (tx0 >> 2) + ((tid & 15) >> 2)] = cmin;
+                }
             }
         }
     }
@@ -474,87 +509,67 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
 // ONE tile of the frame is free (every cell of such a tile equals the floor and no blurred value is
 // below it).  A frame without any free tile falls back to the full build.
 #define TRIAGE_THREADS 1024
-// Branch and bound (lv.bnb): the triage also lists the tiles of the POOLED image (4x4 min-pooled cost, k_pool).
-// Pooled tile t reads field tiles t, t+(0,1), t+(1,0), t+(1,1); it differs from the free-space constant only if one
-// of those holds a wall nearby, i.e. an occupied cell in tile rows ty-1..ty+2, columns tx-1..tx+2.  Lists 2 / 3:
-// pooled tiles to compute / to fill with the constant (lv.poolstate remembers the constant ones across scans).
 __global__ __launch_bounds__(TRIAGE_THREADS) void k_tile_triage(Slam2dLevel lv, int lazy) {
     // tile flags, tile states and the needed-tile bitmap of the particle are staged in LDS with one batch
     // of coalesced loads; everything after that runs out of LDS (the kernel is pure latency otherwise)
-    extern __shared__ __attribute__((aligned(16))) uint8_t tri_lds[];     // [ntile4] flags, [ntile4] states, [ntile4] pool states, [nneed] words
-    __shared__ int base[4];
+    extern __shared__ __attribute__((aligned(16))) uint8_t tri_lds[];     // [ntile4] flags, [ntile4] states, [nneed] words
+    __shared__ int base[2];
     const int p = blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const Slam2dFrame fr = lv.frames[p];
     const int nty = (fr.fh + BLUR_TILE - 1) >> BLUR_SHIFT, ntx = (fr.fw + BLUR_TILE - 1) >> BLUR_SHIFT;
     const int ntile = lv.tmax * lv.tmax, ntile4 = (ntile + 3) & ~3, nneed = (ntile + 31) >> 5;
     const int iters = (ntile + TRIAGE_THREADS - 1) / TRIAGE_THREADS;          // <= 32 (checked by the host)
-    const bool bnb = lv.bnb != 0;
     uint8_t* tiles_s = tri_lds;
     uint8_t* state_s = tri_lds + ntile4;
-    uint8_t* pstate_s = tri_lds + 2 * ntile4;                                // only with bnb
-    uint32_t* need_s = reinterpret_cast<uint32_t*>(tri_lds + (bnb ? 3 : 2) * ntile4);
+    uint32_t* need_s = reinterpret_cast<uint32_t*>(tri_lds + 2 * ntile4);
     const uint8_t stamp = occ_stamp(lv);
     uint8_t* state = lv.tilestate + (size_t)p * ntile;
-    uint8_t* pstate = bnb ? lv.poolstate + (size_t)p * ntile : nullptr;
     {
         const uint8_t* tiles = lv.tilemask + (size_t)p * ntile;
-        for (int t = tid; t < ntile; t += TRIAGE_THREADS) {
-            tiles_s[t] = tiles[t] == stamp; state_s[t] = state[t];
-            if (bnb) pstate_s[t] = pstate[t];
-        }
+        for (int t = tid; t < ntile; t += TRIAGE_THREADS) { tiles_s[t] = tiles[t] == stamp; state_s[t] = state[t]; }
         if (lazy) for (int w = tid; w < nneed; w += TRIAGE_THREADS) need_s[w] = lv.tileneed[(size_t)p * nneed + w];
     }
-    if (tid < 4) base[tid] = 0;
+    if (tid < 2) base[tid] = 0;
     __syncthreads();
-    uint32_t liveb = 0u, anyb = 0u, panyb = 0u;
+    uint32_t liveb = 0u, anyb = 0u;
     int has_free = 0;
     for (int it = 0; it < iters; ++it) {
         const int t = it * TRIAGE_THREADS + tid;
         const int ty = t / lv.tmax, tx = t - ty * lv.tmax;
         if (t < ntile && ty < nty && tx < ntx) {
-            int any = 0, pany = 0;
+            int any = 0;
 #pragma unroll
-            for (int dy = -1; dy <= 2; ++dy)
+            for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-                for (int dx = -1; dx <= 2; ++dx) {
+                for (int dx = -1; dx <= 1; ++dx) {
                     const int yy = ty + dy, xx = tx + dx;
-                    if (yy >= 0 && yy < nty && xx >= 0 && xx < ntx) {
-                        const int o = tiles_s[yy * lv.tmax + xx];
-                        pany |= o;
-                        if (dy <= 1 && dx <= 1) any |= o;
-                    }
+                    if (yy >= 0 && yy < nty && xx >= 0 && xx < ntx) any |= tiles_s[yy * lv.tmax + xx];
                 }
             liveb |= 1u << it;
             if (any) anyb |= 1u << it; else has_free = 1;
-            if (pany) panyb |= 1u << it;
         }
     }
     has_free = __syncthreads_or(has_free);
     // one free tile pins the field minimum (:43) to the analytic floor: k_blur_check_redo has nothing to do
     if (tid == 0) lv.frames[p].min_known = has_free;
     const bool everything = !lazy || !has_free;
-    int* list = lv.tilelist + (size_t)p * 4 * ntile;
+    int* list = lv.tilelist + (size_t)p * 2 * ntile;
     // list positions from LDS counters (one aggregated atomic per wave and list): the order of a list does not
     // matter -- every tile is blurred / filled independently -- and the loop needs no barrier
     const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
     for (int it = 0; it < iters; ++it) {
         const int t = it * TRIAGE_THREADS + tid;
-        const bool live = (liveb >> it) & 1u, any = (anyb >> it) & 1u, pany = (panyb >> it) & 1u;
+        const bool live = (liveb >> it) & 1u, any = (anyb >> it) & 1u;
         const bool wanted = live && (everything || ((need_s[t >> 5] >> (t & 31)) & 1u));
-        bool to_fill = false, p_fill = false;
+        bool to_fill = false;
         if (live && !any) {
             lv.tilemin[(size_t)p * ntile + t] = lv.floor_value;
             if (wanted && state_s[t] != 0) { to_fill = true; state[t] = 0; }
         }
-        if (bnb && wanted) {
-            if (pany) pstate[t] = 1;
-            else if (pstate_s[t] != 0) { p_fill = true; pstate[t] = 0; }      // (pstate_s is read only under bnb)
-        }
-        const bool mine[4] = {wanted && any, to_fill, bnb && wanted && pany, p_fill};
+        const bool mine[2] = {wanted && any, to_fill};
 #pragma unroll
-        for (int which = 0; which < 4; ++which) {
-            if (which >= 2 && !bnb) break;
+        for (int which = 0; which < 2; ++which) {
             const unsigned long long mask = __ballot(mine[which]);
             if (!mask) continue;
             int start = 0;
@@ -564,122 +579,74 @@ __global__ __launch_bounds__(TRIAGE_THREADS) void k_tile_triage(Slam2dLevel lv, 
         }
     }
     __syncthreads();
-    if (tid < 4) lv.tilecount[4 * p + tid] = base[tid];
+    if (tid < 2) lv.tilecount[2 * p + tid] = base[tid];
     // fill: one wave per tile, 64 lanes x 16 bytes = the tile's 256 cells (the whole tile, also beyond the
     // current frame, so that the tile stays valid when the frame grows by its +-1 jitter)
+    const int nfill = base[1];
     const double v = lv.floor_value;
     const uint32_t c = v > 0.5 * v ? 0u : (uint32_t)rint(-v * lv.cost_scale);
     uint32_t* field = lv.field + (size_t)p * lv.fmax * lv.fpitch;
-    for (int b = wave; b < base[1]; b += TRIAGE_THREADS / 64) {
+    for (int b = wave; b < nfill; b += TRIAGE_THREADS / 64) {
         const int t = list[ntile + b];
         const int ty0 = (t / lv.tmax) * BLUR_TILE, tx0 = (t % lv.tmax) * BLUR_TILE;
         const int y = lane >> 2, x = (lane & 3) * 4;
         if (ty0 + y < lv.fmax && tx0 + x + 3 < lv.fpitch)
             *reinterpret_cast<uint4*>(field + (size_t)(ty0 + y) * lv.fpitch + tx0 + x) = make_uint4(c, c, c, c);
-    }
-    if (!bnb) return;
-    // pooled image: lane = (row y, x-phase ph) writes elements 4*tx .. 4*tx+3 of plane ph
-    const int ppitch = lv.fpitch >> 2;
-    uint32_t* pool = lv.pool + (size_t)p * lv.fmax * lv.fpitch;
-    for (int b = wave; b < base[3]; b += TRIAGE_THREADS / 64) {
-        const int t = list[3 * ntile + b];
-        const int ty0 = (t / lv.tmax) * BLUR_TILE, tx = t % lv.tmax;
-        const int y = lane >> 2, ph = lane & 3;
-        if (ty0 + y < lv.fmax && 4 * tx + 3 < ppitch)
-            *reinterpret_cast<uint4*>(pool + ((size_t)ph * lv.fmax + ty0 + y) * ppitch + 4 * tx) = make_uint4(c, c, c, c);
+        if (lv.bnb && lane < 16) {                         // the tile's 4 x 4 block minima (branch and bound)
+            const int gp = lv.tmax << 2;
+            lv.gmin[((size_t)p * gp + (ty0 >> 2) + (lane >> 2)) * gp + (tx0 >> 2) + (lane & 3)] = c;
+        }
     }
 }
 
-// 4x4 min-pooled cost image for the branch and bound (lv.pool): one wave per listed tile; the 19 x 19 cost
-// window (the tile + 3 cells to the right / below, clamped to the buffer: duplicates only loosen a minimum) goes
-// through LDS, separable minimum (4 columns, then 4 rows).  The values were written by k_blur_clamp / the
-// triage a moment ago and come out of L2.
-#define POOL_W (BLUR_TILE + 3)
-__global__ __launch_bounds__(64) void k_pool(Slam2dLevel lv) {
-    __shared__ uint32_t win[POOL_W][POOL_W + 1];
-    __shared__ uint32_t hm[POOL_W][BLUR_TILE + 1];
-    const int p = blockIdx.y, lane = threadIdx.x;
-    const int ntile = lv.tmax * lv.tmax;
-    const int n = lv.tilecount[4 * p + 2];
-    if ((int)blockIdx.x >= n) return;
-    const int* list = lv.tilelist + (size_t)p * 4 * ntile + 2 * ntile;
-    const uint32_t* __restrict__ field = lv.field + (size_t)p * lv.fmax * lv.fpitch;
-    uint32_t* pool = lv.pool + (size_t)p * lv.fmax * lv.fpitch;
-    const int ppitch = lv.fpitch >> 2;
-    for (int b = blockIdx.x; b < n; b += gridDim.x) {
-        const int t = list[b];
-        const int ty0 = (t / lv.tmax) * BLUR_TILE, tx0 = (t % lv.tmax) * BLUR_TILE;
-        // 19 rows x 5 quads of 4 cells (the last quad clamped element-wise)
-        uint4 q[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = min(lane + 64 * i, POOL_W * 5 - 1);
-            const int r = idx / 5, c4 = idx - r * 5;
-            const int gy = min(ty0 + r, lv.fmax - 1), gx = tx0 + 4 * c4;
-            if (gx + 3 < lv.fpitch) q[i] = *reinterpret_cast<const uint4*>(field + (size_t)gy * lv.fpitch + gx);
-            else {
-                const uint32_t* row = field + (size_t)gy * lv.fpitch;
-                q[i] = make_uint4(row[min(gx, lv.fpitch - 1)], row[min(gx + 1, lv.fpitch - 1)], row[min(gx + 2, lv.fpitch - 1)], row[min(gx + 3, lv.fpitch - 1)]);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = lane + 64 * i;
-            if (idx < POOL_W * 5) {
-                const int r = idx / 5, c = (idx - r * 5) * 4;
-                win[r][c] = q[i].x;
-                if (c + 1 < POOL_W) win[r][c + 1] = q[i].y;
-                if (c + 2 < POOL_W) win[r][c + 2] = q[i].z;
-                if (c + 3 < POOL_W) win[r][c + 3] = q[i].w;
-            }
-        }
-        __syncthreads();
-        for (int idx = lane; idx < POOL_W * BLUR_TILE; idx += 64) {
-            const int r = idx >> BLUR_SHIFT, c = idx & (BLUR_TILE - 1);
-            hm[r][c] = min(min(win[r][c], win[r][c + 1]), min(win[r][c + 2], win[r][c + 3]));
-        }
-        __syncthreads();
-        {
-            const int y = lane >> 2, ph = lane & 3;
-            uint32_t o[4];
-#pragma unroll
-            for (int X = 0; X < 4; ++X) {
-                const int c = 4 * X + ph;
-                o[X] = min(min(hm[y][c], hm[y + 1][c]), min(hm[y + 2][c], hm[y + 3][c]));
-            }
-            if (ty0 + y < lv.fmax && (tx0 >> 2) + 3 < ppitch)
-                *reinterpret_cast<uint4*>(pool + ((size_t)ph * lv.fmax + ty0 + y) * ppitch + (tx0 >> 2)) = make_uint4(o[0], o[1], o[2], o[3]);
-        }
-        __syncthreads();
-    }
-}
 
 // Blur of the work list: gridDim.x one-wave blocks per particle walk that particle's active tiles.
 template <int RAD>
 __global__ __launch_bounds__(BLUR_THREADS) void k_blur_clamp(Slam2dLevel lv) {
     __shared__ BlurLds<RAD> sm;
     const int p = blockIdx.y;
-    const int n = lv.tilecount[4 * p];
+    const int n = lv.tilecount[2 * p];
     if ((int)blockIdx.x >= n) return;
     const Slam2dFrame fr = lv.frames[p];
-    const int* list = lv.tilelist + (size_t)p * 4 * lv.tmax * lv.tmax;
+    const int* list = lv.tilelist + (size_t)p * 2 * lv.tmax * lv.tmax;
     for (int b = blockIdx.x; b < n; b += gridDim.x) {
         const int t = list[b];
         blur_tile<RAD>(lv, sm, p, fr, t / lv.tmax, t % lv.tmax, 0, false);
     }
 }
 
+// gmin2 (branch and bound): element [Y][X] = min(gmin[Y..Y+1][X..X+1]) >> 12 over the frame's blocks; `part` of
+// `parts` thread groups of `nthreads` threads each.  Blocks beyond the buffer are clamped (duplicates only).
+__device__ __forceinline__ void gmin2_pass(const Slam2dLevel& lv, const int p, const Slam2dFrame& fr, const int tid,
+                                           const int nthreads, const int part, const int parts) {
+    const int gp = lv.tmax << 2;
+    const int rows = min(gp, (fr.fh >> 2) + 2), cols = min(gp, (fr.fw >> 2) + 2);
+    const uint32_t* __restrict__ G = lv.gmin + (size_t)p * gp * gp;
+    uint32_t* __restrict__ G2 = lv.gmin2 + (size_t)p * gp * gp;
+    for (int idx = part * nthreads + tid; idx < rows * cols; idx += parts * nthreads) {
+        const int Y = idx / cols, X = idx - Y * cols;
+        const int Y1 = min(Y + 1, gp - 1), X1 = min(X + 1, gp - 1);
+        const uint32_t v = min(min(G[(size_t)Y * gp + X], G[(size_t)Y * gp + X1]), min(G[(size_t)Y1 * gp + X], G[(size_t)Y1 * gp + X1]));
+        G2[(size_t)Y * gp + X] = v >> 12;
+    }
+}
+
 // probMin (:43) = minimum over the per-tile minima; when it is not the analytic floor (rare: no cell
-// of the field has an all-free neighbourhood) the clamp is redone with it.  One wave per particle.
+// of the field has an all-free neighbourhood) the clamp is redone with it.  Block (p, 0) does that; with branch
+// and bound, blocks (p, 0 .. gridDim.y-1) also derive gmin2 from the block minima the blur just wrote -- all of them
+// at once when a free tile pins the minimum (frames[p].min_known, set by the triage: no redo can follow), block
+// (p, 0) alone after the check otherwise.
 template <int RAD>
 __global__ __launch_bounds__(256) void k_blur_check_redo(Slam2dLevel lv, uint32_t* flags) {
     __shared__ BlurLds<RAD> sm;
     __shared__ double red_s[4];
     const int p = blockIdx.x, tid = threadIdx.x;
     Slam2dFrame fr = lv.frames[p];
+    if (lv.bnb && fr.min_known) gmin2_pass(lv, p, fr, tid, 256, blockIdx.y, gridDim.y);
+    if (blockIdx.y != 0) return;
     {   // largest value any pose can read: free tiles hold the floor, the blurred ones recorded theirs
-        const int n = lv.tilecount[4 * p];
-        const int* list = lv.tilelist + (size_t)p * 4 * lv.tmax * lv.tmax;
+        const int n = lv.tilecount[2 * p];
+        const int* list = lv.tilelist + (size_t)p * 2 * lv.tmax * lv.tmax;
         double mx = lv.floor_value > 0.5 * lv.floor_value ? 0.0 : lv.floor_value;
         for (int i = tid; i < n; i += 256) mx = fmax(mx, lv.tilemax[(size_t)p * lv.tmax * lv.tmax + list[i]]);
         for (int o = 1; o < WAVE; o <<= 1) mx = fmax(mx, __shfl_xor(mx, o));
@@ -711,9 +678,14 @@ __global__ __launch_bounds__(256) void k_blur_check_redo(Slam2dLevel lv, uint32_
         lv.frames[p].field_min = m;
         if (m != lv.floor_value) { lv.frames[p].redo = 1; atomicOr(&flags[p], SLAM2D_F_FLOOR_REDO); }
     }
-    if (m == lv.floor_value || tid >= BLUR_THREADS) return;     // the redo itself is one wave's work
+    if (m == lv.floor_value) {                         // (block-uniform)
+        if (lv.bnb) gmin2_pass(lv, p, fr, tid, 256, 0, 1);
+        return;
+    }
+    if (tid >= BLUR_THREADS) return;                   // the redo itself is one wave's work
     fr.field_min = m;
     for (int t = 0; t < nty * ntx; ++t) blur_tile<RAD>(lv, sm, p, fr, t / ntx, t % ntx, 1, true);
+    if (lv.bnb) gmin2_pass(lv, p, fr, tid, BLUR_THREADS, 0, 1);
 }
 
 // ------------------------------------------------------------------------------------
@@ -894,10 +866,11 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
         atomicMin(&hown[h], tid * per + q);
         if (mark) {                                        // tiles of the (2 nc + 1)^2 patch at (x0, y0)
             const int y0 = key[q] / lv.fpitch, x0 = key[q] - y0 * lv.fpitch;
-            // branch and bound: the last pose tile's 4x4 pooling window reaches up to 3 cells beyond the patch
-            const int span = lv.bnb ? 4 * ((2 * nc + 4) >> 2) - 1 : 2 * nc;
-            const int tx0 = x0 >> BLUR_SHIFT, tx1 = min((x0 + span) >> BLUR_SHIFT, lv.tmax - 1);
-            for (int ty = y0 >> BLUR_SHIFT; ty <= min((y0 + span) >> BLUR_SHIFT, lv.tmax - 1); ++ty)
+            // branch and bound: gmin2 summarises the aligned 8x8 blocks around the 4x4 windows of the pose tiles, which
+            // reach from 3 cells before the patch to 4 * ceil(nx / 4) + 3 cells after its corner
+            const int lead = lv.bnb ? 3 : 0, span = lv.bnb ? 4 * ((2 * nc + 4) >> 2) + 3 : 2 * nc;
+            const int tx0 = max(x0 - lead, 0) >> BLUR_SHIFT, tx1 = min((x0 + span) >> BLUR_SHIFT, lv.tmax - 1);
+            for (int ty = max(y0 - lead, 0) >> BLUR_SHIFT; ty <= min((y0 + span) >> BLUR_SHIFT, lv.tmax - 1); ++ty)
                 for (int tx = tx0; tx <= tx1;) {           // runs of bits inside one 32-bit word
                     const int bit = ty * lv.tmax + tx;
                     const int len = min(tx1 - tx + 1, 32 - (bit & 31));
@@ -931,15 +904,15 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
     for (int w2 = 1; w2 <= wv; ++w2) pos += cnt_s[w2];
     int* out = lv.cells + ((size_t)p * lv.ntheta + it) * lv.kmax;
     int* pout = lv.bnb ? lv.pcells + ((size_t)p * lv.ntheta + it) * lv.kmax : nullptr;
-    const int ppitch = lv.fpitch >> 2;
+    const int gp = lv.tmax << 2;
 #pragma unroll
     for (int q = 0; q < SLAM2D_MAX_BEAMS / 256; ++q)
         if ((keep >> q) & 1) {
             if (pos < lv.kmax) {
                 out[pos] = key[q];
-                if (pout) {                                    // the same cell as a byte offset into the pooled planes
+                if (pout) {                                    // the block of the patch corner, as a byte offset into gmin2
                     const int y0 = key[q] / lv.fpitch, x0 = key[q] - y0 * lv.fpitch;
-                    pout[pos] = (((x0 & 3) * lv.fmax + y0) * ppitch + (x0 >> 2)) * 4;
+                    pout[pos] = ((y0 >> 2) * gp + (x0 >> 2)) * 4;
                 }
             }
             ++pos;
@@ -1359,15 +1332,15 @@ __global__ __launch_bounds__(64) void k_select(Slam2dLevel lv, int chunks, int R
 // ------------------------------------------------------------------------------------
 // K1e  branch and bound over 4x4 pose tiles (include/slam2d.h, "Branch and bound"): the same scores as k_sweep
 //      for every pose that can matter, from 1/16 of the gathers plus the exact scores of a few per cent of the tiles.
-//        k_bound   block = (particle, theta): upper bound U of every tile from the pooled cost planes (lane = one
-//                  pose-tile row x 4 consecutive tiles: one 16-byte load per cell and lane, the 4 waves split the
-//                  cell list); then the tile with the largest U is scored exactly and its best score raises
-//                  lv.bnb_best[p] (atomic max: order-independent, deterministic).
-//        k_exact   block = (particle, theta): every tile with U >= bnb_best - SLAM2D_PRUNE_MARGIN is scored exactly,
-//                  one wave per tile (lane = pose row x 1/16 of the cell list); the block leaves ONE partial
-//                  {max, argmax, sum exp} for its theta.
-//        k_select_bnb  arg-max / soft-max draw / confidence from the per-theta partials; the draw walks theta, then
-//                  pose rows, then the poses of a row -- the cube's C order, as np.random.choice's cdf does.
+//        blur / triage  write gmin (minimum of every aligned 4x4 block of the cost image) with the field tiles;
+//                  k_blur_check_redo derives gmin2 = min over 2x2 blocks (>> 12): a lower bound of the cost anywhere
+//                  in the aligned 8x8 block that contains a pose tile's 4x4 window at a cell.
+//        k_bound   one wave per (particle, theta): upper bound U of every tile (lane = one pose-tile row x 4
+//                  consecutive tiles: ONE 16-byte load per cell from an image 1/16 the size of the field, 16 in
+//                  flight, plain 32-bit adds); then the tile with the largest U is scored exactly and its best
+//                  score raises lv.bnb_best[p] (atomic max: order-independent, deterministic).
+//        k_exact   one wave per (particle, theta): every tile with U >= bnb_best - SLAM2D_PRUNE_MARGIN is scored
+//                  exactly (lane = pose row x 1/16 of the cell list); ONE partial {max, argmax, sum exp} per theta.
 // ------------------------------------------------------------------------------------
 struct Running { double m, s; int arg, nan; };
 __device__ __forceinline__ void running_merge(Running& a, const double tm, const double ts, const int targ, const int tnan) {
@@ -1388,18 +1361,62 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
 // exact cost sums of the 16 poses of tile (by, bx): lane = (pose row r = lane / 16, cell slice s = lane % 16) scores
 // the 4 poses (4 by + r, 4 bx .. 4 bx + 3) against cells k0 + s, k0 + s + kstep, ...; on return every lane of a
 // row group holds the row's 4 sums over ALL the cells this wave walked (reduced over the 16 slices).
-#define EXACT_DEPTH 4
+#define EXACT_DEPTH 8
+// sum over the 16 lanes of a DPP row, in every lane of the row: quad butterflies, then the two mirrors (no LDS
+// crossbar round trips: a ds_bpermute butterfly of 4 x 64-bit values costs ~1 us in a lone wave)
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_u64(const unsigned long long v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, 0xF, 0xF, true);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long row16_sum_u64(unsigned long long t) {
+    t += dpp_u64<0xB1>(t);           // quad_perm [1, 0, 3, 2]
+    t += dpp_u64<0x4E>(t);           // quad_perm [2, 3, 0, 1]
+    t += dpp_u64<0x141>(t);          // row_half_mirror
+    t += dpp_u64<0x140>(t);          // row_mirror
+    return t;
+}
+// the same for a double (returned as its bits): used for the 16 exp(score - M) of a tile
+__device__ __forceinline__ unsigned long long row16_sum_f64(double v) {
+    v += __longlong_as_double((long long)dpp_u64<0xB1>((unsigned long long)__double_as_longlong(v)));
+    v += __longlong_as_double((long long)dpp_u64<0x4E>((unsigned long long)__double_as_longlong(v)));
+    v += __longlong_as_double((long long)dpp_u64<0x141>((unsigned long long)__double_as_longlong(v)));
+    v += __longlong_as_double((long long)dpp_u64<0x140>((unsigned long long)__double_as_longlong(v)));
+    return (unsigned long long)__double_as_longlong(v);
+}
+// byte offsets of the first NPRE cells of lane slice s (cells s, s + 16, ...), beyond-the-buffer where the list ends
+template <int NPRE>
+__device__ __forceinline__ void tile_prefetch(const int* __restrict__ cl, const int K, int (&pre)[NPRE]) {
+    const int s = threadIdx.x & 15;
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) pre[i] = s + 16 * i < K ? cl[s + 16 * i] * 4 : 0x7ffffff0;
+}
+template <int NPRE>
 __device__ __forceinline__ void tile_exact(const Slam2dLevel& lv, const __amdgpu_buffer_rsrc_t rsrc, const int* __restrict__ cl,
-                                           const int K, const int by, const int bx, const int k0, const int kstep,
+                                           const int K, const int by, const int bx, const int (&pre)[NPRE],
                                            unsigned long long (&acc)[4]) {
     const int lane = threadIdx.x & 63, r = lane >> 4, s = lane & 15;
     const int lanepart = ((4 * by + r) * lv.fpitch + 4 * bx) * 4;
     unsigned lo[4] = {0u, 0u, 0u, 0u}, hi[4] = {0u, 0u, 0u, 0u};
-    for (int k = k0 + s; k < K; k += EXACT_DEPTH * kstep) {
+    {
+        u32x4 v[NPRE];
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lanepart + pre[i], 0, 0);
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned s2 = lo[e] + v[i][e];
+                hi[e] += s2 < v[i][e] ? 1u : 0u;
+                lo[e] = s2;
+            }
+    }
+    for (int k = s + 16 * NPRE; k < K; k += EXACT_DEPTH * 16) {            // longer lists
         int off[EXACT_DEPTH];
 #pragma unroll
         for (int i = 0; i < EXACT_DEPTH; ++i) {
-            const int kk = k + i * kstep;
+            const int kk = k + i * 16;
             off[i] = kk < K ? lanepart + cl[kk] * 4 : 0x7ffffff0;      // beyond the buffer: reads zeros
         }
         u32x4 v[EXACT_DEPTH];
@@ -1415,239 +1432,355 @@ __device__ __forceinline__ void tile_exact(const Slam2dLevel& lv, const __amdgpu
             }
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        unsigned long long t = ((unsigned long long)hi[e] << 32) | lo[e];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) t += shfl_xor_u64(t, o);
-        acc[e] = t;
-    }
+    for (int e = 0; e < 4; ++e) acc[e] = row16_sum_u64(((unsigned long long)hi[e] << 32) | lo[e]);
 }
 
-__global__ __launch_bounds__(256) void k_bound(Slam2dLevel lv, int P) {
-    __shared__ unsigned long long part_s[3][4][WAVE];
-    __shared__ unsigned long long ex_s[4][16];
-    __shared__ int seed_s;
+// One wave per (particle, theta); blocks of a particle pinned to one XCD like the sweep's.  Lane = one pose-tile row
+// x 4 consecutive tiles: ONE 16-byte load per cell.  The loop is bound by the texture path's 16 clocks per wave
+// instruction (a dword-per-tile mapping needs two instructions per cell and measured 2x slower), so what counts
+// is the instruction count, 1/8 of the brute-force sweep's.  The cell list is read 64 cells at a time, one per
+// lane, and handed to the loads with v_readlane: no scalar-memory round trip per batch.
+#define BOUND_BATCH 32
+__global__ __launch_bounds__(64) void k_bound(Slam2dLevel lv, int P) {
     const int b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
     const int p = (slot / lv.ntheta) * 8 + xcd, it = slot % lv.ntheta;
     if (p >= P) return;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int lane = threadIdx.x;
     const int nx = 2 * lv.ncell + 1, npose = nx * nx;
     const int nbt = (nx + 3) >> 2, nq = (nbt + 3) >> 2, nbq4 = nq << 2;
-    const int ppitch = lv.fpitch >> 2;
+    const int gp = lv.tmax << 2;
     const int K = lv.kcount[p * lv.ntheta + it];
-    const size_t image = (size_t)lv.fmax * lv.fpitch;
     const int* __restrict__ pcl = lv.pcells + ((size_t)p * lv.ntheta + it) * lv.kmax;
-    const __amdgpu_buffer_rsrc_t rpool = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(lv.pool + (size_t)p * image), (short)0, (int)(image * sizeof(uint32_t)), 0x00020000);
+    const int* __restrict__ cl = lv.cells + ((size_t)p * lv.ntheta + it) * lv.kmax;
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(lv.gmin2 + (size_t)p * gp * gp), (short)0, (int)((size_t)gp * gp * sizeof(uint32_t)), 0x00020000);
+    DBG_CLOCK(0, b == 0);
     const bool active = lane < nbt * nq;
     const int by = lane / nq, q = lane - by * nq;
-    const int voff = active ? ((4 * by) * ppitch + 4 * q) * 4 : 0x7ffffff0;
-    unsigned lo[4] = {0u, 0u, 0u, 0u}, hi[4] = {0u, 0u, 0u, 0u};
-    int k = wave;
-    for (; k + 12 < K; k += 16) {                          // 4 loads in flight per wave
-        const int c0 = pcl[k], c1 = pcl[k + 4], c2 = pcl[k + 8], c3 = pcl[k + 12];
-        const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rpool, voff, c0, 0);
-        const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rpool, voff, c1, 0);
-        const u32x4 v2 = __builtin_amdgcn_raw_buffer_load_b128(rpool, voff, c2, 0);
-        const u32x4 v3 = __builtin_amdgcn_raw_buffer_load_b128(rpool, voff, c3, 0);
+    const int voff = active ? (by * gp + 4 * q) * 4 : 0x7ffffff0;
+    const double* __restrict__ pm = lv.tile_pmax + (size_t)p * nbt * nbq4;
+    double pmx[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pmx[e] = active ? pm[by * nbq4 + 4 * q + e] : -INFINITY;     // in flight during the loop
+    int pre[16];
+    tile_prefetch<16>(cl, K, pre);                          // for the seed tile below: likewise
+    unsigned sum[4] = {0u, 0u, 0u, 0u};                    // 20-bit values, <= 2048 cells: no carry
+    int cv = lane < K ? pcl[lane] : 0x7ffffff0;
+    for (int base = 0; base < K; base += WAVE) {
+        const int cur = cv;
+        if (base + WAVE < K) cv = base + WAVE + lane < K ? pcl[base + WAVE + lane] : 0x7ffffff0;     // next 64 cells
+#pragma unroll
+        for (int j0 = 0; j0 < WAVE; j0 += BOUND_BATCH) {
+            if (base + j0 < K) {                            // (wave-uniform)
+                u32x4 v[BOUND_BATCH];
+#pragma unroll
+                for (int i = 0; i < BOUND_BATCH; ++i)
+                    v[i] = __builtin_amdgcn_raw_buffer_load_b128(rg, voff, __builtin_amdgcn_readlane(cur, j0 + i), 0);
+#pragma unroll
+                for (int i = 0; i < BOUND_BATCH; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sum[e] += v[i][e];
+            }
+        }
+    }
+    DBG_CLOCK(1, b == 0);
+    const double inv = 1.0 / lv.cost_scale;
+    double* __restrict__ bnd = lv.bounds + ((size_t)p * lv.ntheta + it) * nbt * nbq4;
+    Best me{-INFINITY, INT_MAX, 0};
+    if (active) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            unsigned s2 = lo[e] + v0[e]; hi[e] += s2 < v0[e] ? 1u : 0u; lo[e] = s2;
-            s2 = lo[e] + v1[e]; hi[e] += s2 < v1[e] ? 1u : 0u; lo[e] = s2;
-            s2 = lo[e] + v2[e]; hi[e] += s2 < v2[e] ? 1u : 0u; lo[e] = s2;
-            s2 = lo[e] + v3[e]; hi[e] += s2 < v3[e] ? 1u : 0u; lo[e] = s2;
+            const int t = by * nbq4 + 4 * q + e;
+            // every pose of the tile scores (-(cost sum) / scale + rv) + thetaWeight <= -L / scale + max(rv + thetaWeight),
+            // L = (sum of the block minima >> 12) << 12; 1e-9 covers the different association of the roundings;
+            // padding tiles (4 q + e >= nbt) come out as -inf (their tile_pmax is)
+            const double U = (-(((double)sum[e] * 4096.0) * inv) + pmx[e]) + 1e-9;
+            bnd[t] = U;
+            Best cand{U, t, 0};
+            if (4 * q + e < nbt && better(cand, me)) me = cand;
         }
     }
-    for (; k < K; k += 4) {
-        const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rpool, voff, pcl[k], 0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { const unsigned s2 = lo[e] + v0[e]; hi[e] += s2 < v0[e] ? 1u : 0u; lo[e] = s2; }
-    }
-    if (wave > 0) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) part_s[wave - 1][e][lane] = ((unsigned long long)hi[e] << 32) | lo[e];
-    }
-    __syncthreads();
-    if (wave == 0) {
-        const double inv = 1.0 / lv.cost_scale;
-        const double* __restrict__ pm = lv.tile_pmax + (size_t)p * nbt * nbq4;
-        double* __restrict__ bnd = lv.bounds + ((size_t)p * lv.ntheta + it) * nbt * nbq4;
-        Best me{-INFINITY, INT_MAX, 0};
-        if (active) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const unsigned long long L = (((unsigned long long)hi[e] << 32) | lo[e]) + part_s[0][e][lane] + part_s[1][e][lane] + part_s[2][e][lane];
-                const int t = by * nbq4 + 4 * q + e;
-                // every pose of the tile scores (-(cost sum) / scale + rv) + thetaWeight <= -L / scale + max(rv + thetaWeight);
-                // 1e-9 covers the different association of the two roundings (scores are O(100))
-                const double U = (-((double)L * inv) + pm[t]) + 1e-9;
-                bnd[t] = U;
-                Best cand{U, t, 0};
-                if (4 * q + e < nbt && better(cand, me)) me = cand;
-            }
-        }
-        me = wave_best(me);
-        if (lane == 0) seed_s = me.i;
-    }
-    __syncthreads();
-    // the seed tile, exactly: its best score is a lower bound of the cube's maximum
-    const int seed = seed_s;
+    me = wave_best(me);
+    DBG_CLOCK(2, b == 0);
+    // the tile with the largest bound, exactly: its best score is a lower bound of the cube's maximum
+    const int seed = me.i;
     const int sby = seed / nbq4, sbx = seed - sby * nbq4;
-    const uint32_t* __restrict__ F = lv.field + (size_t)p * image;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)F, (short)0, (int)(image * sizeof(uint32_t)), 0x00020000);
-    const int* __restrict__ cl = lv.cells + ((size_t)p * lv.ntheta + it) * lv.kmax;
-    unsigned long long acc[4];
-    tile_exact(lv, rsrc, cl, K, sby, sbx, wave * 16, 64, acc);
-    if ((lane & 15) == 0) {
+    const int dy = 4 * sby + (lane >> 4);
+    const bool leader = (lane & 15) == 0 && dy < nx;
+    const double* __restrict__ pr = lv.prior + (size_t)p * 2 * npose;
+    double prv[4], ptw[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ex_s[wave][(lane >> 4) * 4 + e] = acc[e];
+    for (int e = 0; e < 4; ++e) {                           // issued ahead of the tile's field loads
+        const int qq = min(dy, nx - 1) * nx + min(4 * sbx + e, nx - 1);
+        prv[e] = pr[qq]; ptw[e] = pr[npose + qq];
     }
-    __syncthreads();
-    if (wave == 0) {
-        double val = -INFINITY;
-        if (lane < 16) {
-            const int dy = 4 * sby + (lane >> 2), dx = 4 * sbx + (lane & 3);
-            if (dy < nx && dx < nx) {
-                const unsigned long long tot = ex_s[0][lane] + ex_s[1][lane] + ex_s[2][lane] + ex_s[3][lane];
-                const double* __restrict__ pr = lv.prior + (size_t)p * 2 * npose;
-                const int qq = dy * nx + dx;
-                const double sc = (-((double)tot * (1.0 / lv.cost_scale)) + pr[qq]) + pr[npose + qq];
-                if (!isnan(sc)) val = sc;
-            }
-        }
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) val = fmax(val, __shfl_xor(val, o));
-        if (lane == 0 && val > -INFINITY) atomicMax(&lv.bnb_best[p], order_bits(val));
-    }
-}
-
-__global__ __launch_bounds__(256) void k_exact(Slam2dLevel lv, int P) {
-    __shared__ short kept_s[256];
-    __shared__ int cnt_s[4];
-    __shared__ Running run_s[4];
-    const int b = blockIdx.x;
-    const int xcd = b & 7, slot = b >> 3;
-    const int p = (slot / lv.ntheta) * 8 + xcd, it = slot % lv.ntheta;
-    if (p >= P) return;
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int nx = 2 * lv.ncell + 1, npose = nx * nx;
-    const int nbt = (nx + 3) >> 2, nbq4 = ((nbt + 3) >> 2) << 2;
-    const double thr = unorder_bits(lv.bnb_best[p]) - SLAM2D_PRUNE_MARGIN;
-    const double* __restrict__ bnd = lv.bounds + ((size_t)p * lv.ntheta + it) * nbt * nbq4;
-    bool keep = false;
-    if (tid < nbt * nbq4) keep = (tid % nbq4) < nbt && bnd[tid] >= thr;
-    const unsigned long long mask = __ballot(keep);
-    if (lane == 0) cnt_s[wave] = __popcll(mask);
-    __syncthreads();
-    int pos = __popcll(mask & (lane ? (~0ull >> (64 - lane)) : 0ull));
-    for (int w2 = 0; w2 < wave; ++w2) pos += cnt_s[w2];
-    if (keep) kept_s[pos] = (short)tid;
-    const int nk = cnt_s[0] + cnt_s[1] + cnt_s[2] + cnt_s[3];
-    __syncthreads();
-    const int K = lv.kcount[p * lv.ntheta + it];
     const size_t image = (size_t)lv.fmax * lv.fpitch;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(lv.field + (size_t)p * image), (short)0, (int)(image * sizeof(uint32_t)), 0x00020000);
-    const int* __restrict__ cl = lv.cells + ((size_t)p * lv.ntheta + it) * lv.kmax;
-    const double* __restrict__ pr = lv.prior + (size_t)p * 2 * npose;
-    double* __restrict__ cube = lv.cube + ((size_t)p * lv.ntheta + it) * npose;
-    const double inv = 1.0 / lv.cost_scale;
-    Running run{-INFINITY, 0.0, INT_MAX, 0};
-    for (int j = wave; j < nk; j += 4) {
-        const int t = kept_s[j];
-        const int by = t / nbq4, bx = t - by * nbq4;
-        unsigned long long acc[4];
-        tile_exact(lv, rsrc, cl, K, by, bx, 0, 16, acc);
-        const int dy = 4 * by + (lane >> 4);
-        double sc[4];
-        Best me{-INFINITY, INT_MAX, 0};
-        const bool leader = (lane & 15) == 0 && dy < nx;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            sc[e] = -INFINITY;
-            const int dx = 4 * bx + e;
-            if (leader && dx < nx) {
-                const int qq = dy * nx + dx;
-                sc[e] = (-((double)acc[e] * inv) + pr[qq]) + pr[npose + qq];              // :131, as k_sweep
-                cube[qq] = sc[e];
-                Best cand{sc[e], it * npose + qq, isnan(sc[e]) ? 1 : 0};
-                if (better(cand, me)) me = cand;
-            }
-        }
-        me = wave_best(me);
-        double ex = 0.0;
+    unsigned long long acc[4];
+    tile_exact<16>(lv, rsrc, cl, K, sby, sbx, pre, acc);
+    double val = -INFINITY;
+    if (leader) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (leader && 4 * bx + e < nx) ex += exp(sc[e] - me.v);
-        ex = wave_sum(ex);
-        running_merge(run, me.v, ex, me.i, me.nan);
+            if (4 * sbx + e < nx) {
+                const double sc = (-((double)acc[e] * inv) + prv[e]) + ptw[e];
+                if (!isnan(sc)) val = fmax(val, sc);
+            }
     }
-    if (lane == 0) run_s[wave] = run;
-    __syncthreads();
-    if (tid == 0) {
-        Running r = run_s[0];
-        for (int w2 = 1; w2 < 4; ++w2) running_merge(r, run_s[w2].m, run_s[w2].s, run_s[w2].arg, run_s[w2].nan);
-        Slam2dPartial pt;
-        pt.max = r.m; pt.sumexp = r.s; pt.argmax = r.arg; pt.has_nan = r.nan;
-        lv.partials[(size_t)p * lv.npartial + it] = pt;
-    }
+    val = fmax(val, __shfl_xor(val, 16));
+    val = fmax(val, __shfl_xor(val, 32));
+    DBG_CLOCK(3, b == 0);
+    if (lane == 0 && val > -INFINITY) atomicMax(&lv.bnb_best[p], order_bits(val));
+    DBG_CLOCK(4, b == 0);
 }
 
-__global__ __launch_bounds__(64) void k_select_bnb(Slam2dLevel lv, const double* __restrict__ est, int estride,
-                                                   const double* __restrict__ uniform, Slam2dMatch* out) {
-    const int p = blockIdx.x, lane = threadIdx.x;
+// One block per particle: the tiles whose bound reaches bnb_best - SLAM2D_BNB_MARGIN, exactly, then the selection
+// (np.argmax / np.random.choice / confidence, :133-143).  Everything serial in a single wave is slow here (an fp64
+// exp is ~0.25 us when no other wave hides its latency, a vector-memory instruction costs the CU 16 clocks), so
+// every stage is spread over the block and the tile loop issues as few memory instructions as it can:
+//   scan     thread = consecutive (theta, tile) bounds; block-wide exclusive scan of the survivor counts -> an
+//            ascending list of surviving tiles (= cube order of theta, then tile row, then tile column); meanwhile the
+//            particle's cell lists are staged in LDS (when they fit)
+//   tiles    one tile per wave, 16 waves at a time: lane = pose row x 1/16 of the cell list, 16-byte field loads,
+//            DPP row sums; 16 lanes add the priors and store the scores (level->cube and LDS)
+//   max      thread = scored pose -> block reduction -> the maximum M (np.argmax order: first NaN, else largest,
+//            lowest index)
+//   exp      thread = scored pose: exp(score - M) -> LDS; DPP row sums per tile; the first tile of every theta adds
+//            up the theta's tiles
+//   select   wave 0: cdf over theta, then over the pose rows of the chosen theta, then along the row
+// More than XS_TILES surviving tiles (rare) are handled in passes; the row walk then re-reads the cube.
+#define XS_THREADS 1024
+#define XS_TILES 256
+#define XS_MAX_PER 32
+#define XS_CELLS 8192                // cell-list entries staged in LDS (ntheta * kmax: config 2 6480, reference 5400)
+#define SLAM2D_BNB_MAX_THETA 256
+__global__ __launch_bounds__(XS_THREADS) void k_exact_select(Slam2dLevel lv, const double* __restrict__ est, int estride,
+                                                             const double* __restrict__ uniform, Slam2dMatch* out) {
+    __shared__ int list_s[XS_TILES];                   // theta << 8 | tile, ascending
+    __shared__ double sc_s[XS_TILES][16];              // a tile's scores (row-major 4 x 4, -inf = no pose), then exp(score - M)
+    __shared__ double tsum_s[XS_TILES], tmax_s[XS_TILES];
+    __shared__ int targ_s[XS_TILES], tnan_s[XS_TILES];
+    __shared__ double S_s[SLAM2D_BNB_MAX_THETA];       // sum over the theta's scored poses of exp(score - M)
+    __shared__ int kc_s[SLAM2D_BNB_MAX_THETA], j0_s[SLAM2D_BNB_MAX_THETA], jn_s[SLAM2D_BNB_MAX_THETA];
+    __shared__ int cells_s[XS_CELLS];
+    __shared__ int wtot_s[XS_THREADS / WAVE];
+    __shared__ double wbv_s[XS_THREADS / WAVE];
+    __shared__ int wbi_s[XS_THREADS / WAVE], wbn_s[XS_THREADS / WAVE];
+    __shared__ double M_s[2];                          // [0] running maximum, [1] the one before this pass
+    __shared__ int Mi_s[2];                            // its flat index, nan flag
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int nx = 2 * lv.ncell + 1, npose = nx * nx;
-    const int nbt = (nx + 3) >> 2, nbq4 = ((nbt + 3) >> 2) << 2;
-    const int nW = lv.ntheta;
-    const Slam2dPartial* __restrict__ pt = lv.partials + (size_t)p * lv.npartial;
-    Best me{-INFINITY, INT_MAX, 0};
-    for (int w = lane; w < nW; w += WAVE) {
-        Best cand{pt[w].max, pt[w].argmax, pt[w].has_nan};
-        if (pt[w].argmax != INT_MAX && better(cand, me)) me = cand;
+    const int nbt = (nx + 3) >> 2, nbq4 = ((nbt + 3) >> 2) << 2, nt = nbt * nbq4;
+    const int ntot = lv.ntheta * nt;
+    const double thr = unorder_bits(lv.bnb_best[p]) - SLAM2D_BNB_MARGIN;
+    const double* __restrict__ bnd = lv.bounds + (size_t)p * ntot;
+    DBG_CLOCK(8, p == 0);
+    // ---- scan ----
+    const int per = (ntot + XS_THREADS - 1) / XS_THREADS;          // <= XS_MAX_PER (checked by the host)
+    const int g0 = tid * per;
+    unsigned keepbits = 0u;
+    for (int i = 0; i < per; ++i) {
+        const int g = g0 + i;
+        if (g < ntot && bnd[g] >= thr) keepbits |= 1u << i;        // (padding tiles hold -inf)
     }
-    me = wave_best(me);
-    const double M = me.v;
-    const int per = (nW + WAVE - 1) / WAVE;
-    const int w0 = lane * per, w1 = min(nW, w0 + per);
-    double mine = 0.0;
-    for (int w = w0; w < w1; ++w) if (pt[w].argmax != INT_MAX) mine += pt[w].sumexp * exp(pt[w].max - M);
-    double incl = mine;
+    const bool cells_in_lds = lv.ntheta * lv.kmax <= XS_CELLS;
+    if (cells_in_lds) {
+        const int* __restrict__ call = lv.cells + (size_t)p * lv.ntheta * lv.kmax;
+        for (int i = tid; i < lv.ntheta * lv.kmax; i += XS_THREADS) cells_s[i] = call[i];
+    }
+    const int cnt = __popc(keepbits);
+    int incl = cnt;
 #pragma unroll
     for (int o = 1; o < WAVE; o <<= 1) {
-        const double up = __shfl_up(incl, o);
+        const int up = __shfl_up(incl, o);
         if (lane >= o) incl += up;
     }
-    const double total = __shfl(incl, WAVE - 1);
-    int pick = me.i;
+    if (lane == WAVE - 1) wtot_s[wave] = incl;
+    if (tid < lv.ntheta) { kc_s[tid] = lv.kcount[p * lv.ntheta + tid]; S_s[tid] = 0.0; }
+    if (tid == 0) { M_s[0] = -INFINITY; Mi_s[0] = INT_MAX; Mi_s[1] = 0; }
+    __syncthreads();
+    int off = incl - cnt, n_all = 0;
+    for (int w2 = 0; w2 < XS_THREADS / WAVE; ++w2) { const int c = wtot_s[w2]; if (w2 < wave) off += c; n_all += c; }
+    DBG_CLOCK(9, p == 0);
+    const size_t image = (size_t)lv.fmax * lv.fpitch;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(lv.field + (size_t)p * image), (short)0, (int)(image * sizeof(uint32_t)), 0x00020000);
+    const double* __restrict__ pr = lv.prior + (size_t)p * 2 * npose;
+    const double inv = 1.0 / lv.cost_scale;
+    int n = 0;
+    for (int base = 0; base < n_all; base += XS_TILES) {           // (block-uniform)
+        n = min(XS_TILES, n_all - base);
+        {
+            int o = off;
+            for (int i = 0; i < per; ++i)
+                if ((keepbits >> i) & 1u) {
+                    if (o >= base && o < base + XS_TILES) { const int g = g0 + i; list_s[o - base] = ((g / nt) << 8) | (g % nt); }
+                    ++o;
+                }
+        }
+        if (tid < lv.ntheta) jn_s[tid] = 0;
+        __syncthreads();
+        DBG_CLOCK(10, p == 0 && base == 0);
+        // ---- tiles ----
+        for (int j = wave; j < n; j += XS_THREADS / WAVE) {
+            const int ent = list_s[j];
+            const int it = ent >> 8, t = ent & 255;
+            const int by = t / nbq4, bx = t - by * nbq4;
+            const int K = kc_s[it];
+            const int* __restrict__ cl = lv.cells + ((size_t)p * lv.ntheta + it) * lv.kmax;
+            int pre[12];
+            if (cells_in_lds) {
+                const int* cs = cells_s + it * lv.kmax;
+                const int sl = lane & 15;
+#pragma unroll
+                for (int i = 0; i < 12; ++i) pre[i] = sl + 16 * i < K ? cs[sl + 16 * i] * 4 : 0x7ffffff0;
+            } else {
+                tile_prefetch<12>(cl, K, pre);
+            }
+            // the 16 scoring lanes (16 r + e: pose row r, column e of the tile) fetch their pose's priors now
+            const int r = lane >> 4, e = lane & 15;
+            const int dy = 4 * by + r, dx = 4 * bx + e;
+            const bool scorer = e < 4 && dy < nx && dx < nx;
+            const int qq = dy * nx + dx;
+            double prv = 0.0, ptw = 0.0;
+            if (scorer) { prv = pr[qq]; ptw = pr[npose + qq]; }
+            unsigned long long acc[4];
+            tile_exact<12>(lv, rsrc, cl, K, by, bx, pre, acc);
+            double sc = -INFINITY;
+            if (e < 4) {
+                const unsigned long long a = e == 0 ? acc[0] : e == 1 ? acc[1] : e == 2 ? acc[2] : acc[3];
+                if (scorer) {
+                    sc = (-((double)a * inv) + prv) + ptw;                                    // :131, as k_sweep
+                    lv.cube[((size_t)p * lv.ntheta + it) * npose + qq] = sc;
+                }
+                sc_s[j][r * 4 + e] = sc;
+            }
+            // the tile's maximum in np.argmax order (first NaN, else largest, lowest index): the scoring lanes 16 r + e
+            // ascend with the flat pose index, so "lowest index" = lowest lane.  Quad butterflies, then the four rows.
+            double mq = scorer && !isnan(sc) ? sc : -INFINITY;
+            mq = fmax(mq, __longlong_as_double((long long)dpp_u64<0xB1>((unsigned long long)__double_as_longlong(mq))));
+            mq = fmax(mq, __longlong_as_double((long long)dpp_u64<0x4E>((unsigned long long)__double_as_longlong(mq))));
+            const double tmx = fmax(fmax(__shfl(mq, 0), __shfl(mq, 16)), fmax(__shfl(mq, 32), __shfl(mq, 48)));
+            const unsigned long long nanm = __ballot(scorer && isnan(sc));
+            const unsigned long long eqm = nanm ? nanm : __ballot(scorer && sc == tmx);
+            if (lane == 0) {
+                int arg = INT_MAX;
+                if (eqm) {
+                    const int l = __ffsll((long long)eqm) - 1;
+                    arg = it * npose + (4 * by + (l >> 4)) * nx + 4 * bx + (l & 15);
+                }
+                tmax_s[j] = nanm ? NAN : tmx; targ_s[j] = arg; tnan_s[j] = nanm ? 1 : 0;
+            }
+        }
+        __syncthreads();
+        DBG_CLOCK(11, p == 0 && base == 0);
+        // ---- maximum ----
+        {
+            if (wave < XS_TILES / WAVE) {                // thread = tile
+                Best bme{-INFINITY, INT_MAX, 0};
+                if (tid < n && targ_s[tid] != INT_MAX) bme = Best{tmax_s[tid], targ_s[tid], tnan_s[tid]};
+                bme = wave_best(bme);
+                if (lane == 0) { wbv_s[wave] = bme.v; wbi_s[wave] = bme.i; wbn_s[wave] = bme.nan; }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                Best rbest{M_s[0], Mi_s[0], Mi_s[1]};
+                M_s[1] = M_s[0];
+                for (int w2 = 0; w2 < XS_TILES / WAVE; ++w2) {
+                    Best c{wbv_s[w2], wbi_s[w2], wbn_s[w2]};
+                    if (c.i != INT_MAX && better(c, rbest)) rbest = c;
+                }
+                M_s[0] = rbest.v; Mi_s[0] = rbest.i; Mi_s[1] = rbest.nan;
+            }
+            __syncthreads();
+        }
+        const double M = M_s[0];
+        DBG_CLOCK(29, p == 0 && base == 0);
+        // ---- exp ----
+        if (base > 0 && tid < lv.ntheta) S_s[tid] *= exp(M_s[1] - M);       // earlier passes: rescale to the new maximum
+        for (int i0 = 0; i0 < n * 16; i0 += XS_THREADS) {                   // (block-uniform trip count)
+            const int idx = i0 + tid;
+            double ev = 0.0;
+            if (idx < n * 16) {
+                const double sc = sc_s[idx >> 4][idx & 15];
+                ev = sc == -INFINITY ? 0.0 : exp(sc - M);
+                sc_s[idx >> 4][idx & 15] = ev;
+            }
+            const unsigned long long tb = row16_sum_f64(ev);
+            if (idx < n * 16 && (idx & 15) == 0) tsum_s[idx >> 4] = __longlong_as_double((long long)tb);
+        }
+        __syncthreads();
+        DBG_CLOCK(30, p == 0 && base == 0);
+        if (tid < n) {                                  // the first tile of a theta adds up the theta's tiles, in list order
+            const int th = list_s[tid] >> 8;
+            if (tid == 0 || (list_s[tid - 1] >> 8) != th) {
+                double a = 0.0;
+                int k = tid;
+                for (; k < n && (list_s[k] >> 8) == th; ++k) a += tsum_s[k];
+                S_s[th] += a;
+                j0_s[th] = tid; jn_s[th] = k - tid;
+            }
+        }
+        __syncthreads();
+        DBG_CLOCK(12, p == 0 && base == 0);
+    }
+    if (wave != 0) return;
+    // ---- selection (wave 0) ----
+    const double M = M_s[0];
+    const int nW = lv.ntheta;
+    const int tper = (nW + WAVE - 1) / WAVE;
+    const int w0 = lane * tper, w1 = min(nW, w0 + tper);
+    double mine = 0.0;
+    for (int w = w0; w < w1; ++w) mine += S_s[w];
+    double cinc = mine;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const double up = __shfl_up(cinc, o);
+        if (lane >= o) cinc += up;
+    }
+    const double total = __shfl(cinc, WAVE - 1);
+    int pick = Mi_s[0];
     if (uniform != nullptr && !isnan(total)) {
         // np.random.choice(n, 1, p): first index whose normalised cdf exceeds u (:137-138); the poses that were not
-        // scored carry < 1e-12 of the mass
+        // scored carry < 1e-8 of the mass
         const double target = uniform[p] * total;
-        const unsigned long long ahead = __ballot(incl > target);
+        const unsigned long long ahead = __ballot(cinc > target);
         const int lsel = ahead ? __ffsll((long long)ahead) - 1 : WAVE - 1;
-        double run = __shfl(incl - mine, lsel);
-        const int s0 = min(lsel * per, nW - 1), s1 = max(s0 + 1, min(nW, lsel * per + per));
+        double run = __shfl(cinc - mine, lsel);
+        const int s0 = min(lsel * tper, nW - 1), s1 = max(s0 + 1, min(nW, lsel * tper + tper));
         int it = s1 - 1;
         for (int w = s0; w < s1; ++w) {                           // wave-uniform loop
-            const double t = pt[w].argmax != INT_MAX ? pt[w].sumexp * exp(pt[w].max - M) : 0.0;
+            const double t = S_s[w];
             if (run + t > target || w == s1 - 1) { it = w; break; }
             run += t;
         }
-        while (it > 0 && pt[it].argmax == INT_MAX) --it;         // rounding fallback landed on an empty theta
-        const double thr = unorder_bits(lv.bnb_best[p]) - SLAM2D_PRUNE_MARGIN;
-        const double* __restrict__ bnd = lv.bounds + ((size_t)p * lv.ntheta + it) * nbt * nbq4;
-        const double* __restrict__ c = lv.cube + ((size_t)p * lv.ntheta + it) * npose;
-        // lane = pose row dy (nx <= 64): the row's scored poses in dx order
+        while (it > 0 && !(S_s[it] > 0.0)) --it;                 // rounding fallback landed on a theta without a scored pose
+        const int by = lane >> 2, rr = lane & 3;
+        const bool in_lds = n_all <= XS_TILES;
+        const int ja = in_lds ? j0_s[it] : 0, jb = in_lds ? ja + jn_s[it] : 0;
         double lsum = 0.0;
         bool has = false;
-        if (lane < nx) {
-            const int by = lane >> 2;
-            for (int bx = 0; bx < nbt; ++bx)
-                if (bnd[by * nbq4 + bx] >= thr) {
-                    has = true;
-                    for (int e = 0; e < 4 && 4 * bx + e < nx; ++e) lsum += exp(c[lane * nx + 4 * bx + e] - M);
-                }
+        if (in_lds) {
+            // the theta's tiles are in LDS: lane = pose row dy, its poses in dx order (tiles ascend with bx)
+            if (lane < nx)
+                for (int j = ja; j < jb; ++j)
+                    if ((list_s[j] & 255) / nbq4 == by) {
+                        has = true;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) lsum += sc_s[j][rr * 4 + e];
+                    }
+        } else {
+            const double* c = lv.cube + ((size_t)p * lv.ntheta + it) * npose;
+            const double* bt = bnd + (size_t)it * nt;
+            if (lane < nx)
+                for (int bx = 0; bx < nbt; ++bx)
+                    if (bt[by * nbq4 + bx] >= thr) {
+                        has = true;
+                        for (int e = 0; e < 4 && 4 * bx + e < nx; ++e) lsum += exp(c[lane * nx + 4 * bx + e] - M);
+                    }
         }
         double linc = lsum;
 #pragma unroll
@@ -1662,14 +1795,29 @@ __global__ __launch_bounds__(64) void k_select_bnb(Slam2dLevel lv, const double*
             double r2 = run + __shfl(linc - lsum, l2);
             int found = -1, last = -1;
             if (lane == l2) {
-                const int by = lane >> 2;
-                for (int bx = 0; bx < nbt && found < 0; ++bx)
-                    if (bnd[by * nbq4 + bx] >= thr)
-                        for (int e = 0; e < 4 && 4 * bx + e < nx; ++e) {
-                            last = it * npose + lane * nx + 4 * bx + e;
-                            r2 += exp(c[lane * nx + 4 * bx + e] - M);
-                            if (r2 > target) { found = last; break; }
+                if (in_lds) {
+                    for (int j = ja; j < jb && found < 0; ++j) {
+                        const int t = list_s[j] & 255;
+                        if (t / nbq4 == by) {
+                            const int bx = t % nbq4;
+                            for (int e = 0; e < 4 && 4 * bx + e < nx; ++e) {
+                                last = it * npose + lane * nx + 4 * bx + e;
+                                r2 += sc_s[j][rr * 4 + e];
+                                if (r2 > target) { found = last; break; }
+                            }
                         }
+                    }
+                } else {
+                    const double* c = lv.cube + ((size_t)p * lv.ntheta + it) * npose;
+                    const double* bt = bnd + (size_t)it * nt;
+                    for (int bx = 0; bx < nbt && found < 0; ++bx)
+                        if (bt[by * nbq4 + bx] >= thr)
+                            for (int e = 0; e < 4 && 4 * bx + e < nx; ++e) {
+                                last = it * npose + lane * nx + 4 * bx + e;
+                                r2 += exp(c[lane * nx + 4 * bx + e] - M);
+                                if (r2 > target) { found = last; break; }
+                            }
+                }
                 if (found < 0) found = last;                      // rounding fallback: the row's last scored pose
             }
             pick = __shfl(found, l2);
@@ -1687,9 +1835,10 @@ __global__ __launch_bounds__(64) void k_select_bnb(Slam2dLevel lv, const double*
         m.log_confidence = M + log(total);
         m.best_score = M;
         m.pick = pick;
-        m.argmax = me.i;
+        m.argmax = Mi_s[0];
         out[p] = m;
     }
+    DBG_CLOCK(13, p == 0);
 }
 
 // ------------------------------------------------------------------------------------
@@ -2051,10 +2200,11 @@ static int check_field_args(const Slam2dLevel& lv, int P, bool lazy) {
     if (lv.tmax * lv.tmax > 28000) return SLAM2D_E_TOOLARGE;        // k_tile_triage: 32 passes, 64 KB of LDS
     if (lv.bnb) {
         const int nx = 2 * lv.ncell + 1;
-        if (!lazy || !lv.pool || !lv.poolstate || !lv.pcells || !lv.bounds || !lv.tile_pmax || !lv.bnb_best) return SLAM2D_E_BADARG;
-        if (nx < 9 || nx > 64 || (lv.fpitch & 15) || lv.tmax * 16 != lv.fpitch) return SLAM2D_E_BADARG;
-        if (lv.tmax * lv.tmax > 20000) return SLAM2D_E_TOOLARGE;    // a third byte per tile in the triage's LDS
-        if (lv.npartial < lv.ntheta) return SLAM2D_E_BADARG;
+        if (!lazy || !lv.gmin || !lv.gmin2 || !lv.pcells || !lv.bounds || !lv.tile_pmax || !lv.bnb_best || !lv.prune_state)
+            return SLAM2D_E_BADARG;
+        if (nx < 9 || nx > 64 || lv.tmax * 16 != lv.fpitch) return SLAM2D_E_BADARG;
+        if (lv.ntheta > SLAM2D_BNB_MAX_THETA) return SLAM2D_E_TOOLARGE;
+        if ((long long)lv.ntheta * ((nx + 3) / 4) * (((nx + 3) / 4 + 3) / 4 * 4) > (long long)XS_THREADS * XS_MAX_PER) return SLAM2D_E_TOOLARGE;
     }
     return 0;
 }
@@ -2075,7 +2225,7 @@ static void launch_field(const Slam2dLevel& lv, const Slam2dMap* d_maps, int P, 
         k_occ_scatter<<<dim3(cdiv(cdiv(lv.wmax, 32) + 1, 64), cdiv(lv.wmax, SCATTER_ROWS), P), dim3(64, 4), (size_t)lv.wmax * sizeof(int32_t), s>>>(lv, d_maps);
     }
     const int ntile = lv.tmax * lv.tmax;
-    k_tile_triage<<<P, TRIAGE_THREADS, (size_t)(lv.bnb ? 3 : 2) * ((ntile + 3) & ~3) + 4 * ((ntile + 31) / 32), s>>>(lv, lazy ? 1 : 0);
+    k_tile_triage<<<P, TRIAGE_THREADS, (size_t)2 * ((ntile + 3) & ~3) + 4 * ((ntile + 31) / 32), s>>>(lv, lazy ? 1 : 0);
     {
         StageScope prof(SLAM2D_STAGE_BLUR, s);
         static const int blur_blocks = [] { const char* e = getenv("SLAM2D_BLUR_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : SLAM2D_BLUR_BLOCKS_PER_PARTICLE; }();
@@ -2088,10 +2238,10 @@ static void launch_field(const Slam2dLevel& lv, const Slam2dMap* d_maps, int P, 
         }
     }
     switch (lv.blur_radius) {
-        case 2: k_blur_check_redo<2><<<P, 256, 0, s>>>(lv, d_flags); break;
-        case 4: k_blur_check_redo<4><<<P, 256, 0, s>>>(lv, d_flags); break;
-        case 8: k_blur_check_redo<8><<<P, 256, 0, s>>>(lv, d_flags); break;
-        default: k_blur_check_redo<0><<<P, 256, 0, s>>>(lv, d_flags); break;
+        case 2: k_blur_check_redo<2><<<dim3(P, lv.bnb ? 16 : 1), 256, 0, s>>>(lv, d_flags); break;
+        case 4: k_blur_check_redo<4><<<dim3(P, lv.bnb ? 16 : 1), 256, 0, s>>>(lv, d_flags); break;
+        case 8: k_blur_check_redo<8><<<dim3(P, lv.bnb ? 16 : 1), 256, 0, s>>>(lv, d_flags); break;
+        default: k_blur_check_redo<0><<<dim3(P, lv.bnb ? 16 : 1), 256, 0, s>>>(lv, d_flags); break;
     }
 }
 
@@ -2225,20 +2375,12 @@ int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2
         launch_field(lv, d_maps, P, d_flags, true, s);
         const unsigned grid = (unsigned)cdiv(P, 8) * 8 * lv.ntheta;
         {
-            StageScope prof(SLAM2D_STAGE_POOL, s);
-            k_pool<<<dim3(min(lv.tmax * lv.tmax, SLAM2D_BLUR_BLOCKS_PER_PARTICLE), P), 64, 0, s>>>(lv);
-        }
-        {
             StageScope prof(SLAM2D_STAGE_BOUND, s);
-            k_bound<<<grid, 256, 0, s>>>(lv, P);
+            k_bound<<<grid, WAVE, 0, s>>>(lv, P);
         }
         {
             StageScope prof(SLAM2D_STAGE_EXACT, s);
-            k_exact<<<grid, 256, 0, s>>>(lv, P);
-        }
-        {
-            StageScope prof(SLAM2D_STAGE_SELECT, s);
-            k_select_bnb<<<P, WAVE, 0, s>>>(lv, d_est, est_stride, d_uniform, d_out);
+            k_exact_select<<<P, XS_THREADS, 0, s>>>(lv, d_est, est_stride, d_uniform, d_out);
         }
         return launch_status();
     }
@@ -2366,6 +2508,12 @@ int slam2d_prof_collect(int32_t stage, double* total_ms, int32_t* launches) {
 }
 
 void slam2d_prof_disable(void) { g_prof_mask = 0; }
+
+#ifdef SLAM2D_DEBUG_CLOCK
+int slam2d_debug_clock(long long* out64) {
+    return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_dbg_clock), sizeof(long long) * 64);
+}
+#endif
 
 // ---- plain event timer ----
 struct Timer { hipEvent_t a, b; };

@@ -428,7 +428,8 @@ class SearchLevel:
         npose = self.nx * self.nx
         self.npartial = self.ntheta * (-(-npose // 64))
         self.tmax = -(-self.fmax // 16)             # 16x16-cell tiles of the blur
-        self.bnb = bnb_default(self.nx, self.ntheta, lidar.beams, self.tmax) if bnb is None else bool(bnb)
+        applicable = 9 <= self.nx <= 64 and self.tmax * self.tmax <= 20000
+        self.bnb = bnb_default(self.nx, self.ntheta, lidar.beams, self.tmax) if bnb is None else (bool(bnb) and applicable)
         nbt = (self.nx + 3) // 4
         nbq4 = 4 * ((nbt + 3) // 4)
         i32, f64 = torch.int32, torch.float64
@@ -452,8 +453,8 @@ class SearchLevel:
             tilestate=torch.ones((P, self.tmax, self.tmax), dtype=torch.uint8, device=device),   # all dirty
             tilemin=torch.zeros((P, self.tmax, self.tmax), dtype=f64, device=device),
             tilemax=torch.zeros((P, self.tmax, self.tmax), dtype=f64, device=device),
-            tilelist=torch.zeros((P, 4, self.tmax * self.tmax), dtype=i32, device=device),
-            tilecount=torch.zeros((P, 4), dtype=i32, device=device),
+            tilelist=torch.zeros((P, 2, self.tmax * self.tmax), dtype=i32, device=device),
+            tilecount=torch.zeros((P, 2), dtype=i32, device=device),
             tileneed=torch.zeros((P, (self.tmax * self.tmax + 31) // 32), dtype=i32, device=device),
             freerow=torch.zeros((P, 64), dtype=torch.int64, device=device),
             ring=torch.zeros(1 + self.nx * ((self.nx + 3) // 4), dtype=i32, device=device),
@@ -461,8 +462,8 @@ class SearchLevel:
         )
         if self.bnb:        # branch and bound over 4x4 pose tiles (include/slam2d.h)
             t.update(
-                pool=torch.zeros((P, 4, self.fmax, self.fpitch // 4), dtype=i32, device=device),
-                poolstate=torch.ones((P, self.tmax, self.tmax), dtype=torch.uint8, device=device),   # all dirty
+                gmin=torch.zeros((P, 4 * self.tmax, 4 * self.tmax), dtype=i32, device=device),
+                gmin2=torch.zeros((P, 4 * self.tmax, 4 * self.tmax), dtype=i32, device=device),
                 pcells=torch.zeros((P, self.ntheta, self.kmax), dtype=i32, device=device),
                 bounds=torch.zeros((P, self.ntheta, nbt, nbq4), dtype=f64, device=device),
                 tile_pmax=torch.zeros((P, nbt, nbq4), dtype=f64, device=device),
@@ -483,7 +484,7 @@ class SearchLevel:
             tilecount=t["tilecount"].data_ptr(),
             tileneed=t["tileneed"].data_ptr(), freerow=t["freerow"].data_ptr(), ring=t["ring"].data_ptr(), prune_state=t["prune_state"].data_ptr(),
             ring_cap=self.nx * ((self.nx + 3) // 4), bnb=int(self.bnb),
-            **({k: t[k].data_ptr() for k in ("pool", "poolstate", "pcells", "bounds", "tile_pmax", "bnb_best")} if self.bnb else {}))
+            **({k: t[k].data_ptr() for k in ("gmin", "gmin2", "pcells", "bounds", "tile_pmax", "bnb_best")} if self.bnb else {}))
 
     def next_generation(self):
         """Advance the occupancy-image generation stamp (Slam2dLevel.occ_gen) for the next build: the
@@ -516,10 +517,24 @@ class SearchLevel:
         fh, fw = prob.shape
         self.t["field"][p, :fh, :fw] = torch.from_numpy(cost.view(np.int32)).to(self.device)
         self.t["tilestate"][p].fill_(1)          # the buffer no longer holds what field_build left there
-        if self.bnb:
-            self.t["poolstate"][p].fill_(1)
         self.t["freerow"][p].zero_()             # ... and no tile of it is known to hold the constant
         return scale
+
+    def bnb_stats(self):
+        """Diagnostics of the last slam2d_match: mean tiles per particle in the two work lists (blur, fill) and,
+        with branch and bound, the fraction of pose tiles that were scored exactly."""
+        tc = self.t["tilecount"].cpu().numpy().astype(np.float64).mean(axis=0)
+        out = dict(blur_tiles=tc[0], fill_tiles=tc[1])
+        if self.bnb:
+            nbt = (self.nx + 3) // 4
+            b = self.t["bounds"].cpu().numpy()[..., :nbt]
+            best = self.t["bnb_best"].cpu().numpy().view(np.uint64)
+            bits = np.where(best >> np.uint64(63), best & np.uint64(0x7FFFFFFFFFFFFFFF), ~best).astype(np.uint64)
+            m0 = bits.view(np.float64)
+            kept = b >= (m0 - _lib.BNB_MARGIN)[:, None, None, None]
+            out.update(kept_fraction=float(kept.mean()), kept_per_particle=float(kept.reshape(len(m0), -1).sum(axis=1).mean()),
+                       kept_max_per_theta=int(kept.reshape(len(m0), self.ntheta, -1).sum(axis=2).max()))
+        return out
 
     def cube(self, p=0):
         return self.t["cube"][p].cpu().numpy().reshape(self.ntheta, self.nx, self.nx)

@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/kstat_$WL
 rm -rf $OUT
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o k -- python $GRAFT_REPO_ROOT/bench.py --workload $WL --steps 30 --warmup 5 --no-cpu-baseline "$@" > $OUT.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o k -- python $GRAFT_REPO_ROOT/bench.py --workload $WL --steps 100 --warmup 5 --no-cpu-baseline --no-variants "$@" > $OUT.log 2>&1
 cd $GRAFT_REPO_ROOT
 python - <<PY
 import csv, glob
