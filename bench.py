@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the scan-matching / map-update hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config2|ref2level] [--particles P]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config2|ref2level|config5] [--particles P]
 
 A "step" is one lidar scan processed for every particle of the rank: search-field build
 from each particle's own map, pose-cube sweep with soft-max pose draw and confidence,
@@ -57,13 +57,15 @@ WORKLOAD_PARTICLES = {"config5": 128}
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
     ap.add_argument("--particles", type=int, default=None, help="particles per GPU (default 64; config5: 128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-variants", action="store_true", help="skip the prior-pruned variant measurement")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample")
+    ap.add_argument("--no-variants", action="store_true", help="skip the variant measurements (brute-force sweep, prior-pruned "
+                    "sweep, reference defaults, config-5 slice, config-3 closed loop)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of each CPU baseline leg")
+    ap.add_argument("--cpu-workers", type=int, default=0, help="processes of the all-cores CPU baseline (0: every host core)")
     return ap.parse_args()
 
 
@@ -206,42 +208,155 @@ class HotPath:
         return out
 
 
-def cpu_baseline(cfg, scen, target_seconds):
-    """The CPU oracle (a NumPy port of the reference; oracle/slam_oracle.py) on the same
-    workload, one process, one core, on a bounded sample of particle-scans."""
+_CPU = {}
+
+
+def _cpu_worker_init(cfg, visited, total, est, ranges, dist, psi):
+    """One oracle matcher + grid per worker process (the reference builds one per particle, Algorithm/FastSlam.py:69-70)."""
     from oracle import slam_oracle as so
     u = cfg["unit"]
-    t0 = time.perf_counter()
     lut = so.SpokeLUT(u, cfg["max_range"], cfg["fov"], cfg["beams"])
     og = so.GridOracle(cfg["map_m"], cfg["map_m"], {"x": 0.0, "y": 0.0}, u, cfg["fov"], cfg["beams"],
                        cfg["max_range"], cfg["wall"], lut=lut)
-    og.visited[:], og.total[:] = scen.visited, scen.total
+    og.visited[:], og.total[:] = visited, total
     sm = so.MatcherOracle(og, cfg["search_radius"], cfg["half_rad"], cfg["sigma_cells"], cfg["move_sigma"],
                           cfg["max_dev"], cfg["turn_sigma"], cfg["miss"], cfg["coarse_factor"],
                           rng=np.random.RandomState(0))
+    _CPU.update(cfg=cfg, og=og, sm=sm, est=est, ranges=ranges, dist=dist, psi=psi)
+
+
+def _cpu_unit(unit):
+    """One particle-scan of the workload through the oracle: field build(s), cube(s), soft-max draw, map update."""
+    cfg, og, sm = _CPU["cfg"], _CPU["og"], _CPU["sm"]
+    n_scans, P = _CPU["est"].shape[:2]
+    s, p = unit // P % n_scans, unit % P
+    x, y, th = _CPU["est"][s, p]
+    ranges, u = _CPU["ranges"][s], cfg["unit"]
+    if cfg["levels"] == 2:
+        matched, _ = sm.matchScan({"x": x, "y": y, "theta": th, "range": ranges}, _CPU["dist"][s], _CPU["psi"][s], 2, matchMax=False)
+    else:
+        xr, yr, prob = sm.frameSearchSpace(x, y, u, cfg["sigma_cells"], cfg["miss"])
+        matched, _, _ = sm.searchToMatch(prob, x, y, th, ranges, xr, yr, cfg["search_radius"], cfg["half_rad"], u,
+                                         _CPU["dist"][s], _CPU["psi"][s], fineSearch=False, matchMax=False)
+    og.update_cell_major(matched)
+    return 1
+
+
+def cpu_baseline(cfg, scen, target_seconds, workers):
+    """The CPU oracle (a NumPy port of the reference; oracle/slam_oracle.py) on the same workload: (i) one process,
+    as the reference runs; (ii) a process pool over particle-scans on every host core (particles are independent,
+    Algorithm/FastSlam.py:25-27).  Bounded samples.  Runs BEFORE the GPU is initialised (the pool forks)."""
+    import multiprocessing as mp
+    args = (cfg, scen.visited, scen.total, scen.est, scen.ranges, scen.dist, scen.psi)
+    n_scans, P = scen.est.shape[:2]
+    t0 = time.perf_counter()
+    _cpu_worker_init(*args)
     setup = time.perf_counter() - t0
     units, t_start = 0, time.perf_counter()
-    n_scans, P = scen.est.shape[:2]
     while True:
-        s, p = units // P % n_scans, units % P
-        x, y, th = scen.est[s, p]
-        ranges = scen.ranges[s]
-        reading = {"x": x, "y": y, "theta": th, "range": ranges}
-        if cfg["levels"] == 2:
-            matched, _ = sm.matchScan(reading, scen.dist[s], scen.psi[s], 2, matchMax=False)
-        else:
-            xr, yr, prob = sm.frameSearchSpace(x, y, u, cfg["sigma_cells"], cfg["miss"])
-            matched, _, _ = sm.searchToMatch(prob, x, y, th, ranges, xr, yr, cfg["search_radius"], cfg["half_rad"], u,
-                                             scen.dist[s], scen.psi[s], fineSearch=False, matchMax=False)
-        og.update_cell_major(matched)
+        _cpu_unit(units)
         units += 1
         el = time.perf_counter() - t_start
         if el >= target_seconds or units >= 4 * P:
             break
-    return dict(value=units / el, unit="particle-scans/s", cores=1, kind="port",
-                sample=f"{units} particle-scans of the same workload (scan(s) 0..{(units - 1) // P}, "
-                       f"{el:.1f} s; NumPy port of the reference, single process; LUT/setup {setup:.1f} s excluded)",
-                host_cores_available=os.cpu_count())
+    single = units / el
+    out = dict(value=single, unit="particle-scans/s", cores=1, kind="port",
+               sample=f"{units} particle-scans of the same workload ({el:.1f} s; NumPy port of the reference, one process; "
+                      f"LUT / setup {setup:.1f} s excluded)", host_cores_available=os.cpu_count())
+    workers = workers or os.cpu_count() or 1
+    if workers > 1:
+        try:
+            ctx = mp.get_context("fork")
+            with ctx.Pool(workers, initializer=_cpu_worker_init, initargs=args) as pool:
+                pool.map(_cpu_unit, range(workers), chunksize=1)                   # every worker warm (its matcher built)
+                n = max(workers, int(min(single * workers, 40 * workers) * target_seconds / 4))
+                n = -(-n // workers) * workers
+                t1 = time.perf_counter()
+                pool.map(_cpu_unit, range(n), chunksize=max(1, n // (4 * workers)))
+                el2 = time.perf_counter() - t1
+            out.update(value=n / el2, cores=workers, single_core_value=single,
+                       sample=f"{n} particle-scans on a {workers}-process pool ({el2:.1f} s); single process: {units} in {el:.1f} s; "
+                              "NumPy port of the reference; LUT / setup excluded")
+        except Exception as exc:                                                    # the single-core leg stands
+            out["pool_error"] = repr(exc)
+    return out
+
+
+TA_CLK_PER_WAVE_LOAD = 16.0     # measured: a vector-memory instruction occupies a CU's texture path for 16 clocks whatever its width
+GPU_CLOCK_GHZ = 2.4
+N_CU = 256
+
+
+def timed_run(hot, lib, E, first, K, stages_mask_of=None):
+    """K steps starting at scan `first`, bracketed by barrier + synchronize; returns (seconds, per-stage event timing)."""
+    if dist.is_initialized():
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(first, first + K):
+        hot.step(s)
+    torch.cuda.synchronize()
+    if dist.is_initialized():
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if dist.is_initialized():
+        t = torch.tensor([el], dtype=torch.float64, device=hot.d_logw.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    return el
+
+
+def side_workload(name, P, K, W, device, rank):
+    """A short run of another workload for the `variants` block (same launch sequence, its own scenario)."""
+    cfg = WORKLOADS[name]
+    scen = Scenario(cfg, P, K + W, seed=0, rank=rank)
+    hot = HotPath(cfg, P, scen, device)
+    E = hot.E
+    for s in range(W):
+        hot.step(s)
+    hot.eng.take_flags()
+    el = timed_run(hot, hot.L, E, W, K)
+    hot.eng.take_flags()
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    return dict(value=P * world * K / el, unit="particle-scans/s", ms_per_step=1e3 * el / K, steps=K, particles_per_gpu=P,
+                workload=cfg["note"], pose_hypotheses_per_particle_scan=hot.coarse.ntheta * hot.coarse.nx ** 2 +
+                (hot.fine.ntheta * hot.fine.nx ** 2 if hot.fine else 0),
+                branch_and_bound={k: bool(lv.bnb) for k, lv in (("coarse", hot.coarse), ("fine", hot.fine)) if lv is not None},
+                tile_stats={k: {a: round(float(b), 4) for a, b in lv.bnb_stats().items()}
+                            for k, lv in (("coarse", hot.coarse), ("fine", hot.fine)) if lv is not None})
+
+
+def config3_closed_loop(P, device):
+    """BASELINE config 3: FastSLAM over the bundled Intel log (910 scans x 180 beams), reference defaults, 50 m map with
+    growth, CLOSED loop through ParticleFilter (host decides growth / resampling, one synchronisation per scan; scans
+    are staged from host memory) -- the host- and PCIe-inclusive rate, never `value`."""
+    pkg = importlib.import_module("slam-2d-lidar-scan_amd")
+    dataio = importlib.import_module("slam-2d-lidar-scan_amd.dataio")
+    path = os.path.join(REPO, "tests", "golden", "intel_gfs.npz")
+    if not os.path.exists(path):
+        return None
+    readings = dataio.read_npz(path)
+    u = 0.02
+    ogP = [50.0, 50.0, readings[0], u, math.pi, 10, 180, 5 * u]
+    smP = [1.4, 0.25, 2, 0.1, 0.25, 0.3, 0.15, 5]
+    pf = pkg.ParticleFilter(P, ogP, smP, device=device, rng=np.random.RandomState(0))
+    for count, raw in enumerate(readings[:5], start=1):          # warm-up: first scans
+        pf.updateParticles(raw, count)
+        pf.weightUnbalanced()
+    pf = pkg.ParticleFilter(P, ogP, smP, device=device, rng=np.random.RandomState(0))
+    torch.cuda.synchronize()
+    resamples, t0 = 0, time.perf_counter()
+    for count, raw in enumerate(readings, start=1):
+        pf.updateParticles(raw, count)
+        if pf.weightUnbalanced():
+            pf.resample()
+            resamples += 1
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    m = pf.engine.maps[int(np.argmax(pf.weights))]
+    return dict(value=P * len(readings) / el, unit="particle-scans/s", scans=len(readings), particles=P, seconds=el,
+                scans_per_sec=len(readings) / el, resamples=resamples, final_map=[m.rows, m.cols],
+                note="closed loop incl. host decisions, per-scan H2D staging and one synchronisation per scan")
 
 
 def main():
@@ -250,6 +365,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     force_dist = os.environ.get("SLAM2D_FORCE_DIST") == "1"     # exercise the sharded code path on one GPU
+    cfg = WORKLOADS[args.workload]
+    P, K, W = args.particles or WORKLOAD_PARTICLES.get(args.workload, 64), args.steps, args.warmup
+    scen = Scenario(cfg, P, K + W, seed=0, rank=rank)
+    cpu = None
+    if not args.no_cpu_baseline and world == 1 and rank == 0:
+        cpu = cpu_baseline(cfg, scen, args.cpu_seconds, args.cpu_workers)      # before HIP is initialised: the pool forks
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
@@ -263,10 +384,6 @@ def main():
     torch.cuda.set_device(device)
     E = importlib.import_module("slam-2d-lidar-scan_amd.engine")
     lib = E._lib.lib()
-
-    cfg = WORKLOADS[args.workload]
-    P, K, W = args.particles or WORKLOAD_PARTICLES.get(args.workload, 64), args.steps, args.warmup
-    scen = Scenario(cfg, P, K + W, seed=0, rank=rank)
     hot = HotPath(cfg, P, scen, device)
 
     stages = [E._lib.STAGE_SWEEP, E._lib.STAGE_BLUR, E._lib.STAGE_SCATTER, E._lib.STAGE_UPDATE,
@@ -281,68 +398,59 @@ def main():
                 out[E._lib.STAGE_NAMES[st]] = dict(total_ms=tot.value, launches=n.value, avg_us=1e3 * tot.value / n.value)
         return out
 
-    # warm-up: every stage bracketed by HIP events (on the launch stream) to find the dominant kernel
-    E._lib.check(lib.slam2d_prof_enable(sum(1 << st for st in stages), 4 * max(W, 1) + 8), "prof_enable")
+    # warm-up: the first steps build every field tile (nothing is known to hold the free-space constant yet)
     for s in range(W):
         hot.step(s)
     flags = hot.eng.take_flags()        # synchronises; raises on any fault
-    warm_ms = collect()
-    dom_stage = max(stages, key=lambda st: warm_ms.get(E._lib.STAGE_NAMES[st], {}).get("total_ms", 0.0))
-    # timed region: only the dominant kernel keeps its event pair (an event pair costs ~5 us of
-    # stream time, so bracketing every stage would inflate the step by ~10 %)
-    E._lib.check(lib.slam2d_prof_enable(1 << dom_stage, 4 * K + 8), "prof_enable")
-
-    if dist.is_initialized():
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for s in range(W, W + K):
+    # a few bracketed steps (outside the timed region: an event pair costs ~5 us of stream time) find the dominant kernel
+    E._lib.check(lib.slam2d_prof_enable(sum(1 << st for st in stages), 4 * 8 + 8), "prof_enable")
+    for s in range(W, W + min(8, K)):
         hot.step(s)
-    torch.cuda.synchronize()
-    if dist.is_initialized():
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    hot.eng.take_flags()
+    probe_ms = collect()
+    dom_stage = max(stages, key=lambda st: probe_ms.get(E._lib.STAGE_NAMES[st], {}).get("total_ms", 0.0))
+    # timed region: only the dominant kernel keeps its event pair
+    E._lib.check(lib.slam2d_prof_enable(1 << dom_stage, 4 * K + 8), "prof_enable")
+    elapsed = timed_run(hot, lib, E, W, K)
     flags = hot.eng.take_flags()
     lib.slam2d_prof_disable()
-    if dist.is_initialized():
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
     stage_ms = collect()
+    tile_stats = {k: {a: round(float(b), 4) for a, b in lv.bnb_stats().items()}
+                  for k, lv in (("coarse", hot.coarse), ("fine", hot.fine)) if lv is not None}
 
-    # Variant, measured after (and outside) the headline region: the same K scans with the poses that the
-    # motion prior rules out not scored (SLAM2D_MATCH_PRUNE_BY_PRIOR; same arg-max, confidence within 1e-12).
-    variant = None
-    if hot.lazy and not args.no_variants:
-        hot.prune = True
-        for s in range(W):
-            hot.step(s)
-        if dist.is_initialized():
-            dist.barrier()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for s in range(W, W + K):
-            hot.step(s)
-        torch.cuda.synchronize()
-        if dist.is_initialized():
-            dist.barrier()
-        el2 = time.perf_counter() - t1
-        hot.eng.take_flags()
-        unsettled = int(hot.coarse.t["prune_state"].sum().item())
-        hot.prune = False
-        if dist.is_initialized():
-            t = torch.tensor([el2], dtype=torch.float64, device=device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el2 = float(t.item())
-        variant = dict(value=P * world * K / el2, ms_per_step=1e3 * el2 / K, particles_swept_in_full_last_scan=unsettled,
-                       note="coarse-level poses outside the motion prior's ring (rv = -100) are not scored; "
-                            "arg-max identical, confidence within 1e-12 relative; the pose cube is not materialised")
+    variants = {}
+    if not args.no_variants:
+        def variant(bnb, prune, note):
+            saved = [(lv, lv.c.bnb) for lv in (hot.coarse, hot.fine) if lv is not None]
+            for lv, _ in saved:
+                if not bnb:
+                    lv.c.bnb = 0
+            hot.prune = prune
+            for s in range(W):
+                hot.step(s)
+            hot.eng.take_flags()
+            el = timed_run(hot, lib, E, W, K)
+            hot.eng.take_flags()
+            for lv, v in saved:
+                lv.c.bnb = v
+            hot.prune = False
+            return dict(value=P * world * K / el, unit="particle-scans/s", ms_per_step=1e3 * el / K, note=note)
+        if any(lv is not None and lv.bnb for lv in (hot.coarse, hot.fine)):
+            variants["brute_force_sweep"] = variant(False, False, "every pose of the cube scored (k_sweep), the whole cube materialised "
+                                                    "in HBM: the round-1 headline path")
+        variants["prior_pruned_sweep"] = variant(False, True, "brute-force sweep restricted to the motion prior's ring where that "
+                                                 "settles the particle (SLAM2D_MATCH_PRUNE_BY_PRIOR)")
+        for name, (p2, k2) in {"ref2level": (64, 40), "config5": (128, 12)}.items():
+            if name != args.workload:
+                variants[name] = side_workload(name, p2, k2, 4, device, rank)
+        if world == 1 and args.workload == "config2":
+            c3 = config3_closed_loop(64, device)
+            if c3 is not None:
+                variants["config3_closed_loop"] = c3
 
     if rank == 0:
         total_units = P * world * K
         ab = hot.algorithmic_bytes(scen)
-        # dominant kernel = largest measured total time over the timed region
         dom = max(stage_ms, key=lambda k: stage_ms[k]["total_ms"])
         lev = {k: v for k, v in ab.items() if k != "update"}
         per_unit = {"k_sweep": sum(v["sweep"] for v in lev.values() if not v["bnb"]),
@@ -359,9 +467,24 @@ def main():
         traffic = None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tpath):
-            # measured offline for the same command (tools/gpu_session.sh prof): per-launch HBM bytes,
-            # 2*FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950
+            # measured offline for the same command (tools/gpu_pmc.sh): per-launch HBM bytes, 2*FETCH_SIZE + WRITE_SIZE
+            # as MI355X_MICROARCH.md prescribes for gfx950
             traffic = (json.load(open(tpath)).get(f"{args.workload}:{dom}") or {}).get("hbm_bytes_corrected")
+        # whole step against the memory roofline: SURVEY 8(d) bytes of every stage of one particle-scan, once per direction
+        step_bytes = sum(v["scatter"] + v["blur"] + (v["bound"] + v["exact"] if v["bnb"] else v["sweep"]) for v in lev.values()) \
+            + ab["update"]["per_particle"]
+        whole = step_bytes * P / (elapsed / K) / 1e9
+        # the gather kernels are bound by the texture path, not by bytes: wave-level load instructions x 16 clk per CU
+        cl = hot.coarse
+        kbar = float(hot.coarse.t["kcount"].double().mean().item())
+        gathers = {"k_sweep": cl.ntheta * kbar * math.ceil(cl.nx * math.ceil(cl.nx / 4) / 64),
+                   "k_bound": cl.ntheta * kbar,
+                   "k_exact": tile_stats["coarse"].get("kept_per_particle", 0.0) * math.ceil(kbar / 16)}
+        gather = None
+        if dom in gathers:
+            ta_us = gathers[dom] * P * TA_CLK_PER_WAVE_LOAD / N_CU / (GPU_CLOCK_GHZ * 1e3)
+            gather = dict(wave_loads_per_launch=gathers[dom] * P, clk_per_wave_load=TA_CLK_PER_WAVE_LOAD, texture_path_bound_us=ta_us,
+                          frac_of_texture_path_bound=ta_us / stage_ms[dom]["avg_us"])
         out = {
             "metric": f"scans/sec ({cfg['beams']}-beam) x particles at fixed search volume",
             "value": total_units / elapsed, "unit": "particle-scans/s",
@@ -371,23 +494,26 @@ def main():
             "config": {"workload": f"{args.workload}: {cfg['note']}", "particles_per_gpu": P,
                        "total_particles": P * world, "pose_hypotheses_per_particle_scan":
                        hot.coarse.ntheta * hot.coarse.nx ** 2 + (hot.fine.ntheta * hot.fine.nx ** 2 if hot.fine else 0),
+                       "pose_scoring": "branch and bound over 4x4 pose tiles (exact arg-max / draw, confidence within 2e-8)"
+                       if hot.coarse.bnb else "brute-force sweep",
                        "parallelism": f"particles sharded x{world}, one 24-byte-per-rank RCCL all-gather of the weight normaliser per scan"
                        if world > 1 else "single GPU"},
             "scans_per_sec": K / elapsed,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "avg_launch_us": stage_ms[dom]["avg_us"]},
-            "stages_warmup": {k: {"avg_us": round(v["avg_us"], 2), "launches": v["launches"]} for k, v in warm_ms.items()},
+                         "avg_launch_us": stage_ms[dom]["avg_us"],
+                         "whole_step": {"algorithmic_bytes_per_particle_scan": step_bytes, "achieved": whole, "frac": whole / HBM_PEAK_GBS},
+                         "gather": gather},
+            "stages_probe": {k: {"avg_us": round(v["avg_us"], 2), "launches": v["launches"]} for k, v in probe_ms.items()},
             "algorithmic_bytes_per_particle_scan": ab,
+            "tile_stats": tile_stats,
             "fault_flags": int(np.bitwise_or.reduce(flags)) if len(flags) else 0,
         }
-        out["tile_stats"] = {k: {a: round(float(b), 4) for a, b in lv.bnb_stats().items()}
-                             for k, lv in (("coarse", hot.coarse), ("fine", hot.fine)) if lv is not None}
-        if variant is not None:
-            out["variants"] = {"prior_pruned": variant}
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, scen, args.cpu_seconds)
+        if variants:
+            out["variants"] = variants
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -355,6 +355,10 @@ int slam2d_map_refresh_bits(const Slam2dMap* d_maps, const int32_t* d_index, int
 /* Fill a map with SLAM2D_INIT_CELL (np.ones / 2*np.ones, Utils/OccupancyGrid.py:13-14). */
 int slam2d_map_fill(uint32_t* d_cells, int64_t n, uint32_t value, void* stream);
 
+/* cos / sin of n angles as the endpoint kernel evaluates them on the device (ocml, fp64).  Test aid: the
+ * reference evaluates them with NumPy (Utils/ScanMatcher_OGBased.py:87-88); tests measure the distance. */
+int slam2d_device_sincos(const double* d_angles, int32_t n, double* d_cos, double* d_sin, void* stream);
+
 /* Per-stage timing for bench.py's roofline figure: when a stage's bit is enabled, every
  * launch of that stage's kernel is bracketed by a HIP event pair on the launch stream
  * (up to `capacity` launches).  slam2d_prof_collect synchronises on the recorded

@@ -123,6 +123,7 @@ SIGNATURES = {
     "slam2d_gather_maps": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int64, _vp]),
     "slam2d_map_fill": (C.c_int, [_vp, C.c_int64, C.c_uint32, _vp]),
     "slam2d_map_refresh_bits": (C.c_int, [_vp, _vp, C.c_int32, _vp]),
+    "slam2d_device_sincos": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp]),
     "slam2d_prof_enable": (C.c_int, [C.c_uint32, C.c_int32]),
     "slam2d_prof_collect": (C.c_int, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "slam2d_prof_disable": (None, []),

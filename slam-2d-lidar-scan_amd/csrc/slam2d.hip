@@ -2509,6 +2509,18 @@ int slam2d_prof_collect(int32_t stage, double* total_ms, int32_t* launches) {
 
 void slam2d_prof_disable(void) { g_prof_mask = 0; }
 
+// cos / sin exactly as k_endpoints evaluates them for the beam angles (ocml fp64): lets the tests measure the
+// distance to NumPy's libm on the same angles (deviation (i))
+__global__ void k_sincos(const double* __restrict__ a, int n, double* c, double* s) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { c[i] = cos(a[i]); s[i] = sin(a[i]); }
+}
+int slam2d_device_sincos(const double* d_angles, int32_t n, double* d_cos, double* d_sin, void* stream) {
+    if (!d_angles || !d_cos || !d_sin || n <= 0) return SLAM2D_E_BADARG;
+    k_sincos<<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(d_angles, n, d_cos, d_sin);
+    return launch_status();
+}
+
 #ifdef SLAM2D_DEBUG_CLOCK
 int slam2d_debug_clock(long long* out64) {
     return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_dbg_clock), sizeof(long long) * 64);

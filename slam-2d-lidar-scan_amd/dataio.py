@@ -1,4 +1,5 @@
-"""Scan logs: the reference's JSON format (`{"map": {"<timestamp>": {"x", "y", "theta", "range": [...]}}}`,
+"""Scan logs: CARMEN / GMapping text logs (`FLASER`, `LASER_READING` records -- what the reference's
+DataPreprocess/preprocess_log_intel.py:22-55 and preprocess_gfs.py:7-22 convert), the reference's JSON format (`{"map": {"<timestamp>": {"x", "y", "theta", "range": [...]}}}`,
 DataSet/PreprocessedData/*, read by `readJson` at Utils/ScanMatcher_OGBased.py:265-268 and iterated in
 sorted-key order, :232) and the compact `.npz` re-encoding used by this repository's fixtures
 (`range_cm` uint16 [scans, beams], `pose` float64 [scans, 3])."""
@@ -28,3 +29,38 @@ def write_npz(path, readings):
         raise ValueError("ranges are not representable in whole centimetres below 655.36 m")
     pose = np.array([[r["x"], r["y"], r["theta"]] for r in readings], dtype=np.float64)
     np.savez_compressed(path, range_cm=cm.astype(np.uint16), pose=pose)
+
+
+def _parse_laser_line(tokens, stamp_offset):
+    """`<TAG> n r_1 .. r_n x y theta ...`: ranges, the laser pose that follows them, and the time stamp
+    `stamp_offset` tokens after the ranges (GFS LASER_READING: 3, CARMEN FLASER: 6 -- the odometry pose sits
+    in between, DataPreprocess/preprocess_log_intel.py:29,50)."""
+    n = int(tokens[1])
+    rng = np.array(tokens[2:n + 2], dtype=np.float64)
+    x, y, theta = (float(v) for v in tokens[n + 2:n + 5])
+    return float(tokens[n + 2 + stamp_offset]), {"x": x, "y": y, "theta": theta, "range": rng}
+
+
+def read_text_log(path, record=None):
+    """Readings of a CARMEN (`FLASER`) or GMapping (`LASER_READING`) text log, in time-stamp order -- the order
+    the reference iterates its JSON in (sorted keys).  `record`: which tag to read; default: whichever the file
+    holds (LASER_READING wins if both occur, as in the reference's Intel pipeline).  Returns (readings, stamps)."""
+    offsets = {"LASER_READING": 3, "FLASER": 6}
+    found = {k: [] for k in offsets}
+    with open(path, "r") as f:
+        for line in f:
+            tag = line.split(" ", 1)[0]
+            if tag in offsets and (record is None or tag == record):
+                found[tag].append(_parse_laser_line(line.split(), offsets[tag]))
+    rows = found["LASER_READING"] or found["FLASER"]
+    if not rows:
+        raise ValueError(f"{path}: no FLASER / LASER_READING records")
+    rows.sort(key=lambda r: r[0])
+    return [r[1] for r in rows], np.array([r[0] for r in rows])
+
+
+def text_log_to_npz(src, dst, record=None):
+    """Text log -> the compact binary fixture format (ranges must be whole centimetres, as the bundled logs are)."""
+    readings, _ = read_text_log(src, record)
+    write_npz(dst, readings)
+    return len(readings)

@@ -1068,6 +1068,48 @@ def test_branch_and_bound_reproduces_reference_runs(pkg, intel_readings, golden)
     assert pf.coarse.bnb and pf.fine.bnb
 
 
+def test_device_sincos_vs_numpy(pkg, intel_readings):
+    """Deviation (i) of DESIGN.md, measured: the endpoint kernel evaluates cos / sin of the beam angles with ocml,
+    the reference with NumPy (Utils/ScanMatcher_OGBased.py:87-88).  Over every beam angle of the Intel log's
+    headings (|theta| up to ~31 rad over the run, +- the search half-width) the two agree to <= 1 ulp, and an
+    endpoint's cell index -- trunc of (x + r cos a - begin) / step -- is the same for every beam of the log at both
+    levels."""
+    import torch
+    lib = importlib.import_module("slam-2d-lidar-scan_amd._lib")
+    L = lib.lib()
+    th = np.array([r["theta"] for r in intel_readings])
+    th = np.concatenate([th * k for k in (1.0, 5.0, 13.0)])                # the run winds up to ~31 rad; go well past it
+    fov, B = np.pi, 180
+    ang = np.concatenate([np.linspace(t - fov / 2, t + fov / 2, B) for t in th])
+    d_a = torch.from_numpy(ang).cuda()
+    d_c, d_s = torch.empty_like(d_a), torch.empty_like(d_a)
+    lib.check(L.slam2d_device_sincos(d_a.data_ptr(), ang.size, d_c.data_ptr(), d_s.data_ptr(), E._stream()), "sincos")
+    c, s_ = d_c.cpu().numpy(), d_s.cpu().numpy()
+
+    def ulps(a, b):
+        ia, ib = a.view(np.int64), b.view(np.int64)
+        return np.abs(np.where(ia < 0, np.int64(-2 ** 63) - ia, ia) - np.where(ib < 0, np.int64(-2 ** 63) - ib, ib))
+    uc, us = ulps(c, np.cos(ang)), ulps(s_, np.sin(ang))
+    print(f"ocml vs NumPy over {ang.size} beam angles: cos exact {np.mean(uc == 0):.4f}, max {uc.max()} ulp; "
+          f"sin exact {np.mean(us == 0):.4f}, max {us.max()} ulp")
+    assert uc.max() <= 1 and us.max() <= 1
+    # endpoint cells of the real log with either pair of tables: identical
+    n_diff = 0
+    for r in intel_readings[::7]:
+        rng = np.asarray(r["range"])
+        a = np.linspace(r["theta"] - fov / 2, r["theta"] + fov / 2, B)
+        d_a = torch.from_numpy(a).cuda(); d_c = torch.empty_like(d_a); d_s = torch.empty_like(d_a)
+        lib.check(L.slam2d_device_sincos(d_a.data_ptr(), B, d_c.data_ptr(), d_s.data_ptr(), E._stream()), "sincos")
+        cd, sd = d_c.cpu().numpy(), d_s.cpu().numpy()
+        for step in (0.1, 0.02):
+            lo_x, lo_y = r["x"] - 12.4, r["y"] - 12.4
+            for cc, ss in ((np.cos(a), np.sin(a)),):
+                ref_x = ((r["x"] + cc * rng - lo_x) / step).astype(int); ref_y = ((r["y"] + ss * rng - lo_y) / step).astype(int)
+            dev_x = ((r["x"] + cd * rng - lo_x) / step).astype(int); dev_y = ((r["y"] + sd * rng - lo_y) / step).astype(int)
+            n_diff += int((ref_x != dev_x).sum() + (ref_y != dev_y).sum())
+    assert n_diff == 0
+
+
 def test_fault_flags_instead_of_out_of_bounds(pkg):
     """Data-dependent faults are reported, never executed: a search window or an update window
     that leaves a non-growable map raises, and a 16-bit count that would overflow raises."""

@@ -2,6 +2,7 @@
 field floor, level geometry, map growth emulation, odometry prior -- against the oracle.
 CPU only (MapState works on torch's CPU device; nothing here calls the HIP library)."""
 import importlib
+import os
 import math
 
 import numpy as np
@@ -165,3 +166,77 @@ def test_dataio_roundtrip(tmp_path, intel_readings):
     dataio.write_npz(npath, back)
     again = dataio.read_npz(npath)
     assert all(np.array_equal(a["range"], np.asarray(b["range"])) and a["theta"] == b["theta"] for a, b in zip(again, sub))
+
+
+def test_text_log_ingest(tmp_path):
+    """CARMEN FLASER / GMapping LASER_READING records -> readings in time order -> the compact npz and back
+    (DataPreprocess/preprocess_gfs.py:7-22, preprocess_log_intel.py:22-55)."""
+    import importlib
+    dataio = importlib.import_module("slam-2d-lidar-scan_amd.dataio")
+    gfs = tmp_path / "a.gfs"
+    gfs.write_text("# comment\n"
+                   "LASER_READING 3 1.25 2.50 81.91 0.5 -0.25 1.5 976052892.5 extra\n"
+                   "ODOM 1 2 3\n"
+                   "LASER_READING 3 1.00 2.00 3.00 0.1 0.2 0.3 976052890.25 extra\n")
+    readings, stamps = dataio.read_text_log(str(gfs))
+    assert list(stamps) == [976052890.25, 976052892.5]
+    assert readings[0]["x"] == 0.1 and readings[0]["theta"] == 0.3 and list(readings[1]["range"]) == [1.25, 2.5, 81.91]
+    clf = tmp_path / "a.log"
+    clf.write_text("FLASER 2 4.50 5.75 1.0 2.0 0.5 9.0 9.0 9.0 12.5 host 0.1\n"
+                   "FLASER 2 1.50 2.25 3.0 4.0 0.25 8.0 8.0 8.0 11.5 host 0.1\n")
+    readings, stamps = dataio.read_text_log(str(clf))
+    assert list(stamps) == [11.5, 12.5] and (readings[0]["x"], readings[0]["y"], readings[0]["theta"]) == (3.0, 4.0, 0.25)
+    assert dataio.text_log_to_npz(str(clf), str(tmp_path / "a.npz")) == 2
+    back = dataio.read_npz(str(tmp_path / "a.npz"))
+    assert list(back[1]["range"]) == [4.5, 5.75] and back[1]["x"] == 1.0
+    ref_raw, ref_json = "/root/reference/DataSet/RawData/csail.corrected.gfs", "/root/reference/DataSet/PreprocessedData/csail_gfs"
+    if os.path.exists(ref_raw) and os.path.exists(ref_json):          # the reference's own conversion, when it is around
+        got, _ = dataio.read_text_log(ref_raw)
+        want = dataio.read_json(ref_json)
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            assert (a["x"], a["y"], a["theta"]) == (b["x"], b["y"], b["theta"]) and list(a["range"]) == list(b["range"])
+
+
+def test_reference_caller_binds_to_the_shims():
+    """The reference's unchanged Algorithm/FastSlam.py, imported with this repository ahead of the reference on
+    sys.path, must bind OccupancyGrid / ScanMatcher to this implementation, and the signatures it calls must match
+    the reference's (Utils/OccupancyGrid.py:7, Utils/ScanMatcher_OGBased.py:9,47).  Development container only."""
+    import importlib
+    import inspect
+    import subprocess
+    import sys
+    ref = "/root/reference"
+    if not os.path.isdir(ref):
+        pytest.skip("reference not present")
+    code = r'''
+import sys, inspect, importlib, os
+os.environ["MPLBACKEND"] = "Agg"
+sys.dont_write_bytecode = True
+repo, ref = sys.argv[1], sys.argv[2]
+sys.path[:0] = [repo, os.path.join(ref, "Algorithm"), ref]
+import FastSlam
+assert FastSlam.__file__.startswith(ref)
+mine_g = importlib.import_module("slam-2d-lidar-scan_amd.grid").OccupancyGrid
+mine_m = importlib.import_module("slam-2d-lidar-scan_amd.matcher").ScanMatcher
+assert FastSlam.OccupancyGrid is mine_g and FastSlam.ScanMatcher is mine_m, (FastSlam.OccupancyGrid, FastSlam.ScanMatcher)
+# the reference's own classes, loaded from their files, for the signature comparison
+import importlib.util
+def load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path); m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m); return m
+rg = load("ref_og", os.path.join(ref, "Utils", "OccupancyGrid.py")).OccupancyGrid
+sys.modules.setdefault("Utils.OccupancyGrid", sys.modules["Utils.OccupancyGrid"])
+rm = load("ref_sm", os.path.join(ref, "Utils", "ScanMatcher_OGBased.py")).ScanMatcher
+def params(f): return [p for p in inspect.signature(f).parameters]
+assert params(mine_g.__init__)[:9] == params(rg.__init__), (params(mine_g.__init__), params(rg.__init__))
+assert params(mine_m.__init__) == params(rm.__init__)
+assert params(mine_m.matchScan) == params(rm.matchScan)
+assert params(mine_g.updateOccupancyGrid) == params(rg.updateOccupancyGrid)
+assert params(mine_g.convertRealXYToMapIdx) == params(rg.convertRealXYToMapIdx)
+for name in ("plotOccupancyGrid", "checkAndExapndOG", "occupancyGridVisited", "occupancyGridTotal", "OccupancyGridX", "OccupancyGridY"):
+    assert hasattr(mine_g, name), name
+print("bound")
+'''
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", code, repo, ref], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "bound" in res.stdout, res.stdout + res.stderr

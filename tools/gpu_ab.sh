@@ -7,7 +7,7 @@ for LIB in "$@"; do
 import sys, json
 for line in sys.stdin:
     if line.startswith('{'):
-        d = json.loads(line); print('$LIB $WL', round(d['value']), 'ms/step', round(d['ms_per_step'],3), {k: v['avg_us'] for k, v in d['stages_warmup'].items()})
+        d = json.loads(line); print('$LIB $WL', round(d['value']), 'ms/step', round(d['ms_per_step'],3), {k: v['avg_us'] for k, v in d['stages_probe'].items()})
 "
   done
 done

@@ -11,7 +11,7 @@ for R in 0; do
 import sys, json
 for line in sys.stdin:
     if line.startswith('{'):
-        d = json.loads(line); print('value', round(d['value']), 'ms/step', round(d['ms_per_step'],3), {k: v['avg_us'] for k, v in d['stages_warmup'].items()})
+        d = json.loads(line); print('value', round(d['value']), 'ms/step', round(d['ms_per_step'],3), {k: v['avg_us'] for k, v in d['stages_probe'].items()})
 "
 done
 unset SLAM2D_SWEEP_R
@@ -20,7 +20,7 @@ timeout 300 python bench.py --workload ref2level --steps 20 --warmup 3 --no-cpu-
 import sys, json
 for line in sys.stdin:
     if line.startswith('{'):
-        d = json.loads(line); print('value', round(d['value']), 'ms/step', round(d['ms_per_step'],3), {k: v['avg_us'] for k, v in d['stages_warmup'].items()})
+        d = json.loads(line); print('value', round(d['value']), 'ms/step', round(d['ms_per_step'],3), {k: v['avg_us'] for k, v in d['stages_probe'].items()})
 "
 echo "== forced dist (nccl, 1 rank)"
 SLAM2D_FORCE_DIST=1 timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -n 2 | cut -c1-400
@@ -31,5 +31,5 @@ timeout 300 python bench.py --workload config5 --steps 6 --warmup 2 --no-cpu-bas
 import sys, json
 for line in sys.stdin:
     if line.startswith('{'):
-        d = json.loads(line); print('value', round(d['value']), 'ms/step', round(d['ms_per_step'],3), {k: v['avg_us'] for k, v in d['stages_warmup'].items()})
+        d = json.loads(line); print('value', round(d['value']), 'ms/step', round(d['ms_per_step'],3), {k: v['avg_us'] for k, v in d['stages_probe'].items()})
 "
