@@ -211,6 +211,29 @@ class HotPath:
 _CPU = {}
 
 
+def effective_cores():
+    """Host cores this process may really use: os.cpu_count() capped by the scheduler affinity and the cgroup CPU quota."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]))))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
+
+
 def _cpu_worker_init(cfg, visited, total, est, ranges, dist, psi):
     """One oracle matcher + grid per worker process (the reference builds one per particle, Algorithm/FastSlam.py:69-70)."""
     from oracle import slam_oracle as so
@@ -262,18 +285,20 @@ def cpu_baseline(cfg, scen, target_seconds, workers):
     single = units / el
     out = dict(value=single, unit="particle-scans/s", cores=1, kind="port",
                sample=f"{units} particle-scans of the same workload ({el:.1f} s; NumPy port of the reference, one process; "
-                      f"LUT / setup {setup:.1f} s excluded)", host_cores_available=os.cpu_count())
-    workers = workers or os.cpu_count() or 1
+                      f"LUT / setup {setup:.1f} s excluded)", host_cores_available=os.cpu_count(), host_cores_effective=effective_cores())
+    workers = workers or effective_cores()
     if workers > 1:
         try:
             ctx = mp.get_context("fork")
             with ctx.Pool(workers, initializer=_cpu_worker_init, initargs=args) as pool:
-                pool.map(_cpu_unit, range(workers), chunksize=1)                   # every worker warm (its matcher built)
-                n = max(workers, int(min(single * workers, 40 * workers) * target_seconds / 4))
-                n = -(-n // workers) * workers
-                t1 = time.perf_counter()
-                pool.map(_cpu_unit, range(n), chunksize=max(1, n // (4 * workers)))
-                el2 = time.perf_counter() - t1
+                pool.map(_cpu_unit, range(workers), chunksize=1)                   # workers warm (their matchers built)
+                n, t1 = 0, time.perf_counter()
+                while True:                                                         # rounds of one unit per worker, time-bounded
+                    pool.map(_cpu_unit, range(n, n + workers), chunksize=1)
+                    n += workers
+                    el2 = time.perf_counter() - t1
+                    if el2 >= target_seconds:
+                        break
             out.update(value=n / el2, cores=workers, single_core_value=single,
                        sample=f"{n} particle-scans on a {workers}-process pool ({el2:.1f} s); single process: {units} in {el:.1f} s; "
                               "NumPy port of the reference; LUT / setup excluded")

@@ -132,11 +132,16 @@ class ParticleFilter:
         self.d_ranges = torch.zeros(beams, dtype=torch.float64, device=dev)
         self._h_uniform = torch.zeros(P, dtype=torch.float64).pin_memory()
         self._h_ranges = torch.zeros(beams, dtype=torch.float64).pin_memory()
-        self._h_report = torch.zeros((P, 5), dtype=torch.float64).pin_memory()
-        self.d_report = torch.zeros((P, 5), dtype=torch.float64, device=dev)   # x, y, theta, confidence, log-confidence
+        # everything the host reads per scan sits in ONE device buffer (one D2H copy, one synchronisation):
+        # [P x 5 report: x, y, theta, confidence, log-confidence | P normalised weights | variance, log of the weight sum]
+        self._d_pack = torch.zeros(6 * P + 2, dtype=torch.float64, device=dev)
+        self._h_pack = torch.zeros(6 * P + 2, dtype=torch.float64).pin_memory()
+        self.d_report = self._d_pack[:5 * P].view(P, 5)
+        self.d_w = self._d_pack[5 * P:6 * P]
+        self.d_stats = self._d_pack[6 * P:]
+        self.d_w.fill_(1.0)
         self.d_logw = torch.zeros(P, dtype=torch.float64, device=dev)     # log of weight = 1 (:75)
-        self.d_w = torch.full((P,), 1.0, dtype=torch.float64, device=dev)
-        self.d_stats = torch.zeros(2, dtype=torch.float64, device=dev)
+        self._normalized_step = -1
         self.weights = np.ones(P)
         self.trajectory = []
         self.prev_matched = None
@@ -223,10 +228,12 @@ class ParticleFilter:
                        "slam2d_post_match")
             eng.grid_update(self.d_pose, 3, self.d_ranges)          # :133 (the update window lies inside the
             #                                                         search window that was grown for)
-            self._h_report.copy_(self.d_report, non_blocking=True)  # x, y, theta, confidence, log-confidence
+            self._normalize_on_device()                             # Algorithm/FastSlam.py:43-48, ahead of weightUnbalanced()
+            self._h_pack.copy_(self._d_pack, non_blocking=True)     # poses, confidences, weights, variance
             eng.take_flags()                                        # the one synchronisation of the scan
-            rep = self._h_report.numpy()
+            rep = self._h_pack.numpy()[:5 * P].reshape(P, 5)
             matched, conf = rep[:, 0:3].copy(), rep[:, 3].copy()
+            self._normalized_step = self.step + 1
             self.prev_raw_heading = raw_heading
         self.trajectory.append(matched[:, :2].copy())
         self.prev_matched, self.prev_raw = matched, reading
@@ -319,27 +326,36 @@ class ParticleFilter:
         The N weights themselves are gathered only when the filter is within _DEGENERACY_BAND of total
         degeneracy (the only place the reference's trigger can fire) or when a resample needs them.
         ``self.weights`` holds this rank's particles; ``self.all_weights`` all N (None until gathered)."""
-        n = self.total_particles
+        n, P = self.total_particles, self.numParticles
+        if self._normalized_step == self.step:          # updateParticles already ran the normaliser and downloaded its results
+            host = self._h_pack.numpy()
+        else:
+            self._normalize_on_device()
+            host = self._d_pack.cpu().numpy()
+        self._normalized_step = -1
+        self.weights = host[5 * P:6 * P].copy()
         if self.sharded:
-            if self._normalizer is None:
-                self._normalizer = parallel.ShardedNormalizer(_lib.lib(), _lib.check, self.device, n, self.group)
-            self._normalizer(self.d_logw, None, 1, self.d_w, self.d_stats)
-            self.weights = self.d_w.cpu().numpy()
             self.all_weights = None
-            self.last_variance = float(self.d_stats[0].item())       # sum w^2 - 1/N, same bits on every rank
+            self.last_variance = float(host[6 * P])                  # sum w^2 - 1/N, same bits on every rank
             if self.last_variance >= (n - 1) / n - self._DEGENERACY_BAND:
                 self._gather_all_weights()
         else:
-            L = _lib.lib()
-            _lib.check(L.slam2d_weights_normalize(_ptr(self.d_logw), None, 1, self.numParticles, _ptr(self.d_w),
-                                                  _ptr(self.d_stats), _stream()), "slam2d_weights_normalize")
-            self.weights = self.d_w.cpu().numpy()
             self.all_weights = self.weights
             self._sequential_variance()
         if np.isnan(self.weights).any():
             # the reference fails loudly here: np.random.choice raises on NaN probabilities (a NaN cube entry,
             # e.g. the arccos argument of the heading prior rounding above 1, ScanMatcher_OGBased.py:107,138)
             raise _lib.Slam2dError("a particle weight is NaN (NaN confidence from the scan matcher)")
+
+    def _normalize_on_device(self):
+        """log-weights -> normalised weights + variance on the device (no host round trip)."""
+        if self.sharded:
+            if self._normalizer is None:
+                self._normalizer = parallel.ShardedNormalizer(_lib.lib(), _lib.check, self.device, self.total_particles, self.group)
+            self._normalizer(self.d_logw, None, 1, self.d_w, self.d_stats)
+        else:
+            _lib.check(_lib.lib().slam2d_weights_normalize(_ptr(self.d_logw), None, 1, self.numParticles, _ptr(self.d_w),
+                                                           _ptr(self.d_stats), _stream()), "slam2d_weights_normalize")
 
     def _sequential_variance(self):
         # sum (w_i - 1/N)^2 in the reference's sequential order (:32-35): at total degeneracy the outcome of
