@@ -198,6 +198,8 @@ typedef struct {
     double*  bounds;         /* [P][ntheta][nb][4*ceil(nb/4)] upper bound of the score of every pose tile, nb = ceil(nx/4) */
     double*  tile_pmax;      /* [P][nb][4*ceil(nb/4)] largest rv + thetaWeight of a pose tile (+inf if one is NaN) */
     unsigned long long* bnb_best; /* [P] order-preserving bits of the best exact score of the seed tiles */
+    double*  beam_xy;        /* [P][beams][2] scratch of slam2d_match (may be NULL): beam endpoints of the pose estimate
+                                (covertMeasureToXY, Utils/ScanMatcher_OGBased.py:81-89), evaluated once per particle */
     int32_t bnb;             /* 1: slam2d_match scores this level by branch and bound */
     int32_t _pad_bnb;
     int32_t occ_gen;         /* 0: occ + tilemask are cleared at every build.  1..255: generation stamp -- an

@@ -136,12 +136,27 @@ __device__ __forceinline__ Slam2dFrame make_frame(const Slam2dLidar& lid, const 
 // K2a+b  frame geometry (:21-28) and the field index of every window column / row (:32-36,173-176)
 // ------------------------------------------------------------------------------------
 __global__ void k_frame_axis(Slam2dLidar lid, Slam2dLevel lv, const Slam2dMap* __restrict__ maps,
-                             const double* __restrict__ centre, int cstride, uint32_t* flags, int clear_need) {
+                             const double* __restrict__ centre, int cstride, uint32_t* flags, int clear_need,
+                             const double* __restrict__ ranges) {
     const int p = blockIdx.y, axis = blockIdx.z;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (clear_need && axis == 1) {                     // the needed-tile bitmap of slam2d_match
         const int nneed = (lv.tmax * lv.tmax + 31) >> 5;
         for (int w = j; w < nneed; w += gridDim.x * blockDim.x) lv.tileneed[(size_t)p * nneed + w] = 0u;
+    }
+    if (ranges && axis == 0) {
+        // covertMeasureToXY (Utils/ScanMatcher_OGBased.py:81-89) once per particle: k_endpoints' ntheta blocks of the
+        // particle would otherwise each evaluate the same cos / sin (a third of its time at 1081 beams x 139 angles)
+        const double ex = centre[(size_t)p * cstride], ey = centre[(size_t)p * cstride + 1], eth = centre[(size_t)p * cstride + 2];
+        const int B = lid.beams;
+        const double a0 = eth - lid.fov / 2, a1 = eth + lid.fov / 2;       // np.linspace(theta - fov/2, theta + fov/2, num=B) (:82-83)
+        const double astep = (a1 - a0) / (double)(B - 1);
+        for (int b = j; b < B; b += gridDim.x * blockDim.x) {
+            const double rg = ranges[b];
+            const double a = (b == B - 1) ? a1 : (double)b * astep + a0;
+            lv.beam_xy[((size_t)p * B + b) * 2] = ex + cos(a) * rg;                              // :87
+            lv.beam_xy[((size_t)p * B + b) * 2 + 1] = ey + sin(a) * rg;                          // :88
+        }
     }
     const Slam2dMap m = maps[p];
     uint32_t f;
@@ -795,7 +810,8 @@ __device__ __forceinline__ void write_priors(const Slam2dLevel& lv, const int p,
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel lv, const double* __restrict__ est,
                                                    int estride, const double* __restrict__ ranges, uint32_t* flags,
-                                                   double est_dist, const double* __restrict__ psi_cs, int mark, int prune) {
+                                                   double est_dist, const double* __restrict__ psi_cs, int mark, int prune,
+                                                   int beam_table) {
     // np.unique (:120) through an LDS hash set: every beam inserts its cell; of the beams that hit one
     // cell the lowest beam index owns it (atomicMin), so the list keeps beam order -- which is spatially
     // coherent (neighbouring beams hit neighbouring cells) and deterministic.  Scores are exact
@@ -839,8 +855,13 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
         if (q < per && b < B) {
             const double rg = ranges[b];
             if (rg < lid.max_range) {                                               // :84
-                const double a = (b == B - 1) ? a1 : (double)b * astep + a0;
-                const double px = ex + cos(a) * rg, py = ey + sin(a) * rg;          // :87-88
+                double px, py;
+                if (beam_table) {                           // k_frame_axis evaluated :87-88 once for the particle
+                    px = lv.beam_xy[((size_t)p * B + b) * 2]; py = lv.beam_xy[((size_t)p * B + b) * 2 + 1];
+                } else {
+                    const double a = (b == B - 1) ? a1 : (double)b * astep + a0;
+                    px = ex + cos(a) * rg; py = ey + sin(a) * rg;                   // :87-88
+                }
                 const double dx = px - ex, dy = py - ey;
                 const double qx = ex + c * dx - s * dy;                             // :169
                 const double qy = ey + s * dx + c * dy;                             // :170
@@ -1179,6 +1200,85 @@ __global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks
         }
     } else {
         sweep_chunk(w - it * groups);
+    }
+}
+
+// Small cubes (a plane of <= 32 slots of 4 dx: 2*ncell+1 <= 7, e.g. the 5 x 5 fine level behind a coarse factor of 2):
+// k_sweep would leave most lanes of its waves without a slot.  Here ONE wave scores a whole (particle, theta) plane:
+// lane = (slot, cell slice) -- floor(64 / slots) slices share the cell list, which is staged in LDS once (no
+// vector-memory instruction per cell for the list), so a plane costs ~K / slices 16-byte gathers instead of K.
+// Same exact integer sums, same cube / partial layout as k_sweep with one chunk per theta.
+__global__ __launch_bounds__(64) void k_sweep_small(Slam2dLevel lv, int P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long small_lds[];   // [64 * 4] partial sums, then [kmax] cells
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int p = (slot / lv.ntheta) * 8 + xcd, it = slot % lv.ntheta;
+    if (p >= P) return;
+    const int lane = threadIdx.x;
+    const int nx = 2 * lv.ncell + 1, npose = nx * nx;
+    const int nq = (nx + 3) >> 2, nslot = nx * nq;             // <= 32 (checked by the host)
+    const int S = WAVE / nslot;                                 // cell slices
+    const int K = lv.kcount[p * lv.ntheta + it];
+    const int* __restrict__ cl = lv.cells + ((size_t)p * lv.ntheta + it) * lv.kmax;
+    int* cells_s = reinterpret_cast<int*>(small_lds + WAVE * 4);
+    for (int k = lane; k < K; k += WAVE) cells_s[k] = cl[k];
+    const size_t image = (size_t)lv.fmax * lv.fpitch;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(lv.field + (size_t)p * image), (short)0, (int)(image * sizeof(uint32_t)), 0x00020000);
+    const bool active = lane < S * nslot;
+    const int u = lane % nslot, sl = lane / nslot;
+    const int iy = u / nq, dx = (u - iy * nq) * 4;
+    const int off = (iy * lv.fpitch + dx) * 4;
+    unsigned lo[4] = {0u, 0u, 0u, 0u}, hi[4] = {0u, 0u, 0u, 0u};
+    __syncthreads();
+    for (int k = sl; k < K; k += 8 * S) {                       // 8 gathers in flight
+        int o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (active && k + i * S < K) ? off + cells_s[k + i * S] * 4 : 0x7ffffff0;
+        u32x4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o[i], 0, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned s2 = lo[e] + v[i][e];
+                hi[e] += s2 < v[i][e] ? 1u : 0u;
+                lo[e] = s2;
+            }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) small_lds[e * WAVE + lane] = ((unsigned long long)hi[e] << 32) | lo[e];
+    __syncthreads();
+    const double* __restrict__ pr = lv.prior + (size_t)p * 2 * npose;
+    double* __restrict__ out = lv.cube + ((size_t)p * lv.ntheta + it) * npose;
+    const double inv = 1.0 / lv.cost_scale;
+    const int nv = lane < nslot ? min(4, nx - dx) : 0, q0 = iy * nx + dx;
+    double sc[4];
+    Best me{-INFINITY, INT_MAX, 0};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        sc[e] = -INFINITY;
+        if (e < nv) {
+            unsigned long long acc = 0ull;
+            for (int s2 = 0; s2 < S; ++s2) acc += small_lds[e * WAVE + lane + s2 * nslot];
+            const int q = q0 + e;
+            sc[e] = (-((double)acc * inv) + pr[q]) + pr[npose + q];                 // :131, as k_sweep
+            out[q] = sc[e];
+            Best cand{sc[e], it * npose + q, isnan(sc[e]) ? 1 : 0};
+            if (better(cand, me)) me = cand;
+        }
+    }
+    me = wave_best(me);
+    double ex = 0.0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (e < nv) ex += exp(sc[e] - me.v);
+    ex = wave_sum(ex);
+    if (lane == 0) {
+        Slam2dPartial pt;
+        pt.max = me.v; pt.sumexp = ex; pt.argmax = me.i; pt.has_nan = me.nan;
+        lv.partials[(size_t)p * lv.npartial + it] = pt;
     }
 }
 
@@ -1864,7 +1964,9 @@ __device__ __forceinline__ int rint_div(const double v, const double unit, const
 }
 
 #define UPDB_BEAMS 4                 // = waves per block
+#ifndef UPDB_UNROLL
 #define UPDB_UNROLL 4
+#endif
 __global__ __launch_bounds__(256) void k_grid_update(Slam2dLidar lid, const Slam2dMap* __restrict__ maps, int P,
                                                            const double* __restrict__ pose, int pstride,
                                                            const double* __restrict__ ranges,
@@ -2211,8 +2313,10 @@ static int check_field_args(const Slam2dLevel& lv, int P, bool lazy) {
 
 // frame geometry, axis index vectors, cleared occupancy image / tile flags (/ needed-tile bitmap)
 static int launch_frames(const Slam2dLidar& lid, const Slam2dLevel& lv, const Slam2dMap* d_maps, int P,
-                         const double* d_centre, int centre_stride, uint32_t* d_flags, bool lazy, hipStream_t s) {
-    k_frame_axis<<<dim3(cdiv(lv.wmax, 256), P, 2), 256, 0, s>>>(lid, lv, d_maps, d_centre, centre_stride, d_flags, lazy ? 1 : 0);
+                         const double* d_centre, int centre_stride, uint32_t* d_flags, bool lazy, hipStream_t s,
+                         const double* d_ranges = nullptr) {
+    if (d_ranges && (!lv.beam_xy || centre_stride < 3)) d_ranges = nullptr;
+    k_frame_axis<<<dim3(cdiv(lv.wmax, 256), P, 2), 256, 0, s>>>(lid, lv, d_maps, d_centre, centre_stride, d_flags, lazy ? 1 : 0, d_ranges);
     if (lv.occ_gen < 0 || lv.occ_gen > 255) return SLAM2D_E_BADARG;
     if (lv.occ_gen != 0) return 0;                     // generation stamps: nothing to clear
     return (int)hipMemsetAsync(lv.occ, 0, (size_t)P * lv.fmax * lv.fpitch + (size_t)P * lv.tmax * lv.tmax, s);
@@ -2248,7 +2352,7 @@ static void launch_field(const Slam2dLevel& lv, const Slam2dMap* d_maps, int P, 
 // beam endpoints, unique cells per theta, priors (/ needed tiles)
 static void launch_endpoints(const Slam2dLidar& lid, const Slam2dLevel& lv, int P, const double* d_est, int est_stride,
                              const double* d_ranges, double est_moving_dist, const double* d_psi_cs, uint32_t* d_flags,
-                             bool mark, bool prune, hipStream_t s) {
+                             bool mark, bool prune, hipStream_t s, bool beam_table = false) {
     StageScope prof(SLAM2D_STAGE_ENDPOINTS, s);
     int n = 256;
     while (n < lid.beams) n <<= 1;
@@ -2256,7 +2360,8 @@ static void launch_endpoints(const Slam2dLidar& lid, const Slam2dLevel& lv, int 
     while (hsize < lid.beams + (lid.beams >> 1)) hsize <<= 1;
     const size_t ep_lds = (size_t)(2 * hsize + 8 + (mark ? (lv.tmax * lv.tmax + 31) / 32 : 0)) * sizeof(int);
     k_endpoints<<<dim3(lv.ntheta + 1, P), 256, ep_lds, s>>>(lid, lv, d_est, est_stride, d_ranges, d_flags, est_moving_dist,
-                                                        lv.fine ? nullptr : d_psi_cs, mark ? 1 : 0, prune ? 1 : 0);
+                                                        lv.fine ? nullptr : d_psi_cs, mark ? 1 : 0, prune ? 1 : 0,
+                                                        beam_table && lv.beam_xy ? 1 : 0);
 }
 
 // cube sweep + selection
@@ -2286,6 +2391,16 @@ static int launch_scores(const Slam2dLevel& lv, int P, const double* d_est, int 
         }
     }
     const int mode = ring_chunks > 0 ? 2 : 0;
+    static const bool no_small = [] { const char* e = getenv("SLAM2D_SWEEP_NOSMALL"); return e && atoi(e) == 1; }();
+    if (mode == 0 && nslot <= 32 && chunks == 1 && !no_small) {           // small cube: one wave per (particle, theta) plane
+        {
+            StageScope prof(SLAM2D_STAGE_SWEEP, s);
+            k_sweep_small<<<(unsigned)cdiv(P, 8) * 8 * lv.ntheta, WAVE, (size_t)WAVE * 4 * sizeof(unsigned long long) + (size_t)lv.kmax * sizeof(int), s>>>(lv, P);
+        }
+        StageScope prof(SLAM2D_STAGE_SELECT, s);
+        k_select<0><<<P, WAVE, 0, s>>>(lv, 1, 1, d_est, est_stride, d_uniform, d_out);
+        return 0;
+    }
     {
         StageScope prof(SLAM2D_STAGE_SWEEP, s);
         switch (bestR) {
@@ -2370,8 +2485,8 @@ int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2
     }
     if (lv.bnb) {
         // branch and bound over 4x4 pose tiles: pooled cost planes, tile bounds + seed tiles, surviving tiles, selection
-        if ((rc = launch_frames(*lidar, lv, d_maps, P, d_est, est_stride, d_flags, true, s))) return rc;
-        launch_endpoints(*lidar, lv, P, d_est, est_stride, d_ranges, est_moving_dist, d_psi_cs, d_flags, true, false, s);
+        if ((rc = launch_frames(*lidar, lv, d_maps, P, d_est, est_stride, d_flags, true, s, d_ranges))) return rc;
+        launch_endpoints(*lidar, lv, P, d_est, est_stride, d_ranges, est_moving_dist, d_psi_cs, d_flags, true, false, s, true);
         launch_field(lv, d_maps, P, d_flags, true, s);
         const unsigned grid = (unsigned)cdiv(P, 8) * 8 * lv.ntheta;
         {
@@ -2385,8 +2500,8 @@ int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2
         return launch_status();
     }
     // the endpoints need only the frame, so they run first and tell the field build which tiles matter
-    if ((rc = launch_frames(*lidar, lv, d_maps, P, d_est, est_stride, d_flags, true, s))) return rc;
-    launch_endpoints(*lidar, lv, P, d_est, est_stride, d_ranges, est_moving_dist, d_psi_cs, d_flags, true, ring_chunks > 0, s);
+    if ((rc = launch_frames(*lidar, lv, d_maps, P, d_est, est_stride, d_flags, true, s, d_ranges))) return rc;
+    launch_endpoints(*lidar, lv, P, d_est, est_stride, d_ranges, est_moving_dist, d_psi_cs, d_flags, true, ring_chunks > 0, s, true);
     launch_field(lv, d_maps, P, d_flags, true, s);
     if ((rc = launch_scores(lv, P, d_est, est_stride, d_uniform, d_out, s, ring_chunks))) return rc;
     return launch_status();

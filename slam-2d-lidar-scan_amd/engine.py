@@ -459,6 +459,7 @@ class SearchLevel:
             freerow=torch.zeros((P, 64), dtype=torch.int64, device=device),
             ring=torch.zeros(1 + self.nx * ((self.nx + 3) // 4), dtype=i32, device=device),
             prune_state=torch.zeros(P, dtype=i32, device=device),
+            beam_xy=torch.zeros((P, lidar.beams, 2), dtype=f64, device=device),
         )
         if self.bnb:        # branch and bound over 4x4 pose tiles (include/slam2d.h)
             t.update(
@@ -483,7 +484,7 @@ class SearchLevel:
             tilemin=t["tilemin"].data_ptr(), tilemax=t["tilemax"].data_ptr(), tilelist=t["tilelist"].data_ptr(),
             tilecount=t["tilecount"].data_ptr(),
             tileneed=t["tileneed"].data_ptr(), freerow=t["freerow"].data_ptr(), ring=t["ring"].data_ptr(), prune_state=t["prune_state"].data_ptr(),
-            ring_cap=self.nx * ((self.nx + 3) // 4), bnb=int(self.bnb),
+            ring_cap=self.nx * ((self.nx + 3) // 4), bnb=int(self.bnb), beam_xy=t["beam_xy"].data_ptr(),
             **({k: t[k].data_ptr() for k in ("gmin", "gmin2", "pcells", "bounds", "tile_pmax", "bnb_best")} if self.bnb else {}))
 
     def next_generation(self):
