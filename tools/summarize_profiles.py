@@ -12,13 +12,13 @@ import shutil
 
 ROUND = os.environ.get("ROUND", "r01")
 os.makedirs("profiles", exist_ok=True)
-for wl in ("config2", "ref2level"):
+for wl in ("config2", "ref2level", "config5"):
     src = f"gpurun_out/prof_{wl}/{wl}_kernel_stats.csv"
     if os.path.exists(src):
         shutil.copy(src, f"profiles/{ROUND}_{wl}_kernel_stats.csv")
         print(f"== {src}")
         for i, row in enumerate(csv.DictReader(open(src))):
-            if i < 8:
+            if i < 12:
                 print(f"  {row['Name'][:60]:60s} calls {row['Calls']:>4s} avg {float(row['AverageNs']) / 1e3:9.2f} us  {row['Percentage']:>6s} %")
 
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -47,6 +47,24 @@ for k, d in sorted(agg.items()):
 if traffic:
     json.dump(traffic, open("profiles/traffic.json", "w"), indent=1, sort_keys=True)
     open(f"profiles/{ROUND}_pmc_config2.txt", "w").write(
-        "rocprofv3 --pmc {FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum} --kernel-trace -- python bench.py --steps 30 --warmup 5\n"
+        "rocprofv3 --pmc {FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum} --kernel-trace -- python bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-variants\n"
         "per-launch means over the timed launches; FETCH/WRITE_SIZE are KB counters (x1024 here)\n" + "\n".join(lines) + "\n")
     print("\n".join(lines))
+
+# SQ / TCP counters of every kernel (raw per-launch means; pmc_sq and pmc_tcp passes)
+extra = []
+for k, d in sorted(agg.items()):
+    if not k.startswith("k_"):
+        continue
+    mean = {c: sum(v[len(v) // 4:]) / max(1, len(v[len(v) // 4:])) for c, v in d.items()}
+    keys = [c for c in ("SQ_WAVES", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CU_CYCLES",
+                        "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCP_TOTAL_ACCESSES_sum") if c in mean]
+    if keys:
+        rd = mean.get("SQ_INSTS_VMEM_RD")
+        tail = f"  L1 lines per wave-load {mean['TCP_TOTAL_CACHE_ACCESSES_sum'] / rd:6.1f}" if rd and "TCP_TOTAL_CACHE_ACCESSES_sum" in mean else ""
+        extra.append(f"{k[:40]:40s} " + "  ".join(f"{c} {mean[c]:.4g}" for c in keys) + tail)
+if extra:
+    open(f"profiles/{ROUND}_counters_config2.txt", "w").write(
+        "rocprofv3 --pmc <SQ_* | TCP_*> --kernel-trace -- python bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-variants\n"
+        "per-launch means after the warm-up launches (raw counter values)\n" + "\n".join(extra) + "\n")
+    print("\n".join(extra))
