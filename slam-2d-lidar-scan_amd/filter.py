@@ -132,6 +132,11 @@ class ParticleFilter:
         self.d_ranges = torch.zeros(beams, dtype=torch.float64, device=dev)
         self._h_uniform = torch.zeros(P, dtype=torch.float64).pin_memory()
         self._h_ranges = torch.zeros(beams, dtype=torch.float64).pin_memory()
+        # the pipelined driver (run()) stages scan s while scan s-1 may still be in flight: second set of pinned buffers
+        self._h_uniform2 = torch.zeros(P, dtype=torch.float64).pin_memory()
+        self._h_ranges2 = torch.zeros(beams, dtype=torch.float64).pin_memory()
+        self._d_flagsnap = torch.zeros(P, dtype=torch.int32, device=dev)
+        self._h_flagsnap = torch.zeros(P, dtype=torch.int32).pin_memory()
         # everything the host reads per scan sits in ONE device buffer (one D2H copy, one synchronisation):
         # [P x 5 report: x, y, theta, confidence, log-confidence | P normalised weights | variance, log of the weight sum]
         self._d_pack = torch.zeros(6 * P + 2, dtype=torch.float64, device=dev)
@@ -156,17 +161,19 @@ class ParticleFilter:
         self.step = 0
 
     # ---- odometry prior (Algorithm/FastSlam.py:77-106) ----
-    def _raw_odometry(self, raw):
+    def _raw_odometry(self, raw, prev_raw=None, prev_raw_heading="same"):
         """The particle-independent part of updateEstimatedPose: distance and heading of the raw
         odometry step (:81-104).  Returns (estMovingDist, rawMovingTheta, has_turn, raw_turn)."""
-        pr = self.prev_raw
+        pr = self.prev_raw if prev_raw is None else prev_raw
+        if prev_raw_heading == "same":
+            prev_raw_heading = self.prev_raw_heading
         dx, dy = raw['x'] - pr['x'], raw['y'] - pr['y']
         dist = math.sqrt(dx ** 2 + dy ** 2)
         raw_heading, has_turn, turn = None, 0, 0.0
         if dist > 0.3:
             raw_heading = _heading(dx, dy, dist)
-            if self.prev_raw_heading is not None:
-                has_turn, turn = 1, raw_heading - self.prev_raw_heading
+            if prev_raw_heading is not None:
+                has_turn, turn = 1, raw_heading - prev_raw_heading
         return dist, raw_heading, has_turn, turn
 
     def _prior(self, raw):
@@ -239,6 +246,126 @@ class ParticleFilter:
         self.prev_matched, self.prev_raw = matched, reading
         self.last_confidence = conf
         self.step += 1
+
+    # ---- the reference's driver loop, pipelined (Algorithm/FastSlam.py:152-162) ----
+    def run(self, readings, first_count=1, force_resample=(), on_scan=None):
+        """``for reading: updateParticles(reading, count); if weightUnbalanced(): resample()`` -- the same sequence of
+        decisions and results as calling those methods one by one, but the host never waits for the scan it has just
+        enqueued.  Scan s's match (prior, coarse and fine level: it only reads the maps) is enqueued BEFORE the host has
+        seen scan s-1's results, on the assumption -- true for all but a handful of scans of a run -- that scan s-1
+        triggers neither a resample nor a map growth; the host then reads scan s-1's packed report (already complete: it
+        precedes the match in stream order), and either commits scan s (bookkeeping, map update, normaliser, report
+        download) or, if the assumption failed, discards the speculative match and redoes the scan step by step.  The
+        legacy random stream is consumed exactly as by the unpipelined calls (its state is restored on a discard).
+        ``force_resample``: scan counts after which to resample regardless (tests).  ``on_scan(count, self, unbalanced)``
+        is called once a scan's results are on the host.  Returns the list of (count, resample indices)."""
+        eng, P = self.engine, self.numParticles
+        resamples, pending = [], None          # pending = (count, reading, raw_heading, event) of the scan in flight
+
+        stream_rng = self.rng if self.rng is not None else np.random
+
+        def finish(p):
+            """Scan p's results are on the host: bookkeeping + the reference's degeneracy test.  Returns whether the
+            reference resamples after this scan (the caller does it: the random stream may have to be rewound first)."""
+            count, reading, raw_heading, ev = p
+            ev.synchronize()
+            self._check_flag_snapshot()
+            rep = self._h_pack.numpy()[:5 * P].reshape(P, 5)
+            matched, conf = rep[:, 0:3].copy(), rep[:, 3].copy()
+            self.trajectory.append(matched[:, :2].copy())
+            self.prev_matched, self.prev_raw, self.last_confidence = matched, reading, conf
+            self.prev_raw_heading = raw_heading
+            self.step += 1
+            self._normalized_step = self.step
+            unb = self.weightUnbalanced()
+            if on_scan is not None:
+                on_scan(count, self, unb)
+            return unb or count in force_resample
+
+        def plain(count, reading):
+            """One scan through the unpipelined calls."""
+            self.updateParticles(reading, count)
+            unb = self.weightUnbalanced()
+            if on_scan is not None:
+                on_scan(count, self, unb)
+            if unb or count in force_resample:
+                resamples.append((count, self.resample()))
+
+        for count, reading in enumerate(readings, start=first_count):
+            if count == 1 or (pending is None and self.prev_raw is None) or not self.lazy_field:
+                assert pending is None
+                plain(count, reading)
+                continue
+            parity = count & 1
+            hr, hu = (self._h_ranges, self._h_uniform) if parity else (self._h_ranges2, self._h_uniform2)
+            if pending is None:
+                prev_raw, prev_raw_heading = self.prev_raw, self.prev_raw_heading
+            else:
+                prev_raw, prev_raw_heading = pending[1], pending[2]
+            dist, raw_heading, has_turn, turn = self._raw_odometry(reading, prev_raw, prev_raw_heading)
+            rng_state = stream_rng.get_state()
+            self._stage(hr, self.d_ranges, np.asarray(reading['range'], dtype=np.float64))
+            self._stage(hu, self.d_uniform, self._draw_uniforms())
+            self._enqueue_match(reading, prev_raw, dist, has_turn, turn)          # speculative: scan count-1 not seen yet
+            redo = False
+            if pending is not None:
+                prev_count = pending[0]
+                if finish(pending):
+                    # the reference draws the resample indices BEFORE this scan's uniforms: rewind, resample, redo the scan
+                    stream_rng.set_state(rng_state)
+                    resamples.append((prev_count, self.resample()))
+                    rng_state = None
+                    redo = True
+                pending = None
+            est_xy = self.prev_matched
+            margin = (self.coarse.ncell + 1) * self.coarse.step
+            if not redo and self.growable and self._outside(est_xy[:, 0], est_xy[:, 1], self.coarse.reach + margin).size:
+                redo = True                                                         # a window may leave a map: grow, step by step
+            if redo:
+                # discard the speculative match: its fault flags and its draw from the random stream
+                torch.cuda.current_stream().synchronize()
+                eng.flags.zero_()
+                if rng_state is not None:
+                    stream_rng.set_state(rng_state)
+                plain(count, reading)
+                continue
+            self._enqueue_commit()
+            ev = torch.cuda.Event()
+            ev.record()
+            pending = (count, reading, raw_heading, ev)
+        if pending is not None:
+            if finish(pending):
+                resamples.append((pending[0], self.resample()))
+        return resamples
+
+    def _enqueue_match(self, reading, prev_raw, dist, has_turn, turn):
+        """prior + coarse + fine match of one scan for all particles; reads the maps, changes no filter state."""
+        L, P = _lib.lib(), self.numParticles
+        _lib.check(L.slam2d_prior(_ptr(self.d_pose), float(reading['theta']), float(prev_raw['theta']),
+                                  has_turn, float(turn), _ptr(self.d_head), P, _ptr(self.d_est),
+                                  _ptr(self.d_psi), _stream()), "slam2d_prior")
+        self._match(self.coarse, self.d_est, 3, dist, self.d_psi, self.d_uniform, self.m_coarse)
+        self._match(self.fine, self.m_coarse, MATCH_DOUBLES, dist, None, None, self.m_fine)
+
+    def _enqueue_commit(self):
+        """Bookkeeping, map update, normaliser and the (asynchronous) download of everything the host reads."""
+        L, P = _lib.lib(), self.numParticles
+        _lib.check(L.slam2d_post_match(_ptr(self.m_fine), _ptr(self.m_coarse), P, _ptr(self.d_pose),
+                                       _ptr(self.d_head), _ptr(self.d_logw), _ptr(self.d_report), _stream()),
+                   "slam2d_post_match")
+        self.engine.grid_update(self.d_pose, 3, self.d_ranges)
+        self._normalize_on_device()
+        self._d_flagsnap.copy_(self.engine.flags)
+        self.engine.flags.zero_()
+        self._h_pack.copy_(self._d_pack, non_blocking=True)
+        self._h_flagsnap.copy_(self._d_flagsnap, non_blocking=True)
+
+    def _check_flag_snapshot(self):
+        f = self._h_flagsnap.numpy().view(np.uint32)
+        bad = np.flatnonzero(f & _lib.FATAL_FLAGS)
+        if bad.size:
+            p = int(bad[0])
+            raise _lib.Slam2dError(f"particle {p}: {_lib.describe_flags(int(f[p]) & _lib.FATAL_FLAGS)}")
 
     @property
     def prev_matched_heading(self):

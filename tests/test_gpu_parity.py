@@ -256,6 +256,47 @@ def _batched_filter_against(pkg, z, readings, n_scans=None, **kw):
     return pf
 
 
+def _pipelined_run_against(pkg, z, readings, **kw):
+    """The same replay through ParticleFilter.run(): the pipelined driver (scan s's match enqueued before scan s-1's
+    results are read, discarded and redone when that scan turns out to resample or to need a map growth) must give the
+    reference's results scan for scan, and consume the random stream exactly as the reference does."""
+    import hashlib
+    n_particles, n_scans, seed, map_m = (int(v) for v in z["cfg"])
+    u = 0.02
+    ogP = [map_m, map_m, readings[0], u, np.pi, 10, 180, 5 * u]
+    rng = np.random.RandomState(seed)
+    pf = pkg.ParticleFilter(n_particles, ogP, list(REF_SM), rng=rng, **kw)
+    seen = []
+
+    def on_scan(count, f, unb):
+        assert unb == bool(z["unbalanced"][count - 1]), f"scan {count}"
+        np.testing.assert_allclose(f.weights, z["weights"][count - 1], rtol=RTOL, atol=1e-290, err_msg=f"scan {count}")
+        np.testing.assert_allclose(f.last_variance, z["variance"][count - 1], rtol=RTOL, atol=1e-12)
+        assert np.array_equal(f.prev_matched, z["matched"][count - 1]), f"scan {count}"
+        seen.append(count)
+    resamples = pf.run(readings[:n_scans], force_resample=set(int(v) for v in z["force_resample"]), on_scan=on_scan)
+    assert seen == list(range(1, n_scans + 1))
+    got = np.array([np.concatenate(([c], idx)) for c, idx in resamples]).reshape(-1, n_particles + 1)
+    assert np.array_equal(got, z["resamples"])
+    for p, m, sha, lim in zip(pf.particles, pf.engine.maps, z["maps_sha"], z["final_lims"]):
+        assert [m.lim_x[0], m.lim_x[1], m.lim_y[0], m.lim_y[1]] == list(lim)
+        packed = codec.pack_counts(p.og.occupancyGridVisited, p.og.occupancyGridTotal)
+        assert hashlib.sha256(packed.tobytes()).digest() == sha.tobytes()
+    # the stream was consumed exactly as by the step-by-step calls: the next draw agrees with a fresh replay's
+    ref_rng = np.random.RandomState(seed)
+    for count in range(2, n_scans + 1):
+        ref_rng.random_sample(n_particles)
+        if count in set(int(r[0]) for r in z["resamples"]):
+            ref_rng.choice(np.arange(n_particles), n_particles, p=z["weights"][count - 1])
+    assert rng.random_sample() == ref_rng.random_sample()
+    return pf
+
+
+@pytest.mark.parametrize("golden", ["flow_fastslam_growth.npz", "flow_fastslam_long.npz"])
+def test_pipelined_driver_reproduces_reference_runs(pkg, intel_readings, golden):
+    _pipelined_run_against(pkg, load_golden(golden), intel_readings)
+
+
 def test_batched_filter_growth_matches_reference(pkg, intel_readings):
     """3 particles x 150 scans from a 10 m initial map: the per-beam growth inside the first update with its
     stale-index writes (Utils/OccupancyGrid.py:144-152), search-window growth at both levels (501^2 ->
