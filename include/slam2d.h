@@ -333,6 +333,25 @@ int slam2d_post_match(const Slam2dMatch* d_fine, const Slam2dMatch* d_coarse, in
 int slam2d_weights_normalize(double* d_logw, const double* d_logconf, int32_t logconf_stride, int32_t N,
                              double* d_w, double* d_stats, void* stream);
 
+/* One scan of Particle.update for P particles in two calls (Algorithm/FastSlam.py:122-135), so that a host loop pays two
+ * library calls per scan instead of six:
+ *   slam2d_scan_match   = slam2d_prior + slam2d_match(coarse; soft-max draw if d_uniform) + slam2d_match(fine, centred on
+ *                         the coarse result, arg-max) -- reads the maps, changes no filter state; `options` as slam2d_match
+ *                         (coarse level);
+ *   slam2d_scan_commit  = slam2d_post_match + slam2d_grid_update at the matched poses + (d_w != NULL) slam2d_weights_normalize
+ *                         over these P particles, whose launch also moves the scan's fault bits from d_flags (cleared) into
+ *                         d_flag_snapshot[P], so that one asynchronous download returns everything the host reads.
+ * Arguments as in the calls they bundle. */
+int slam2d_scan_match(const Slam2dLidar* lidar, const Slam2dLevel* coarse, const Slam2dLevel* fine, const Slam2dMap* d_maps,
+                      int32_t P, const double* d_prev_pose, double raw_theta, double prev_raw_theta, int32_t has_turn,
+                      double raw_turn, const double* d_heading, const double* d_ranges, double est_moving_dist,
+                      const double* d_uniform, double* d_est, double* d_psi_cs, Slam2dMatch* d_coarse, Slam2dMatch* d_fine,
+                      uint32_t* d_flags, uint32_t options, void* stream);
+int slam2d_scan_commit(const Slam2dLidar* lidar, const Slam2dMap* d_maps, int32_t P, const Slam2dMatch* d_fine,
+                       const Slam2dMatch* d_coarse, double* d_prev_pose, double* d_heading, double* d_logw, double* d_report,
+                       const double* d_ranges, uint32_t* d_flags, double* d_w, double* d_stats, uint32_t* d_flag_snapshot,
+                       void* stream);
+
 /* The same normaliser for particles sharded over several processes (one per GPU).  Rank-local
  * half: d_logw[i] += d_logconf[i * logconf_stride], then d_part[3] = [max log w, sum exp(lw - max),
  * sum exp(2 (lw - max))] of this rank's N particles.  The caller all-gathers the 24 bytes of every

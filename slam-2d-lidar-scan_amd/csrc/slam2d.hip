@@ -2093,9 +2093,11 @@ __global__ __launch_bounds__(256) void k_grid_update(Slam2dLidar lid, const Slam
 // K4  weights                                        (Algorithm/FastSlam.py:30-48,135)
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_weights(double* logw, const double* __restrict__ logconf, int cstride, int N,
-                                                 double* w, double* stats) {
+                                                 double* w, double* stats, uint32_t* flags, uint32_t* flag_snapshot) {
     __shared__ double red[256];
     const int tid = threadIdx.x;
+    if (flags)                                         // slam2d_scan_commit: the scan's fault bits move into the report
+        for (int i = tid; i < N; i += 256) { flag_snapshot[i] = flags[i]; flags[i] = 0u; }
     double mx = -INFINITY;
     for (int i = tid; i < N; i += 256) {
         double v = logw[i] + (logconf ? logconf[(size_t)i * cstride] : 0.0);
@@ -2541,7 +2543,35 @@ int slam2d_post_match(const Slam2dMatch* d_fine, const Slam2dMatch* d_coarse, in
 int slam2d_weights_normalize(double* d_logw, const double* d_logconf, int32_t logconf_stride, int32_t N, double* d_w,
                              double* d_stats, void* stream) {
     if (!d_logw || !d_w || !d_stats || N <= 0 || (d_logconf && logconf_stride < 1)) return SLAM2D_E_BADARG;
-    k_weights<<<1, 256, 0, (hipStream_t)stream>>>(d_logw, d_logconf, logconf_stride, N, d_w, d_stats);
+    k_weights<<<1, 256, 0, (hipStream_t)stream>>>(d_logw, d_logconf, logconf_stride, N, d_w, d_stats, nullptr, nullptr);
+    return launch_status();
+}
+
+int slam2d_scan_match(const Slam2dLidar* lidar, const Slam2dLevel* coarse, const Slam2dLevel* fine, const Slam2dMap* d_maps,
+                      int32_t P, const double* d_prev_pose, double raw_theta, double prev_raw_theta, int32_t has_turn,
+                      double raw_turn, const double* d_heading, const double* d_ranges, double est_moving_dist,
+                      const double* d_uniform, double* d_est, double* d_psi_cs, Slam2dMatch* d_coarse, Slam2dMatch* d_fine,
+                      uint32_t* d_flags, uint32_t options, void* stream) {
+    int rc = slam2d_prior(d_prev_pose, raw_theta, prev_raw_theta, has_turn, raw_turn, d_heading, P, d_est, d_psi_cs, stream);
+    if (rc) return rc;
+    rc = slam2d_match(lidar, coarse, d_maps, P, d_est, 3, d_ranges, est_moving_dist, d_psi_cs, d_uniform, d_coarse, d_flags,
+                      options, stream);
+    if (rc) return rc;
+    // the fine level is centred on the coarse result and takes its arg-max (matchMax=True), priors off (:65-73)
+    return slam2d_match(lidar, fine, d_maps, P, reinterpret_cast<const double*>(d_coarse), (int32_t)(sizeof(Slam2dMatch) / sizeof(double)),
+                        d_ranges, est_moving_dist, nullptr, nullptr, d_fine, d_flags, 0u, stream);
+}
+
+int slam2d_scan_commit(const Slam2dLidar* lidar, const Slam2dMap* d_maps, int32_t P, const Slam2dMatch* d_fine,
+                       const Slam2dMatch* d_coarse, double* d_prev_pose, double* d_heading, double* d_logw, double* d_report,
+                       const double* d_ranges, uint32_t* d_flags, double* d_w, double* d_stats, uint32_t* d_flag_snapshot,
+                       void* stream) {
+    int rc = slam2d_post_match(d_fine, d_coarse, P, d_prev_pose, d_heading, d_logw, d_report, stream);
+    if (rc) return rc;
+    if ((rc = slam2d_grid_update(lidar, d_maps, P, d_prev_pose, 3, d_ranges, nullptr, d_flags, stream))) return rc;
+    if (!d_w) return 0;                                // sharded filters run their own normaliser (a collective sits in it)
+    if (!d_stats || !d_flag_snapshot) return SLAM2D_E_BADARG;
+    k_weights<<<1, 256, 0, (hipStream_t)stream>>>(d_logw, nullptr, 1, P, d_w, d_stats, d_flags, d_flag_snapshot);
     return launch_status();
 }
 

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib, parallel
-from .engine import MATCH_DOUBLES, LidarModel, MapState, ParticleEngine, SearchLevel, require_gpu, _ptr, _stream
+from .engine import MATCH_DOUBLES, LidarModel, MapState, ParticleEngine, SearchLevel, pinned_stream, require_gpu, _ptr, _stream
 
 
 class ParticleView:
@@ -259,8 +259,13 @@ class ParticleFilter:
         legacy random stream is consumed exactly as by the unpipelined calls (its state is restored on a discard).
         ``force_resample``: scan counts after which to resample regardless (tests).  ``on_scan(count, self, unbalanced)``
         is called once a scan's results are on the host.  Returns the list of (count, resample indices)."""
+        with pinned_stream():
+            return self._run(readings, first_count, force_resample, on_scan)
+
+    def _run(self, readings, first_count, force_resample, on_scan):
         eng, P = self.engine, self.numParticles
         resamples, pending = [], None          # pending = (count, reading, raw_heading, event) of the scan in flight
+        events = [torch.cuda.Event(), torch.cuda.Event()]
 
         stream_rng = self.rng if self.rng is not None else np.random
 
@@ -296,6 +301,19 @@ class ParticleFilter:
                 assert pending is None
                 plain(count, reading)
                 continue
+            if self.growable and self.prev_matched is not None:
+                # no speculation while some particle's window hugs its map's edge (judged from the poses the host
+                # already has, one or two scans old, with 1 m of slack for the motion since): the scan would very likely
+                # have to be redone step by step, and a discarded match is 0.2 ms of device time
+                slack = (self.coarse.ncell + 1) * self.coarse.step + 1.0
+                if self._outside(self.prev_matched[:, 0], self.prev_matched[:, 1], self.coarse.reach + slack).size:
+                    if pending is not None:
+                        prev_count = pending[0]
+                        if finish(pending):
+                            resamples.append((prev_count, self.resample()))
+                        pending = None
+                    plain(count, reading)
+                    continue
             parity = count & 1
             hr, hu = (self._h_ranges, self._h_uniform) if parity else (self._h_ranges2, self._h_uniform2)
             if pending is None:
@@ -330,7 +348,7 @@ class ParticleFilter:
                 plain(count, reading)
                 continue
             self._enqueue_commit()
-            ev = torch.cuda.Event()
+            ev = events[parity]
             ev.record()
             pending = (count, reading, raw_heading, ev)
         if pending is not None:
@@ -339,24 +357,31 @@ class ParticleFilter:
         return resamples
 
     def _enqueue_match(self, reading, prev_raw, dist, has_turn, turn):
-        """prior + coarse + fine match of one scan for all particles; reads the maps, changes no filter state."""
-        L, P = _lib.lib(), self.numParticles
-        _lib.check(L.slam2d_prior(_ptr(self.d_pose), float(reading['theta']), float(prev_raw['theta']),
-                                  has_turn, float(turn), _ptr(self.d_head), P, _ptr(self.d_est),
-                                  _ptr(self.d_psi), _stream()), "slam2d_prior")
-        self._match(self.coarse, self.d_est, 3, dist, self.d_psi, self.d_uniform, self.m_coarse)
-        self._match(self.fine, self.m_coarse, MATCH_DOUBLES, dist, None, None, self.m_fine)
+        """prior + coarse + fine match of one scan for all particles (slam2d_scan_match: one library call); reads the
+        maps, changes no filter state."""
+        eng, P = self.engine, self.numParticles
+        eng.refresh_bits()
+        self.coarse.next_generation()
+        self.fine.next_generation()
+        _lib.check(_lib.lib().slam2d_scan_match(
+            C.byref(eng.lidar_c), C.byref(self.coarse.c), C.byref(self.fine.c), _ptr(eng.d_maps), P, _ptr(self.d_pose),
+            float(reading['theta']), float(prev_raw['theta']), has_turn, float(turn), _ptr(self.d_head), _ptr(self.d_ranges),
+            float(dist), _ptr(self.d_uniform), _ptr(self.d_est), _ptr(self.d_psi), _ptr(self.m_coarse), _ptr(self.m_fine),
+            _ptr(eng.flags), _lib.MATCH_PRUNE_BY_PRIOR if self.prune_by_prior else 0, _stream()), "slam2d_scan_match")
 
     def _enqueue_commit(self):
         """Bookkeeping, map update, normaliser and the (asynchronous) download of everything the host reads."""
-        L, P = _lib.lib(), self.numParticles
-        _lib.check(L.slam2d_post_match(_ptr(self.m_fine), _ptr(self.m_coarse), P, _ptr(self.d_pose),
-                                       _ptr(self.d_head), _ptr(self.d_logw), _ptr(self.d_report), _stream()),
-                   "slam2d_post_match")
-        self.engine.grid_update(self.d_pose, 3, self.d_ranges)
-        self._normalize_on_device()
-        self._d_flagsnap.copy_(self.engine.flags)
-        self.engine.flags.zero_()
+        eng, P = self.engine, self.numParticles
+        own_norm = not self.sharded
+        _lib.check(_lib.lib().slam2d_scan_commit(
+            C.byref(eng.lidar_c), _ptr(eng.d_maps), P, _ptr(self.m_fine), _ptr(self.m_coarse), _ptr(self.d_pose),
+            _ptr(self.d_head), _ptr(self.d_logw), _ptr(self.d_report), _ptr(self.d_ranges), _ptr(eng.flags),
+            _ptr(self.d_w) if own_norm else None, _ptr(self.d_stats) if own_norm else None,
+            _ptr(self._d_flagsnap) if own_norm else None, _stream()), "slam2d_scan_commit")
+        if not own_norm:
+            self._normalize_on_device()                 # two launches around the one all-gather of the scan
+            self._d_flagsnap.copy_(eng.flags)
+            eng.flags.zero_()
         self._h_pack.copy_(self._d_pack, non_blocking=True)
         self._h_flagsnap.copy_(self._d_flagsnap, non_blocking=True)
 
@@ -376,7 +401,7 @@ class ParticleFilter:
         """[P, 4] array (x0, x1, y0, y1) of the particles' map limits, rebuilt only after a growth or a
         resample (the engine's map list is replaced then)."""
         maps = self.engine.maps
-        key = (id(maps), sum(len(m.growth_log) for m in maps))
+        key = (id(maps), self.engine.maps_version)      # refresh_maps() bumps the version after every growth / resample
         if getattr(self, "_lims_key", None) != key:
             self._lims = np.array([[m.lim_x[0], m.lim_x[1], m.lim_y[0], m.lim_y[1]] for m in maps])
             self._lims_key = key

@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Where the host's time goes in the closed loop (config 3): cProfile over ParticleFilter.run() on the Intel log."""
+import cProfile, importlib, os, pstats, sys, math
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import numpy as np, torch
+pkg = importlib.import_module("slam-2d-lidar-scan_amd")
+dataio = importlib.import_module("slam-2d-lidar-scan_amd.dataio")
+readings = dataio.read_npz(os.path.join(REPO, "tests", "golden", "intel_gfs.npz"))
+u = 0.02
+ogP = [50.0, 50.0, readings[0], u, math.pi, 10, 180, 5 * u]
+smP = [1.4, 0.25, 2, 0.1, 0.25, 0.3, 0.15, 5]
+pf = pkg.ParticleFilter(64, ogP, smP, rng=np.random.RandomState(0))
+pf.run(readings[:20])
+pf = pkg.ParticleFilter(64, ogP, smP, rng=np.random.RandomState(0))
+torch.cuda.synchronize()
+pr = cProfile.Profile(); pr.enable()
+pf.run(readings)
+torch.cuda.synchronize()
+pr.disable()
+st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(28)
