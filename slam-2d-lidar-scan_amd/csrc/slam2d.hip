@@ -827,6 +827,7 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
     const Slam2dFrame fr = lv.frames[p];
     const double ex = est[(size_t)p * estride], ey = est[(size_t)p * estride + 1];
     const int B = lid.beams;
+    DBG_CLOCK(40, it == 0 && p == 0);
     int n = 256;
     while (n < B) n <<= 1;
     int hsize = 512;                                       // power of two >= 1.5 * beams (load factor <= 2/3)
@@ -874,6 +875,7 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
         }
     }
     __syncthreads();
+    DBG_CLOCK(41, it == 0 && p == 0);
 #pragma unroll
     for (int q = 0; q < SLAM2D_MAX_BEAMS / 256; ++q) {
         if (key[q] == INT_MAX) continue;
@@ -895,12 +897,16 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
                 for (int tx = tx0; tx <= tx1;) {           // runs of bits inside one 32-bit word
                     const int bit = ty * lv.tmax + tx;
                     const int len = min(tx1 - tx + 1, 32 - (bit & 31));
-                    atomicOr(&need_s[bit >> 5], (len == 32 ? ~0u : ((1u << len) - 1u)) << (bit & 31));
+                    const uint32_t m = (len == 32 ? ~0u : ((1u << len) - 1u)) << (bit & 31);
+                    // neighbouring beams mark the same tiles: a plain read first, the atomic only for new bits (the word
+                    // is a 64-way conflict otherwise -- measured at 1081 beams)
+                    if ((need_s[bit >> 5] & m) != m) atomicOr(&need_s[bit >> 5], m);
                     tx += len;
                 }
         }
     }
     __syncthreads();
+    DBG_CLOCK(42, it == 0 && p == 0);
     if (mark)
         for (int i = tid; i < nneed; i += 256) {
             const uint32_t v = need_s[i];
@@ -938,6 +944,7 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
             }
             ++pos;
         }
+    DBG_CLOCK(43, it == 0 && p == 0);
     if (tid == 255) {
         int K = pos;                                       // the last thread ends at the total
         if (K > lv.kmax) { K = lv.kmax; bad = true; }

@@ -85,11 +85,14 @@ class ParticleFilter:
     kernels without host round trips.
     ``total_particles`` / ``first_index`` describe this rank's slice when sharded;
     ``rng`` defaults to the legacy global NumPy stream like the reference.
+    ``match_max``: take the arg-max at the coarse level instead of the soft-max draw (``matchScan(matchMax=True)``, what
+    the reference's single-trajectory driver does, Utils/ScanMatcher_OGBased.py:244); no uniform is drawn then.  With one
+    particle, ``ParticleFilter(1, ..., match_max=True).run(readings)`` is that driver (``:226-256``) on the batched path.
     ``bnb``: score the pose cubes by branch and bound over 4x4 pose tiles (include/slam2d.h) -- None: wherever
     the cube is large enough for it to pay (engine.bnb_default), True / False: wherever applicable / nowhere."""
 
     def __init__(self, numParticles, ogParameters, smParameters, device=None, growable=True, rng=None,
-                 total_particles=None, first_index=0, group=None, bnb=None):
+                 total_particles=None, first_index=0, group=None, bnb=None, match_max=False):
         (mapX, mapY, initXY, unit, fov, max_range, beams, wall) = ogParameters            # :66
         (sr, half_rad, sigma, move_sigma, max_dev, turn_sigma, miss, cf) = smParameters   # :67-68
         self.device = require_gpu(device or "cuda:0")
@@ -97,6 +100,7 @@ class ParticleFilter:
         self.total_particles = total_particles or numParticles
         self.first_index = first_index
         self.growable = growable
+        self.match_max = bool(match_max)
         self.rng = rng
         self.group = group
         self.sharded = self.total_particles != numParticles
@@ -220,11 +224,12 @@ class ParticleFilter:
             est_xy = self.prev_matched                              # estimate = previous matched x, y (:79)
             if self.growable:
                 self._grow_for_windows(est_xy[:, 0], est_xy[:, 1], self.coarse.reach)
-            self._stage(self._h_uniform, self.d_uniform, self._draw_uniforms())
+            if not self.match_max:
+                self._stage(self._h_uniform, self.d_uniform, self._draw_uniforms())
             _lib.check(L.slam2d_prior(_ptr(self.d_pose), float(reading['theta']), float(self.prev_raw['theta']),
                                       has_turn, float(turn), _ptr(self.d_head), P, _ptr(self.d_est),
                                       _ptr(self.d_psi), _stream()), "slam2d_prior")
-            self._match(self.coarse, self.d_est, 3, dist, self.d_psi, self.d_uniform, self.m_coarse)
+            self._match(self.coarse, self.d_est, 3, dist, self.d_psi, None if self.match_max else self.d_uniform, self.m_coarse)
             if self.growable and not self._fine_window_cannot_grow(est_xy, (self.coarse.ncell + 1) * self.coarse.step):
                 eng.take_flags()
                 c = eng.read_matches(self.m_coarse)
@@ -323,7 +328,8 @@ class ParticleFilter:
             dist, raw_heading, has_turn, turn = self._raw_odometry(reading, prev_raw, prev_raw_heading)
             rng_state = stream_rng.get_state()
             self._stage(hr, self.d_ranges, np.asarray(reading['range'], dtype=np.float64))
-            self._stage(hu, self.d_uniform, self._draw_uniforms())
+            if not self.match_max:
+                self._stage(hu, self.d_uniform, self._draw_uniforms())
             self._enqueue_match(reading, prev_raw, dist, has_turn, turn)          # speculative: scan count-1 not seen yet
             redo = False
             if pending is not None:
@@ -366,7 +372,8 @@ class ParticleFilter:
         _lib.check(_lib.lib().slam2d_scan_match(
             C.byref(eng.lidar_c), C.byref(self.coarse.c), C.byref(self.fine.c), _ptr(eng.d_maps), P, _ptr(self.d_pose),
             float(reading['theta']), float(prev_raw['theta']), has_turn, float(turn), _ptr(self.d_head), _ptr(self.d_ranges),
-            float(dist), _ptr(self.d_uniform), _ptr(self.d_est), _ptr(self.d_psi), _ptr(self.m_coarse), _ptr(self.m_fine),
+            float(dist), None if self.match_max else _ptr(self.d_uniform), _ptr(self.d_est), _ptr(self.d_psi), _ptr(self.m_coarse),
+            _ptr(self.m_fine),
             _ptr(eng.flags), _lib.MATCH_PRUNE_BY_PRIOR if self.prune_by_prior else 0, _stream()), "slam2d_scan_match")
 
     def _enqueue_commit(self):

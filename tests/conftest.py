@@ -27,3 +27,12 @@ def intel_readings():
     pose = z["pose"]
     return [{"x": float(p[0]), "y": float(p[1]), "theta": float(p[2]), "range": list(map(float, r))}
             for p, r in zip(pose, rng)]
+
+
+@pytest.fixture(scope="session")
+def csail_readings():
+    """The bundled CSAIL log (406 scans x 361 beams) decoded from the compact fixture."""
+    z = load_golden("csail_gfs.npz")
+    rng = z["range_cm"].astype(np.float64) / 100.0
+    return [{"x": float(p[0]), "y": float(p[1]), "theta": float(p[2]), "range": list(map(float, r))}
+            for p, r in zip(z["pose"], rng)]

@@ -10,7 +10,7 @@ needs /root/reference).  Companion of make_golden.py; writes
                             search-window growth, forced resamples between particles whose maps
                             have grown differently.
 
-    python tests/golden/make_golden_long.py [long|growth|all]
+    python tests/golden/make_golden_long.py [long|growth|csail|all]
 
 Per scan and particle the fixtures hold the uniform consumed by the soft-max draw, the matched
 pose, the raw and the normalised weight, the variance / unbalanced decision, the resample
@@ -89,8 +89,38 @@ def run(name, readings, n_particles, n_scans, seed, map_m, force_resample=()):
             final_lims=np.array(lims), final_shapes=np.array(shapes), shape_events=np.array(SHAPES, dtype=np.int64))
 
 
+def csail(n_scans=80):
+    """A second dataset through the reference's single-trajectory flow (Utils/ScanMatcher_OGBased.py:226-256): the
+    bundled CSAIL log, 361 beams over pi (722 spokes, 59 search angles) -- a beam count other than the Intel log's 180.
+    Writes the log re-encoded (csail_gfs.npz) and flow_scanmatch_csail.npz."""
+    import json
+    import os
+    d = json.load(open(os.path.join(mg.REF, "DataSet/PreprocessedData/csail_gfs")))["map"]
+    readings = [d[k] for k in sorted(d.keys())]
+    rng = np.array([r["range"] for r in readings])
+    cm = np.rint(rng * 100)
+    assert np.array_equal(cm / 100.0, rng) and cm.max() < 65536
+    mg.save("csail_gfs.npz", range_cm=cm.astype(np.uint16), pose=np.array([[r["x"], r["y"], r["theta"]] for r in readings]))
+    beams = len(readings[0]["range"])
+    og = mg.OccupancyGrid(10, 10, readings[0], 0.02, np.pi, beams, 10, 0.1)
+    sm = mg.ScanMatcher(og, *mg.REF_DEFAULT_SM)
+    t = time.time()
+    with mg.quiet():
+        poses, confs = mg.flow(readings, og, sm, n_scans)
+    print(f"  reference flow over {n_scans} CSAIL scans ({beams} beams): {time.time() - t:.1f} s")
+    mg.save("flow_scanmatch_csail.npz", poses=poses, confs=confs, beams=np.int64(beams),
+            final_shape=np.array(og.occupancyGridVisited.shape),
+            final_lims=np.array([og.mapXLim[0], og.mapXLim[1], og.mapYLim[0], og.mapYLim[1]]),
+            final_map_sha=np.frombuffer(hashlib.sha256(
+                codec.pack_counts(og.occupancyGridVisited, og.occupancyGridTotal).tobytes()).digest(), dtype=np.uint8))
+
+
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("csail", "all"):
+        csail()
+    if what == "csail":
+        return
     readings = mg.load_intel()
     if what in ("growth", "all"):
         run("flow_fastslam_growth.npz", readings, 3, 150, 1, 10, force_resample=(30, 75, 120))

@@ -165,6 +165,60 @@ def test_scanmatch_flow_matches_reference(pkg, intel_readings):
     assert hashlib.sha256(codec.pack_counts(visited, total).tobytes()).digest() == z["final_map_sha"].tobytes()
 
 
+def test_scanmatch_flow_csail_matches_reference(pkg, csail_readings):
+    """The same flow over the reference's second bundled log (CSAIL, 361 beams: 722 spokes, 59 search angles, two beams
+    per endpoint thread), all 80 golden scans: poses identical, confidences within the bar, final map identical."""
+    import hashlib
+    z = load_golden("flow_scanmatch_csail.npz")
+    n = len(z["poses"])
+    r0 = csail_readings[0]
+    og = pkg.OccupancyGrid(10, 10, r0, 0.02, np.pi, int(z["beams"]), 10, 0.1)
+    sm = pkg.ScanMatcher(og, *REF_SM)
+    out, confs = so.run_scanmatch_flow(csail_readings, og, sm, max_scans=n)
+    got = np.array([[m["x"], m["y"], m["theta"]] for m in out])
+    bad = np.flatnonzero((got != z["poses"][:n]).any(axis=1))
+    assert bad.size == 0, f"first differing scan {bad[0] + 1}: {got[bad[0]]} vs {z['poses'][bad[0]]}"
+    np.testing.assert_allclose(np.array(confs, dtype=np.float64), z["confs"][:n], rtol=RTOL)
+    visited, total = og.occupancyGridVisited, og.occupancyGridTotal
+    assert list(visited.shape) == list(z["final_shape"])
+    assert [og.mapXLim[0], og.mapXLim[1], og.mapYLim[0], og.mapYLim[1]] == list(z["final_lims"])
+    assert hashlib.sha256(codec.pack_counts(visited, total).tobytes()).digest() == z["final_map_sha"].tobytes()
+    # the same driver on the batched path: ParticleFilter(1, match_max=True).run() -- lazy field build, prior pruning /
+    # branch and bound, pipelined scans -- must walk the same trajectory and build the same map
+    u = 0.02
+    ogP = [10, 10, r0, u, np.pi, 10, int(z["beams"]), 5 * u]
+    for bnb in (False, True):
+        pf = pkg.ParticleFilter(1, ogP, list(REF_SM), rng=np.random.RandomState(0), bnb=bnb, match_max=True)
+        pf.run(csail_readings[:n])
+        traj = np.array([t[0] for t in pf.trajectory])
+        assert np.array_equal(traj, z["poses"][:n, :2]), f"bnb={bnb}"
+        assert np.array_equal(pf.prev_matched[0], z["poses"][n - 1])
+        m = pf.engine.maps[0]
+        assert [m.lim_x[0], m.lim_x[1], m.lim_y[0], m.lim_y[1]] == list(z["final_lims"])
+        assert hashlib.sha256(codec.pack_counts(*m.download()).tobytes()).digest() == z["final_map_sha"].tobytes()
+
+
+def test_single_trajectory_driver_on_the_batched_path(pkg, intel_readings):
+    """Utils/ScanMatcher_OGBased.py:226-256 (processSensorData) as a product-side driver: one particle, arg-max matches,
+    ParticleFilter.run().  All 320 golden Intel scans: trajectory, last pose and final map identical to the reference's."""
+    import hashlib
+    z = load_golden("flow_scanmatch.npz")
+    n = len(z["poses"])
+    u = 0.02
+    ogP = [10, 10, intel_readings[0], u, np.pi, 10, 180, 5 * u]
+    pf = pkg.ParticleFilter(1, ogP, list(REF_SM), match_max=True)
+    confs = []
+    pf.run(intel_readings[:n], on_scan=lambda count, f, unb: confs.append(float(f.last_confidence[0])))
+    traj = np.array([t[0] for t in pf.trajectory])
+    assert np.array_equal(traj, z["poses"][:n, :2])
+    assert np.array_equal(pf.prev_matched[0], z["poses"][n - 1])
+    np.testing.assert_allclose(np.array(confs), z["confs"][:n], rtol=RTOL)
+    m = pf.engine.maps[0]
+    assert [m.rows, m.cols] == list(z["final_shape"])
+    assert [m.lim_x[0], m.lim_x[1], m.lim_y[0], m.lim_y[1]] == list(z["final_lims"])
+    assert hashlib.sha256(codec.pack_counts(*m.download()).tobytes()).digest() == z["final_map_sha"].tobytes()
+
+
 def test_dropin_under_fastslam_caller(pkg, intel_readings):
     """The reference's Particle / ParticleFilter caller logic (restated in the oracle module,
     Algorithm/FastSlam.py:10-140) driving the HIP OccupancyGrid / ScanMatcher classes

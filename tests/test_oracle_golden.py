@@ -145,6 +145,20 @@ def test_scanmatch_flow_exact(intel_readings, lut_ref):
     assert np.array_equal(np.array(confs, dtype=np.float64), z["confs"][:n])
 
 
+def test_scanmatch_flow_csail_exact(csail_readings):
+    """A second dataset and beam count: the first 25 scans of the reference's single-trajectory flow over the CSAIL
+    log (361 beams over pi: 722 spokes, 59 search angles)."""
+    z = load_golden("flow_scanmatch_csail.npz")
+    r0 = csail_readings[0]
+    og = so.GridOracle(10, 10, r0, 0.02, np.pi, int(z["beams"]), 10, 0.1)
+    sm = so.MatcherOracle(og, *REF_SM)
+    n = 25
+    out, confs = so.run_scanmatch_flow(csail_readings, og, sm, max_scans=n)
+    got = np.array([[m["x"], m["y"], m["theta"]] for m in out])
+    assert np.array_equal(got, z["poses"][:n])
+    assert np.array_equal(np.array(confs, dtype=np.float64), z["confs"][:n])
+
+
 def test_fastslam_flow_exact(intel_readings):
     """4 particles x 40 scans, seed 0, two forced resamples: weights, variance,
     matched poses, consumed uniforms, resample draws and final maps."""
