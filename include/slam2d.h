@@ -294,9 +294,13 @@ int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2
  * the cells of the beam's spoke up to the measured range (each window cell belongs to exactly
  * one spoke, each spoke to at most one beam, so the counts are updated without atomics).
  *   d_pose[p*pose_stride + 0..2] = matched (x, y, theta)
- *   d_beam_shift: NULL, or [P][beams][2] int32 (dx, dy) index shifts reproducing the
- *                 reference's stale-index writes when the map grew during that beam
- *                 (Utils/OccupancyGrid.py:144-147). */
+ *   d_beam_shift: NULL, or [P][beams][6] int32 reproducing the reference's stale-index writes when the map
+ *                 grew during a beam (Utils/OccupancyGrid.py:144-152): (dc, dr) low-side shift of the beam's own
+ *                 growth, (ac, ar) sum of the low-side shifts of the later beams, (cols, rows) map shape right
+ *                 after the beam's growth; a cell with final index (mx, my) is written at
+ *                 wrap(mx - dc - ac, cols) + ac (wrap: a negative index + cols, as Python).  Such writes can land
+ *                 on cells of other beams (the reference adds both increments): with d_beam_shift the counts are
+ *                 updated atomically and occ_bits is NOT maintained -- call slam2d_map_refresh_bits afterwards. */
 int slam2d_grid_update(const Slam2dLidar* lidar, const Slam2dMap* d_maps, int32_t P,
                        const double* d_pose, int32_t pose_stride, const double* d_ranges,
                        const int32_t* d_beam_shift, uint32_t* d_flags, void* stream);

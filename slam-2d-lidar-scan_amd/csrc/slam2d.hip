@@ -2012,10 +2012,13 @@ __global__ __launch_bounds__(256) void k_grid_update(Slam2dLidar lid, const Slam
         const int kbeg = bp[b0], kend = bp[max(b0, b1)];
         const double* __restrict__ sr = lid.spoke_r;
         const uint32_t* __restrict__ sc = lid.spoke_cells;
-        int sx = 0, sy = 0;
-        if (beam_shift) {   // stale indices after a low-side growth inside this beam (:144-147)
-            sx = beam_shift[((size_t)p * lid.beams + beam) * 2 + 0];
-            sy = beam_shift[((size_t)p * lid.beams + beam) * 2 + 1];
+        // stale indices of a beam during which the map grew on a low side (:144-152): shift of the beam's own growth,
+        // of the later beams' growths, and the map shape at the time of the write (Python wraps a negative index
+        // against THAT shape) -- LidarModel.grow_for_update
+        int sx = 0, sy = 0, ax = 0, ay = 0, wc = m.cols, wr = m.rows;
+        if (beam_shift) {
+            const int32_t* bs = beam_shift + ((size_t)p * lid.beams + beam) * 6;
+            sx = bs[0]; sy = bs[1]; ax = bs[2]; ay = bs[3]; wc = bs[4]; wr = bs[5];
         }
         const uint32_t ncells = (uint32_t)m.rows * (uint32_t)m.pitch;
         for (int k0 = kbeg + lane; k0 < kend; k0 += 64 * UPDB_UNROLL) {
@@ -2070,8 +2073,10 @@ __global__ __launch_bounds__(256) void k_grid_update(Slam2dLidar lid, const Slam
                 }
                 int mx = mxs[u] - sx, my = mys[u] - sy;
                 if (beam_shift) {
-                    if (mx < 0) mx += m.cols;
-                    if (my < 0) my += m.rows;
+                    mx -= ax; my -= ay;
+                    if (mx < 0) mx += wc;
+                    if (my < 0) my += wr;
+                    mx += ax; my += ay;
                 }
                 if (inc[u] && (mx < 0 || mx >= m.cols || my < 0 || my >= m.rows)) { f |= SLAM2D_F_UPDATE_OUTSIDE_MAP; inc[u] = 0u; }
                 mxs[u] = mx; mys[u] = my;
@@ -2083,6 +2088,13 @@ __global__ __launch_bounds__(256) void k_grid_update(Slam2dLidar lid, const Slam
             for (int u = 0; u < UPDB_UNROLL; ++u) {
                 if (!inc[u]) continue;
                 if ((c[u] & 0xffffu) + (inc[u] & 0xffffu) > 0xffffu) { f |= SLAM2D_F_COUNT_OVERFLOW; continue; }
+                if (beam_shift) {
+                    // stale-index writes can land on a cell of ANOTHER beam's spoke (the reference then adds both
+                    // increments, Utils/OccupancyGrid.py:148-152): no plain read-modify-write here; the caller rebuilds
+                    // the occupancy bits afterwards (slam2d_map_refresh_bits)
+                    atomicAdd(&m.cells[at[u]], inc[u]);
+                    continue;
+                }
                 const uint32_t nc = c[u] + inc[u];
                 m.cells[at[u]] = nc;
                 const bool was = 2u * (c[u] >> 16) > (c[u] & 0xffffu), is = 2u * (nc >> 16) > (nc & 0xffffu);

@@ -234,20 +234,29 @@ class LidarModel:
             yield i, c, empty, occ
 
     def grow_for_update(self, m, x, y, theta, rng):
-        """Per-beam growth of MapState ``m`` exactly in the reference's order (:147).  Returns the
-        [beams, 2] int32 low-side shifts that make k_grid_update reproduce the reference's stale-index
-        writes (:144-152), or None if nothing grew."""
+        """Per-beam growth of MapState ``m`` exactly in the reference's order (:147).  The reference computes a beam's
+        cell indices BEFORE that beam's growth and writes with them afterwards (:144-152): a low-side growth inside
+        beam i leaves its indices stale by the inserted block, a negative stale index wraps (Python semantics) against
+        the array as it is at that moment, and later low-side growths move what was written.  Returns, for
+        k_grid_update, int32 [beams, 6] = (dc_i, dr_i: low-side shift of beam i's own growth; ac_i, ar_i: sum of the
+        low-side shifts of all LATER beams; cols_i, rows_i: map shape right after beam i's growth) -- or None if
+        nothing grew.  A cell with final index (mx, my) is then written at wrap(mx - dc_i - ac_i, cols_i) + ac_i."""
         W, xs = self.width, self.xs
-        shifts = np.zeros((self.beams, 2), dtype=np.int32)
+        rec = np.zeros((self.beams, 6), dtype=np.int32)
         grew = False
         for i, c, _, occ in self.beam_cells(theta, rng):
-            if not occ.any():
-                continue
-            dc, dr = m.ensure_contains(x + xs[c[occ] % W], y + xs[c[occ] // W], self.unit)
-            if dc or dr:
-                shifts[i] = (dc, dr)
-                grew = True
-        return shifts if grew else None
+            if occ.any():
+                before = len(m.growth_log)
+                dc, dr = m.ensure_contains(x + xs[c[occ] % W], y + xs[c[occ] // W], self.unit)
+                rec[i, 0:2] = (dc, dr)
+                grew |= len(m.growth_log) != before
+            rec[i, 4:6] = (m.cols, m.rows)
+        if not grew:
+            return None
+        # low-side shifts of the beams after i
+        rec[:, 2] = np.concatenate((np.cumsum(rec[::-1, 0])[::-1][1:], [0]))
+        rec[:, 3] = np.concatenate((np.cumsum(rec[::-1, 1])[::-1][1:], [0]))
+        return rec
 
     def on(self, device):
         """Device copies + the C struct (kept alive with the tensors)."""
@@ -649,6 +658,9 @@ class ParticleEngine:
         check(self.L.slam2d_grid_update(C.byref(self.lidar_c), _ptr(self.d_maps), self.P, _ptr(d_pose), stride,
                                         _ptr(d_ranges), _ptr(d_beam_shift),
                                         _ptr(self.flags), _stream()), "slam2d_grid_update")
+        if d_beam_shift is not None:                   # the stale-index path does not keep the occupancy bits in step
+            for m in self.maps:
+                m.bits_valid = False
 
     def take_flags(self, fatal=_lib.FATAL_FLAGS):
         """Synchronise, fetch and clear the per-particle fault bits; raise on fatal ones."""
