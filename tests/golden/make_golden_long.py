@@ -32,7 +32,7 @@ codec = mg.codec
 
 def run(name, readings, n_particles, n_scans, seed, map_m, force_resample=()):
     u = 0.02
-    ogP = [map_m, map_m, readings[0], u, np.pi, 10, 180, 5 * u]      # Algorithm/FastSlam.py:204 order
+    ogP = [map_m, map_m, readings[0], u, np.pi, 10, len(readings[0]['range']), 5 * u]      # Algorithm/FastSlam.py:204 order
     smP = list(mg.REF_DEFAULT_SM)
     np.random.seed(seed)
     with mg.quiet():
@@ -84,7 +84,7 @@ def run(name, readings, n_particles, n_scans, seed, map_m, force_resample=()):
     mg.save(name, weights=np.array(W, dtype=np.float64), raw_weights=np.array(C, dtype=np.float64),
             variance=np.array(V), matched=np.array(M), uniforms=np.array(U), unbalanced=np.array(UNB),
             resamples=np.array(RS).reshape(-1, n_particles + 1).astype(np.int64),
-            cfg=np.array([n_particles, n_scans, seed, map_m]),
+            cfg=np.array([n_particles, n_scans, seed, map_m]), beams=np.int64(len(readings[0]['range'])),
             force_resample=np.array(force_resample, dtype=np.int64), maps_sha=np.array(maps_sha),
             final_lims=np.array(lims), final_shapes=np.array(shapes), shape_events=np.array(SHAPES, dtype=np.int64))
 
@@ -108,6 +108,7 @@ def csail(n_scans=80):
     with mg.quiet():
         poses, confs = mg.flow(readings, og, sm, n_scans)
     print(f"  reference flow over {n_scans} CSAIL scans ({beams} beams): {time.time() - t:.1f} s")
+    run("flow_fastslam_csail.npz", readings, 3, 60, 2, 10, force_resample=(20, 40))
     mg.save("flow_scanmatch_csail.npz", poses=poses, confs=confs, beams=np.int64(beams),
             final_shape=np.array(og.occupancyGridVisited.shape),
             final_lims=np.array([og.mapXLim[0], og.mapXLim[1], og.mapYLim[0], og.mapYLim[1]]),

@@ -282,7 +282,7 @@ def _batched_filter_against(pkg, z, readings, n_scans=None, **kw):
     n_particles, total_scans, seed, map_m = (int(v) for v in z["cfg"])
     n_scans = n_scans or total_scans
     u = 0.02
-    ogP = [map_m, map_m, readings[0], u, np.pi, 10, 180, 5 * u]
+    ogP = [map_m, map_m, readings[0], u, np.pi, 10, int(z["beams"]) if "beams" in z.files else 180, 5 * u]
     pf = pkg.ParticleFilter(n_particles, ogP, list(REF_SM), rng=np.random.RandomState(seed), **kw)
     resamples, events, last = [], [], [None] * n_particles
     for count, raw in enumerate(readings[:n_scans], start=1):
@@ -317,7 +317,7 @@ def _pipelined_run_against(pkg, z, readings, **kw):
     import hashlib
     n_particles, n_scans, seed, map_m = (int(v) for v in z["cfg"])
     u = 0.02
-    ogP = [map_m, map_m, readings[0], u, np.pi, 10, 180, 5 * u]
+    ogP = [map_m, map_m, readings[0], u, np.pi, 10, int(z["beams"]) if "beams" in z.files else 180, 5 * u]
     rng = np.random.RandomState(seed)
     pf = pkg.ParticleFilter(n_particles, ogP, list(REF_SM), rng=rng, **kw)
     seen = []
@@ -349,6 +349,17 @@ def _pipelined_run_against(pkg, z, readings, **kw):
 @pytest.mark.parametrize("golden", ["flow_fastslam_growth.npz", "flow_fastslam_long.npz"])
 def test_pipelined_driver_reproduces_reference_runs(pkg, intel_readings, golden):
     _pipelined_run_against(pkg, load_golden(golden), intel_readings)
+
+
+@pytest.mark.parametrize("driver", ["calls", "run", "run_bnb"])
+def test_batched_filter_csail_matches_reference(pkg, csail_readings, driver):
+    """The reference's FastSLAM on its second log (CSAIL, 361 beams; 3 particles x 60 scans from a 10 m map, two forced
+    resamples): per-call loop, pipelined driver, and the latter with branch and bound forced on."""
+    z = load_golden("flow_fastslam_csail.npz")
+    if driver == "calls":
+        _batched_filter_against(pkg, z, csail_readings)
+    else:
+        _pipelined_run_against(pkg, z, csail_readings, bnb=(driver == "run_bnb") or None)
 
 
 def test_batched_filter_growth_matches_reference(pkg, intel_readings):

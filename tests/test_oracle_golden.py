@@ -190,7 +190,7 @@ def _oracle_fastslam_against(z, readings, n_scans):
     unbalanced decision, matched poses, resample draws and every change of a map's shape, all exact."""
     n_particles, _, seed, map_m = (int(v) for v in z["cfg"])
     u = 0.02
-    ogP = [map_m, map_m, readings[0], u, np.pi, 10, 180, 5 * u]
+    ogP = [map_m, map_m, readings[0], u, np.pi, 10, int(z["beams"]) if "beams" in z.files else 180, 5 * u]
     rng = np.random.RandomState(seed)
     pf = so.ParticleFilterOracle(n_particles, ogP, list(REF_SM), rng=rng)
     resamples, events, last = [], [], [None] * n_particles
@@ -229,6 +229,12 @@ def test_fastslam_growth_flow_exact(intel_readings):
         for p, sha, lim in zip(pf.particles, z["maps_sha"], z["final_lims"]):
             assert hashlib.sha256(codec.pack_counts(p.og.visited, p.og.total).tobytes()).digest() == sha.tobytes()
             assert [p.og.mapXLim[0], p.og.mapXLim[1], p.og.mapYLim[0], p.og.mapYLim[1]] == list(lim)
+
+
+def test_fastslam_csail_flow_exact(csail_readings):
+    """The FastSLAM flow on the CSAIL log (361 beams), first 12 scans by default, all 60 with SLAM2D_LONG_ORACLE=1."""
+    z = load_golden("flow_fastslam_csail.npz")
+    _oracle_fastslam_against(z, csail_readings, int(z["cfg"][1]) if os.environ.get("SLAM2D_LONG_ORACLE") == "1" else 12)
 
 
 @pytest.mark.skipif(os.environ.get("SLAM2D_LONG_ORACLE") != "1",
