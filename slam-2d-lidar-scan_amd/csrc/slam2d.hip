@@ -100,6 +100,49 @@ __device__ __forceinline__ int reflect_index(int i, int n) {
     return m < n ? m : period - 1 - m;
 }
 
+// sum over the 16 lanes of a DPP row, in every lane of the row: quad butterflies, then the two mirrors (no LDS
+// crossbar round trips: a ds_bpermute butterfly of 4 x 64-bit values costs ~1 us in a lone wave)
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_u64(const unsigned long long v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, 0xF, 0xF, true);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long row16_sum_u64(unsigned long long t) {
+    t += dpp_u64<0xB1>(t);           // quad_perm [1, 0, 3, 2]
+    t += dpp_u64<0x4E>(t);           // quad_perm [2, 3, 0, 1]
+    t += dpp_u64<0x141>(t);          // row_half_mirror
+    t += dpp_u64<0x140>(t);          // row_mirror
+    return t;
+}
+// the same for a double (returned as its bits): used for the 16 exp(score - M) of a tile
+__device__ __forceinline__ unsigned long long row16_sum_f64(double v) {
+    v += __longlong_as_double((long long)dpp_u64<0xB1>((unsigned long long)__double_as_longlong(v)));
+    v += __longlong_as_double((long long)dpp_u64<0x4E>((unsigned long long)__double_as_longlong(v)));
+    v += __longlong_as_double((long long)dpp_u64<0x141>((unsigned long long)__double_as_longlong(v)));
+    v += __longlong_as_double((long long)dpp_u64<0x140>((unsigned long long)__double_as_longlong(v)));
+    return (unsigned long long)__double_as_longlong(v);
+}
+// wave-wide minimum / maximum of a double without LDS round trips (all 64 lanes active): DPP inside the four rows,
+// v_readlane across them
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(const double v) {
+    return __longlong_as_double((long long)dpp_u64<CTRL>((unsigned long long)__double_as_longlong(v)));
+}
+__device__ __forceinline__ double readlane_f64(const double v, const int l) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double wave64_min(double v) {
+    v = fmin(v, dpp_f64<0xB1>(v)); v = fmin(v, dpp_f64<0x4E>(v)); v = fmin(v, dpp_f64<0x141>(v)); v = fmin(v, dpp_f64<0x140>(v));
+    return fmin(fmin(readlane_f64(v, 0), readlane_f64(v, 16)), fmin(readlane_f64(v, 32), readlane_f64(v, 48)));
+}
+__device__ __forceinline__ double wave64_max(double v) {
+    v = fmax(v, dpp_f64<0xB1>(v)); v = fmax(v, dpp_f64<0x4E>(v)); v = fmax(v, dpp_f64<0x141>(v)); v = fmax(v, dpp_f64<0x140>(v));
+    return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
+}
+
 // ------------------------------------------------------------------------------------
 // K2a  frame geometry                      (Utils/ScanMatcher_OGBased.py:21-28)
 // ------------------------------------------------------------------------------------
@@ -312,6 +355,8 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
     const int r = RAD > 0 ? RAD : lv.blur_radius;
     const int ext = BLUR_TILE + 2 * r;
     const int tid = threadIdx.x;
+    const bool dbg = p == 0 && blockIdx.x == 0 && mode == 0;
+    DBG_CLOCK(50, dbg);
     const uint8_t* occ = lv.occ + (size_t)p * lv.fmax * lv.fpitch;
     const uint8_t stamp = occ_stamp(lv);
     uint8_t* state = lv.tilestate + ((size_t)p * lv.tmax + tby) * lv.tmax + tbx;
@@ -394,6 +439,7 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
         }
         any = __syncthreads_or(exact);
     }
+    DBG_CLOCK(51, dbg);
     const double L = lv.log_miss;
     const double fmin_used = mode == 1 ? fr.field_min : lv.floor_value;
     const double thr = 0.5 * fmin_used;                                            // :44
@@ -439,6 +485,7 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
             }
         }
         __syncthreads();
+        DBG_CLOCK(52, dbg);
         {   // axis-1 pass: lane = (row y, 4 consecutive columns)
             const int y = tid >> 2, x0 = (tid & 3) * 4;
             double mrow[4 + 2 * RAD];
@@ -504,14 +551,16 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
             }
         }
     }
+    DBG_CLOCK(53, dbg);
     if (mode == 0) {
-        for (int o = 32; o > 0; o >>= 1) { lmin = fmin(lmin, __shfl_down(lmin, o)); lmax = fmax(lmax, __shfl_down(lmax, o)); }
+        lmin = wave64_min(lmin); lmax = wave64_max(lmax);       // (a ds_bpermute butterfly here was ~1 us of the tile's ~4.5)
         if (tid == 0) {                                // reduced by k_blur_check_redo
             lv.tilemin[((size_t)p * lv.tmax + tby) * lv.tmax + tbx] = lmin;
             lv.tilemax[((size_t)p * lv.tmax + tby) * lv.tmax + tbx] = lmax;
         }
     }
     __syncthreads();                                   // LDS is reused by the block's next tile
+    DBG_CLOCK(54, dbg);
 }
 
 // Tile triage, one 1024-thread block per particle looping over its 16x16 field tiles:
@@ -982,9 +1031,23 @@ __device__ __forceinline__ Best wave_best(Best me) {
     return me;
 }
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) v += __shfl_xor(v, o);      // fixed butterfly: deterministic
-    return v;
+    // fixed order: DPP butterflies inside the four rows of 16 lanes, then (row 0 + row 1) + (row 2 + row 3) -- deterministic,
+    // and no LDS-crossbar round trips (all 64 lanes must be active)
+    v += dpp_f64<0xB1>(v); v += dpp_f64<0x4E>(v); v += dpp_f64<0x141>(v); v += dpp_f64<0x140>(v);
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+// wave_best for candidates whose index ascends with the lane (so "lowest index" = lowest lane): ballots and readlanes
+// instead of a 6-step butterfly of three values.  np.argmax semantics as `better`.  All 64 lanes must be active.
+__device__ __forceinline__ Best wave_best_ordered(const Best me) {
+    const unsigned long long nanm = __ballot(me.nan != 0);
+    if (nanm) {
+        const int l = __ffsll((long long)nanm) - 1;
+        return Best{NAN, __builtin_amdgcn_readlane(me.i, l), 1};
+    }
+    const double m = wave64_max(me.v);
+    const unsigned long long eq = __ballot(me.v == m && me.i != INT_MAX);
+    if (!eq) return Best{-INFINITY, INT_MAX, 0};
+    return Best{m, __builtin_amdgcn_readlane(me.i, __ffsll((long long)eq) - 1), 0};
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -1184,7 +1247,8 @@ __global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks
             }
         }
     // per-wave reduction for k_select: max / argmax / sum exp(score - max)
-    me = wave_best(me);
+    if constexpr (RQ == 1) me = wave_best_ordered(me);     // lane = one slot: indices ascend with the lane
+    else me = wave_best(me);
     double ex = 0.0;
 #pragma unroll
     for (int r = 0; r < RQ; ++r)
@@ -1276,7 +1340,7 @@ __global__ __launch_bounds__(64) void k_sweep_small(Slam2dLevel lv, int P) {
             if (better(cand, me)) me = cand;
         }
     }
-    me = wave_best(me);
+    me = wave_best_ordered(me);
     double ex = 0.0;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -1469,29 +1533,6 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
 // the 4 poses (4 by + r, 4 bx .. 4 bx + 3) against cells k0 + s, k0 + s + kstep, ...; on return every lane of a
 // row group holds the row's 4 sums over ALL the cells this wave walked (reduced over the 16 slices).
 #define EXACT_DEPTH 8
-// sum over the 16 lanes of a DPP row, in every lane of the row: quad butterflies, then the two mirrors (no LDS
-// crossbar round trips: a ds_bpermute butterfly of 4 x 64-bit values costs ~1 us in a lone wave)
-template <int CTRL>
-__device__ __forceinline__ unsigned long long dpp_u64(const unsigned long long v) {
-    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, 0xF, 0xF, true);
-    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, 0xF, 0xF, true);
-    return ((unsigned long long)hi << 32) | lo;
-}
-__device__ __forceinline__ unsigned long long row16_sum_u64(unsigned long long t) {
-    t += dpp_u64<0xB1>(t);           // quad_perm [1, 0, 3, 2]
-    t += dpp_u64<0x4E>(t);           // quad_perm [2, 3, 0, 1]
-    t += dpp_u64<0x141>(t);          // row_half_mirror
-    t += dpp_u64<0x140>(t);          // row_mirror
-    return t;
-}
-// the same for a double (returned as its bits): used for the 16 exp(score - M) of a tile
-__device__ __forceinline__ unsigned long long row16_sum_f64(double v) {
-    v += __longlong_as_double((long long)dpp_u64<0xB1>((unsigned long long)__double_as_longlong(v)));
-    v += __longlong_as_double((long long)dpp_u64<0x4E>((unsigned long long)__double_as_longlong(v)));
-    v += __longlong_as_double((long long)dpp_u64<0x141>((unsigned long long)__double_as_longlong(v)));
-    v += __longlong_as_double((long long)dpp_u64<0x140>((unsigned long long)__double_as_longlong(v)));
-    return (unsigned long long)__double_as_longlong(v);
-}
 // byte offsets of the first NPRE cells of lane slice s (cells s, s + 16, ...), beyond-the-buffer where the list ends
 template <int NPRE>
 __device__ __forceinline__ void tile_prefetch(const int* __restrict__ cl, const int K, int (&pre)[NPRE]) {
@@ -1608,7 +1649,7 @@ __global__ __launch_bounds__(64) void k_bound(Slam2dLevel lv, int P) {
             if (4 * q + e < nbt && better(cand, me)) me = cand;
         }
     }
-    me = wave_best(me);
+    me = wave_best_ordered(me);                             // tiles ascend with the lane
     DBG_CLOCK(2, b == 0);
     // the tile with the largest bound, exactly: its best score is a lower bound of the cube's maximum
     const int seed = me.i;

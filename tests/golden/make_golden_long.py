@@ -10,7 +10,7 @@ needs /root/reference).  Companion of make_golden.py; writes
                             search-window growth, forced resamples between particles whose maps
                             have grown differently.
 
-    python tests/golden/make_golden_long.py [long|growth|csail|all]
+    python tests/golden/make_golden_long.py [long|growth|csail|params|all]
 
 Per scan and particle the fixtures hold the uniform consumed by the soft-max draw, the matched
 pose, the raw and the normalised weight, the variance / unbalanced decision, the resample
@@ -116,8 +116,34 @@ def csail(n_scans=80):
                 codec.pack_counts(og.occupancyGridVisited, og.occupancyGridTotal).tobytes()).digest(), dtype=np.uint8))
 
 
+def params(n_scans=45):
+    """The reference's single-trajectory flow over the Intel log with constructor parameters OTHER than its defaults, so
+    that the parametrised code paths are pinned too: unit 0.04, coarse factor 4 (coarse sigma 0.75 -> blur radius 3, a
+    radius without a specialised kernel; fine radius 12), lidar range 8 m, search radius 1.2 / half angle 0.2 (cubes
+    21 x 15 x 15 and 21 x 9 x 9), wall 0.12, miss probability 0.2, other sigmas."""
+    readings = mg.load_intel()
+    og_args = (12, 12, readings[0], 0.04, np.pi, len(readings[0]["range"]), 8, 0.12)
+    sm_args = (1.2, 0.2, 3, 0.15, 0.3, 0.25, 0.2, 4)
+    og = mg.OccupancyGrid(*og_args)
+    sm = mg.ScanMatcher(og, *sm_args)
+    t = time.time()
+    with mg.quiet():
+        poses, confs = mg.flow(readings, og, sm, n_scans)
+    print(f"  reference flow, alternative parameters, {n_scans} scans: {time.time() - t:.1f} s")
+    mg.save("flow_scanmatch_params.npz", poses=poses, confs=confs,
+            og_args=np.array([12, 12, 0.04, np.pi, len(readings[0]["range"]), 8, 0.12]), sm_args=np.array(sm_args, dtype=np.float64),
+            final_shape=np.array(og.occupancyGridVisited.shape),
+            final_lims=np.array([og.mapXLim[0], og.mapXLim[1], og.mapYLim[0], og.mapYLim[1]]),
+            final_map_sha=np.frombuffer(hashlib.sha256(
+                codec.pack_counts(og.occupancyGridVisited, og.occupancyGridTotal).tobytes()).digest(), dtype=np.uint8))
+
+
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("params", "all"):
+        params()
+    if what == "params":
+        return
     if what in ("csail", "all"):
         csail()
     if what == "csail":

@@ -219,6 +219,34 @@ def test_single_trajectory_driver_on_the_batched_path(pkg, intel_readings):
     assert hashlib.sha256(codec.pack_counts(*m.download()).tobytes()).digest() == z["final_map_sha"].tobytes()
 
 
+def test_scanmatch_flow_other_parameters_matches_reference(pkg, intel_readings):
+    """The reference's flow with non-default constructor parameters (unit 0.04, coarse factor 4: blur radii 3 -- no
+    specialised kernel -- and 12; 8 m lidar; 21 x 15 x 15 / 21 x 9 x 9 cubes): drop-in classes, and the batched path with
+    and without branch and bound."""
+    import hashlib
+    z = load_golden("flow_scanmatch_params.npz")
+    mx, my, unit, fov, beams, R, wall = z["og_args"]
+    a = z["sm_args"]
+    smP = [a[0], a[1], a[2], a[3], a[4], a[5], a[6], int(a[7])]
+    n = len(z["poses"])
+    og = pkg.OccupancyGrid(mx, my, intel_readings[0], unit, fov, int(beams), R, wall)
+    sm = pkg.ScanMatcher(og, *smP)
+    out, confs = so.run_scanmatch_flow(intel_readings, og, sm, max_scans=n)
+    got = np.array([[m["x"], m["y"], m["theta"]] for m in out])
+    bad = np.flatnonzero((got != z["poses"]).any(axis=1))
+    assert bad.size == 0, f"first differing scan {bad[0] + 1}: {got[bad[0]]} vs {z['poses'][bad[0]]}"
+    np.testing.assert_allclose(np.array(confs, dtype=np.float64), z["confs"], rtol=RTOL)
+    assert hashlib.sha256(codec.pack_counts(og.occupancyGridVisited, og.occupancyGridTotal).tobytes()).digest() == z["final_map_sha"].tobytes()
+    ogP = [mx, my, intel_readings[0], unit, fov, R, int(beams), wall]
+    for bnb in (False, True):
+        pf = pkg.ParticleFilter(1, ogP, smP, bnb=bnb, match_max=True)
+        pf.run(intel_readings[:n])
+        assert np.array_equal(np.array([t[0] for t in pf.trajectory]), z["poses"][:, :2]), f"bnb={bnb}"
+        m = pf.engine.maps[0]
+        assert [m.lim_x[0], m.lim_x[1], m.lim_y[0], m.lim_y[1]] == list(z["final_lims"])
+        assert hashlib.sha256(codec.pack_counts(*m.download()).tobytes()).digest() == z["final_map_sha"].tobytes()
+
+
 def test_dropin_under_fastslam_caller(pkg, intel_readings):
     """The reference's Particle / ParticleFilter caller logic (restated in the oracle module,
     Algorithm/FastSlam.py:10-140) driving the HIP OccupancyGrid / ScanMatcher classes

@@ -159,6 +159,23 @@ def test_scanmatch_flow_csail_exact(csail_readings):
     assert np.array_equal(np.array(confs, dtype=np.float64), z["confs"][:n])
 
 
+def test_scanmatch_flow_other_parameters_exact(intel_readings):
+    """The reference's flow with non-default constructor parameters (unit 0.04, coarse factor 4, blur radii 3 and 12, 8 m
+    lidar, 21 x 15 x 15 / 21 x 9 x 9 cubes): 45 scans, poses / confidences / final map."""
+    z = load_golden("flow_scanmatch_params.npz")
+    mx, my, unit, fov, beams, R, wall = z["og_args"]
+    og = so.GridOracle(mx, my, intel_readings[0], unit, fov, int(beams), R, wall)
+    a = z["sm_args"]
+    sm = so.MatcherOracle(og, a[0], a[1], a[2], a[3], a[4], a[5], a[6], int(a[7]))
+    n = len(z["poses"])
+    out, confs = so.run_scanmatch_flow(intel_readings, og, sm, max_scans=n)
+    got = np.array([[m["x"], m["y"], m["theta"]] for m in out])
+    assert np.array_equal(got, z["poses"])
+    assert np.array_equal(np.array(confs, dtype=np.float64), z["confs"])
+    assert list(og.visited.shape) == list(z["final_shape"])
+    assert hashlib.sha256(codec.pack_counts(og.visited, og.total).tobytes()).digest() == z["final_map_sha"].tobytes()
+
+
 def test_fastslam_flow_exact(intel_readings):
     """4 particles x 40 scans, seed 0, two forced resamples: weights, variance,
     matched poses, consumed uniforms, resample draws and final maps."""
