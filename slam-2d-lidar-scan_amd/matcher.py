@@ -18,9 +18,31 @@ from .engine import MATCH_DOUBLES, ParticleEngine, SearchLevel
 _level_cache = {}
 
 
+class _Exclusive:
+    """A shared workspace may serve one call at a time: the drop-in methods are synchronous (nothing is live between
+    calls), and this guard turns any overlap -- two threads, a re-entrant callback -- into an error instead of silent
+    corruption of another matcher's results."""
+
+    def __init__(self, *levels):
+        self.levels = levels
+
+    def __enter__(self):
+        for lv in self.levels:
+            if getattr(lv, "_busy", False):
+                raise _lib.Slam2dError("a ScanMatcher call is already using this configuration's shared workspace "
+                                       "(the drop-in classes are synchronous and not re-entrant)")
+        for lv in self.levels:
+            lv._busy = True
+
+    def __exit__(self, *exc):
+        for lv in self.levels:
+            lv._busy = False
+        return False
+
+
 def _shared_level(og, key_extra, **kw):
     """Workspaces are shared by all matchers of one configuration on one device:
-    calls are synchronous and sequential, so nothing is live between calls."""
+    calls are synchronous and sequential, so nothing is live between calls (_Exclusive enforces it)."""
     key = (str(og.device), id(og.lidar)) + key_extra
     if key not in _level_cache:
         _level_cache[key] = SearchLevel(og.lidar, 1, og.device, bnb=False, **kw)     # whole cubes: brute-force sweep
@@ -72,12 +94,13 @@ class ScanMatcher:
         """(:20-39)  Returns xRangeList, yRangeList, probSP (host float64 array decoded from
         the device's fixed-point field: values exact to 2^-32 relative to probMin)."""
         level = self._level(unitLength, sigma, missMatchProbAtCoarse, self.searchRadius, self.searchHalfRad, False)
-        eng = self.og.engine()
-        d_c = eng.to_device([[estimatedX, estimatedY]])
-        eng = self._build_field(eng, level, d_c, 2, estimatedX, estimatedY)
-        self.last_flags = int(eng.take_flags()[0])
-        fr = level.frames()[0]
-        return [fr["xlo"], fr["xhi"]], [fr["ylo"], fr["yhi"]], level.field(0)
+        with _Exclusive(level):
+            eng = self.og.engine()
+            d_c = eng.to_device([[estimatedX, estimatedY]])
+            eng = self._build_field(eng, level, d_c, 2, estimatedX, estimatedY)
+            self.last_flags = int(eng.take_flags()[0])
+            fr = level.frames()[0]
+            return [fr["xlo"], fr["xhi"]], [fr["ylo"], fr["yhi"]], level.field(0)
 
     def matchScan(self, reading, estMovingDist, estMovingTheta, count, matchMax=True):
         """(:47-79)  Coarse then fine; returns (matchedReading, coarse confidence)."""
@@ -86,25 +109,26 @@ class ScanMatcher:
             return reading, 1                                                  # :51-52
         ex, ey, eth = reading['x'], reading['y'], reading['theta']
         coarse, fine = self.coarse_level(), self.fine_level()
-        eng = self.og.engine()
-        d_est = eng.to_device([[ex, ey, eth]])
-        d_rng = eng.to_device(rMeasure)
-        d_psi = eng.to_device(eng.psi_table([estMovingTheta]))
-        d_u = None
-        if not matchMax:                        # one draw from the legacy global stream, like np.random.choice (:138)
-            d_u = eng.to_device([np.random.random_sample()])
-        m_coarse, m_fine = eng.match_buffer("coarse"), eng.match_buffer("fine")
-        eng = self._build_field(eng, coarse, d_est, 3, ex, ey)
-        eng.sweep(coarse, d_est, 3, d_rng, estMovingDist, d_psi, d_u, m_coarse)
-        eng.take_flags()
-        c = eng.read_matches(m_coarse)[0]
-        eng = self._build_field(eng, fine, m_coarse, MATCH_DOUBLES, float(c["x"]), float(c["y"]))
-        eng.sweep(fine, m_coarse, MATCH_DOUBLES, d_rng, estMovingDist, None, None, m_fine)
-        eng.take_flags()
-        f = eng.read_matches(m_fine)[0]
-        matched = {"x": float(f["x"]), "y": float(f["y"]), "theta": float(f["theta"]), "range": rMeasure}
-        self.last = dict(coarse=c.copy(), fine=f.copy())
-        return matched, np.float64(c["confidence"])                            # :79
+        with _Exclusive(coarse, fine):
+            eng = self.og.engine()
+            d_est = eng.to_device([[ex, ey, eth]])
+            d_rng = eng.to_device(rMeasure)
+            d_psi = eng.to_device(eng.psi_table([estMovingTheta]))
+            d_u = None
+            if not matchMax:                        # one draw from the legacy global stream, like np.random.choice (:138)
+                d_u = eng.to_device([np.random.random_sample()])
+            m_coarse, m_fine = eng.match_buffer("coarse"), eng.match_buffer("fine")
+            eng = self._build_field(eng, coarse, d_est, 3, ex, ey)
+            eng.sweep(coarse, d_est, 3, d_rng, estMovingDist, d_psi, d_u, m_coarse)
+            eng.take_flags()
+            c = eng.read_matches(m_coarse)[0]
+            eng = self._build_field(eng, fine, m_coarse, MATCH_DOUBLES, float(c["x"]), float(c["y"]))
+            eng.sweep(fine, m_coarse, MATCH_DOUBLES, d_rng, estMovingDist, None, None, m_fine)
+            eng.take_flags()
+            f = eng.read_matches(m_fine)[0]
+            matched = {"x": float(f["x"]), "y": float(f["y"]), "theta": float(f["theta"]), "range": rMeasure}
+            self.last = dict(coarse=c.copy(), fine=f.copy())
+            return matched, np.float64(c["confidence"])                            # :79
 
     def searchToMatch(self, probSP, estimatedX, estimatedY, estimatedTheta, rMeasure, xRangeList, yRangeList,
                       searchRadius, searchHalfRad, unitLength, estMovingDist, estMovingTheta, fineSearch=False,
@@ -112,6 +136,12 @@ class ScanMatcher:
         """(:91-151) on a caller-supplied field (re-quantised to the device's fixed-point format)."""
         rMeasure = np.asarray(rMeasure)
         level = self._level(unitLength, 1.0, 0.5, searchRadius, searchHalfRad, fineSearch)
+        with _Exclusive(level):
+            return self._search_to_match(level, probSP, estimatedX, estimatedY, estimatedTheta, rMeasure, xRangeList,
+                                         yRangeList, estMovingDist, estMovingTheta, matchMax)
+
+    def _search_to_match(self, level, probSP, estimatedX, estimatedY, estimatedTheta, rMeasure, xRangeList, yRangeList,
+                         estMovingDist, estMovingTheta, matchMax):
         eng = self.og.engine()
         fh, fw = probSP.shape
         if fh > level.fmax or fw > level.fmax:
