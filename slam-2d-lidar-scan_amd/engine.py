@@ -115,7 +115,7 @@ def bnb_default(nx, ntheta, beams, tmax):
     large enough that 1/16 of the gathers + a few per cent of the tiles + three more launches beat the brute-force
     sweep.  SLAM2D_BNB=0 / 1 forces it off / on wherever it is applicable (cube edge 9..64, <= 20000 field tiles)."""
     import os
-    ok = 9 <= nx <= 64 and tmax * tmax <= 20000
+    ok = 9 <= nx <= 64
     env = os.environ.get("SLAM2D_BNB", "auto")
     if env == "0" or not ok:
         return False
@@ -459,8 +459,10 @@ class SearchLevel:
         npose = self.nx * self.nx
         self.npartial = self.ntheta * (-(-npose // 64))
         self.tmax = -(-self.fmax // 16)             # 16x16-cell tiles of the blur
-        applicable = 9 <= self.nx <= 64 and self.tmax * self.tmax <= 20000
-        self.bnb = bnb_default(self.nx, self.ntheta, lidar.beams, self.tmax) if bnb is None else (bool(bnb) and applicable)
+        nbt_ = (self.nx + 3) // 4
+        # limits of k_exact_select: one thread scans <= 32 tile bounds, per-theta sums live in LDS (256 thetas)
+        applicable = 9 <= self.nx <= 64 and self.ntheta <= 256 and self.ntheta * nbt_ * 4 * ((nbt_ + 3) // 4) <= 32768
+        self.bnb = (bnb_default(self.nx, self.ntheta, lidar.beams, self.tmax) if bnb is None else bool(bnb)) and applicable
         nbt = (self.nx + 3) // 4
         nbq4 = 4 * ((nbt + 3) // 4)
         i32, f64 = torch.int32, torch.float64
