@@ -441,7 +441,7 @@ def main():
                   for k, lv in (("coarse", hot.coarse), ("fine", hot.fine)) if lv is not None}
 
     variants = {}
-    if not args.no_variants:
+    if not args.no_variants and world == 1:          # (multi-GPU scaling runs: the headline only)
         def variant(bnb, prune, note):
             saved = [(lv, lv.c.bnb) for lv in (hot.coarse, hot.fine) if lv is not None]
             for lv, _ in saved:
