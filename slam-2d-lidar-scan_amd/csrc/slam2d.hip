@@ -80,6 +80,11 @@ __device__ __forceinline__ double unorder_bits(unsigned long long k) {
 // The occupied-field image and the tile flags are not cleared between builds: a cell / tile is
 // occupied when its byte equals the build's generation stamp (Slam2dLevel.occ_gen, 1..255).
 __device__ __forceinline__ uint8_t occ_stamp(const Slam2dLevel& lv) { return (uint8_t)(lv.occ_gen ? lv.occ_gen : 1); }
+// The needed-tile bitmap is double-buffered by the generation's parity: a call marks and reads bitmap (occ_gen & 1) and
+// its triage clears the OTHER one for the next call -- no clearing launch, and the bitmap of the last call stays readable.
+__device__ __forceinline__ uint32_t* need_bitmap(const Slam2dLevel& lv, const int which, const int P, const int p, const int nneed) {
+    return lv.tileneed + ((size_t)(which & 1) * P + p) * nneed;
+}
 // 0x01 in every byte of v that equals the stamp byte (exact per byte), 0x00 elsewhere
 __device__ __forceinline__ uint32_t bytes_equal(const uint32_t v, const uint8_t stamp) {
     const uint32_t t = v ^ (0x01010101u * stamp);
@@ -185,7 +190,7 @@ __global__ void k_frame_axis(Slam2dLidar lid, Slam2dLevel lv, const Slam2dMap* _
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (clear_need && axis == 1) {                     // the needed-tile bitmap of slam2d_match
         const int nneed = (lv.tmax * lv.tmax + 31) >> 5;
-        for (int w = j; w < nneed; w += gridDim.x * blockDim.x) lv.tileneed[(size_t)p * nneed + w] = 0u;
+        for (int w = j; w < nneed; w += gridDim.x * blockDim.x) need_bitmap(lv, lv.occ_gen, gridDim.y, p, nneed)[w] = 0u;
     }
     if (ranges && axis == 0) {
         // covertMeasureToXY (Utils/ScanMatcher_OGBased.py:81-89) once per particle: k_endpoints' ntheta blocks of the
@@ -592,7 +597,11 @@ __global__ __launch_bounds__(TRIAGE_THREADS) void k_tile_triage(Slam2dLevel lv, 
     {
         const uint8_t* tiles = lv.tilemask + (size_t)p * ntile;
         for (int t = tid; t < ntile; t += TRIAGE_THREADS) { tiles_s[t] = tiles[t] == stamp; state_s[t] = state[t]; }
-        if (lazy) for (int w = tid; w < nneed; w += TRIAGE_THREADS) need_s[w] = lv.tileneed[(size_t)p * nneed + w];
+        if (lazy)
+            for (int w = tid; w < nneed; w += TRIAGE_THREADS) {
+                need_s[w] = need_bitmap(lv, lv.occ_gen, gridDim.x, p, nneed)[w];
+                need_bitmap(lv, lv.occ_gen + 1, gridDim.x, p, nneed)[w] = 0u;       // clean for the next call's k_endpoints
+            }
     }
     if (tid < 2) base[tid] = 0;
     __syncthreads();
@@ -850,6 +859,35 @@ __device__ __forceinline__ void write_priors(const Slam2dLevel& lv, const int p,
     if (threadIdx.x == 0) lv.ring[0] = ring_base <= lv.ring_cap ? ring_base : -1;     // -1: does not fit, sweep in full
 }
 
+// k_frame_axis's per-particle work, done by one 256-thread block (the priors block of k_endpoints) when that
+// kernel is not launched: frame, flags, axis tables (:21-37,173-176).
+__device__ __forceinline__ void frame_duties(const Slam2dLidar& lid, const Slam2dLevel& lv, const Slam2dMap* __restrict__ maps,
+                                             const double* __restrict__ centre, const int cstride, uint32_t* flags, const int p) {
+    const Slam2dMap m = maps[p];
+    uint32_t f;
+    const Slam2dFrame fr = make_frame(lid, lv, m, centre[(size_t)p * cstride], centre[(size_t)p * cstride + 1], f);
+    if (threadIdx.x == 0) {
+        lv.frames[p] = fr;
+        lv.tilecount[2 * p] = 0; lv.tilecount[2 * p + 1] = 0;
+        if (lv.bnb) lv.bnb_best[p] = order_bits(-INFINITY);
+        if (f) atomicOr(&flags[p], f);
+    }
+    bool bad = false;
+    for (int axis = 0; axis < 2; ++axis) {
+        const int n = axis == 0 ? fr.mx1 - fr.mx0 : fr.my1 - fr.my0;
+        const double lo = axis == 0 ? fr.xlo : fr.ylo;
+        const int dim = axis == 0 ? fr.fw : fr.fh;
+        for (int j = threadIdx.x; j < n; j += blockDim.x) {
+            const double coord = axis == 0 ? m.X[fr.mx0 + j] : m.Y[fr.my0 + j];
+            int idx = (int)((coord - lo) / lv.step);       // astype(int): truncation toward zero
+            if (idx < 0) idx += dim;                       // Python negative-index wrap (:37)
+            if (idx < 0 || idx >= dim) { idx = -1; bad = true; }
+            (axis == 0 ? lv.axis_x : lv.axis_y)[(size_t)p * lv.wmax + j] = idx;
+        }
+    }
+    if (bad) atomicOr(&flags[p], SLAM2D_F_FIELD_INDEX);
+}
+
 // ------------------------------------------------------------------------------------
 // K1a  beam endpoints -> unique field cells per theta   (Utils/ScanMatcher_OGBased.py:81-89,
 //      117-121,162-176).  One block per (theta, particle); np.unique through an LDS hash set, ordered
@@ -860,7 +898,9 @@ __device__ __forceinline__ void write_priors(const Slam2dLevel& lv, const int p,
 __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel lv, const double* __restrict__ est,
                                                    int estride, const double* __restrict__ ranges, uint32_t* flags,
                                                    double est_dist, const double* __restrict__ psi_cs, int mark, int prune,
-                                                   int beam_table) {
+                                                   int beam_table, const Slam2dMap* __restrict__ maps) {
+    // maps != NULL: this launch is not preceded by k_frame_axis (slam2d_match below 512 beams): the theta blocks derive
+    // the frame fields they need themselves, the priors block also writes frames[p], the axis tables and the flags.
     // np.unique (:120) through an LDS hash set: every beam inserts its cell; of the beams that hit one
     // cell the lowest beam index owns it (atomicMin), so the list keeps beam order -- which is spatially
     // coherent (neighbouring beams hit neighbouring cells) and deterministic.  Scores are exact
@@ -873,8 +913,20 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
         write_priors(lv, p, est_dist, psi_cs, prune);
         return;
     }
-    const Slam2dFrame fr = lv.frames[p];
+    if (it == lv.ntheta + 1) {                             // a second one (only when maps != NULL): what k_frame_axis would have done
+        frame_duties(lid, lv, maps, est, estride, flags, p);
+        return;
+    }
     const double ex = est[(size_t)p * estride], ey = est[(size_t)p * estride + 1];
+    Slam2dFrame fr;
+    if (maps) {
+        // no k_frame_axis ahead of this launch: the four frame fields used here, in make_frame's very expressions (:22-25)
+        fr.xlo = ex - lv.reach; fr.ylo = ey - lv.reach;
+        fr.fw = min((int)(((ex + lv.reach) - fr.xlo) / lv.step) + 1, lv.fmax);
+        fr.fh = min((int)(((ey + lv.reach) - fr.ylo) / lv.step) + 1, lv.fmax);
+    } else {
+        fr = lv.frames[p];
+    }
     const int B = lid.beams;
     DBG_CLOCK(40, it == 0 && p == 0);
     int n = 256;
@@ -959,7 +1011,7 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
     if (mark)
         for (int i = tid; i < nneed; i += 256) {
             const uint32_t v = need_s[i];
-            uint32_t* g = lv.tileneed + (size_t)p * nneed + i;
+            uint32_t* g = need_bitmap(lv, lv.occ_gen, gridDim.y, p, nneed) + i;
             if (v && (__hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & v) != v) atomicOr(g, v);
         }
     int keep = 0, mine = 0;
@@ -1533,6 +1585,7 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
 // the 4 poses (4 by + r, 4 bx .. 4 bx + 3) against cells k0 + s, k0 + s + kstep, ...; on return every lane of a
 // row group holds the row's 4 sums over ALL the cells this wave walked (reduced over the 16 slices).
 #define EXACT_DEPTH 8
+#define SLAM2D_BEAM_TABLE_MIN 512   // beams from which k_frame_axis (with its per-particle beam-endpoint table) is worth its launch
 // byte offsets of the first NPRE cells of lane slice s (cells s, s + 16, ...), beyond-the-buffer where the list ends
 template <int NPRE>
 __device__ __forceinline__ void tile_prefetch(const int* __restrict__ cl, const int K, int (&pre)[NPRE]) {
@@ -2414,16 +2467,17 @@ static void launch_field(const Slam2dLevel& lv, const Slam2dMap* d_maps, int P, 
 // beam endpoints, unique cells per theta, priors (/ needed tiles)
 static void launch_endpoints(const Slam2dLidar& lid, const Slam2dLevel& lv, int P, const double* d_est, int est_stride,
                              const double* d_ranges, double est_moving_dist, const double* d_psi_cs, uint32_t* d_flags,
-                             bool mark, bool prune, hipStream_t s, bool beam_table = false) {
+                             bool mark, bool prune, hipStream_t s, bool beam_table = false,
+                             const Slam2dMap* own_frame_maps = nullptr) {
     StageScope prof(SLAM2D_STAGE_ENDPOINTS, s);
     int n = 256;
     while (n < lid.beams) n <<= 1;
     int hsize = 512;
     while (hsize < lid.beams + (lid.beams >> 1)) hsize <<= 1;
     const size_t ep_lds = (size_t)(2 * hsize + 8 + (mark ? (lv.tmax * lv.tmax + 31) / 32 : 0)) * sizeof(int);
-    k_endpoints<<<dim3(lv.ntheta + 1, P), 256, ep_lds, s>>>(lid, lv, d_est, est_stride, d_ranges, d_flags, est_moving_dist,
+    k_endpoints<<<dim3(lv.ntheta + (own_frame_maps ? 2 : 1), P), 256, ep_lds, s>>>(lid, lv, d_est, est_stride, d_ranges, d_flags, est_moving_dist,
                                                         lv.fine ? nullptr : d_psi_cs, mark ? 1 : 0, prune ? 1 : 0,
-                                                        beam_table && lv.beam_xy ? 1 : 0);
+                                                        beam_table && lv.beam_xy ? 1 : 0, own_frame_maps);
 }
 
 // cube sweep + selection
@@ -2545,10 +2599,16 @@ int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2
         const int nx = 2 * lv.ncell + 1, nslot = nx * ((nx + 3) / 4);
         if (bound > 0 && 2 * bound <= nslot) ring_chunks = cdiv(bound, WAVE);     // worth it only for a thin ring
     }
+    // Below SLAM2D_BEAM_TABLE_MIN beams k_frame_axis is not launched at all: the endpoint kernel's per-particle block does
+    // its work (one launch less per level); above, k_frame_axis also tabulates the beam endpoints once per particle.
+    static const bool keep_frame_kernel = [] { const char* e = getenv("SLAM2D_FRAME_KERNEL"); return e && atoi(e) == 1; }();
+    const bool framed = lidar->beams >= SLAM2D_BEAM_TABLE_MIN || keep_frame_kernel || lv.occ_gen == 0;
+    const Slam2dMap* own = framed ? nullptr : d_maps;
+    if (lv.occ_gen < 0 || lv.occ_gen > 255) return SLAM2D_E_BADARG;
     if (lv.bnb) {
-        // branch and bound over 4x4 pose tiles: pooled cost planes, tile bounds + seed tiles, surviving tiles, selection
-        if ((rc = launch_frames(*lidar, lv, d_maps, P, d_est, est_stride, d_flags, true, s, d_ranges))) return rc;
-        launch_endpoints(*lidar, lv, P, d_est, est_stride, d_ranges, est_moving_dist, d_psi_cs, d_flags, true, false, s, true);
+        // branch and bound over 4x4 pose tiles: tile bounds + seed tiles, surviving tiles + selection
+        if (framed && (rc = launch_frames(*lidar, lv, d_maps, P, d_est, est_stride, d_flags, true, s, d_ranges))) return rc;
+        launch_endpoints(*lidar, lv, P, d_est, est_stride, d_ranges, est_moving_dist, d_psi_cs, d_flags, true, false, s, framed, own);
         launch_field(lv, d_maps, P, d_flags, true, s);
         const unsigned grid = (unsigned)cdiv(P, 8) * 8 * lv.ntheta;
         {
@@ -2562,8 +2622,8 @@ int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2
         return launch_status();
     }
     // the endpoints need only the frame, so they run first and tell the field build which tiles matter
-    if ((rc = launch_frames(*lidar, lv, d_maps, P, d_est, est_stride, d_flags, true, s, d_ranges))) return rc;
-    launch_endpoints(*lidar, lv, P, d_est, est_stride, d_ranges, est_moving_dist, d_psi_cs, d_flags, true, ring_chunks > 0, s, true);
+    if (framed && (rc = launch_frames(*lidar, lv, d_maps, P, d_est, est_stride, d_flags, true, s, d_ranges))) return rc;
+    launch_endpoints(*lidar, lv, P, d_est, est_stride, d_ranges, est_moving_dist, d_psi_cs, d_flags, true, ring_chunks > 0, s, framed, own);
     launch_field(lv, d_maps, P, d_flags, true, s);
     if ((rc = launch_scores(lv, P, d_est, est_stride, d_uniform, d_out, s, ring_chunks))) return rc;
     return launch_status();

@@ -488,7 +488,7 @@ class SearchLevel:
             tilemax=torch.zeros((P, self.tmax, self.tmax), dtype=f64, device=device),
             tilelist=torch.zeros((P, 2, self.tmax * self.tmax), dtype=i32, device=device),
             tilecount=torch.zeros((P, 2), dtype=i32, device=device),
-            tileneed=torch.zeros((P, (self.tmax * self.tmax + 31) // 32), dtype=i32, device=device),
+            tileneed=torch.zeros((2, P, (self.tmax * self.tmax + 31) // 32), dtype=i32, device=device),   # by generation parity
             freerow=torch.zeros((P, 64), dtype=torch.int64, device=device),
             ring=torch.zeros(1 + self.nx * ((self.nx + 3) // 4), dtype=i32, device=device),
             prune_state=torch.zeros(P, dtype=i32, device=device),
@@ -522,9 +522,9 @@ class SearchLevel:
 
     def next_generation(self):
         """Advance the occupancy-image generation stamp (Slam2dLevel.occ_gen) for the next build: the
-        image is zeroed once per 255 builds instead of at every build."""
+        image is zeroed once per 254 builds instead of at every build."""
         g = self.c.occ_gen + 1
-        if g > 255:
+        if g > 254:                  # (254, not 255: the needed-tile bitmaps alternate with the generation's parity)
             self.t["occ"].zero_()
             g = 1
         self.c.occ_gen = g
