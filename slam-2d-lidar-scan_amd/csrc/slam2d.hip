@@ -907,7 +907,7 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
     // integer sums, so the order of the list cannot change a result.
     // mark != 0 (slam2d_match): the block also ORs the 16x16 field tiles its patches touch into
     // lv.tileneed, through an LDS bitmap, so that the field build can skip every other tile.
-    extern __shared__ __attribute__((aligned(16))) int ep_lds[];     // [hsize] keys, [hsize] owners, [8] wave counts, [nneed] tiles
+    extern __shared__ __attribute__((aligned(16))) int ep_lds[];     // [hsize] keys, [hsize] owners, [32] (step, wave) counts, [nneed] tiles
     const int it = blockIdx.x, p = blockIdx.y, tid = threadIdx.x;
     if (it == lv.ntheta) {                                 // the extra block of every particle: motion priors (+ ring)
         write_priors(lv, p, est_dist, psi_cs, prune);
@@ -938,22 +938,25 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
     int* hown = ep_lds + hsize;
     int* cnt_s = ep_lds + 2 * hsize;
     for (int i = tid; i < hsize; i += 256) { hkey[i] = INT_MAX; hown[i] = INT_MAX; }
-    uint32_t* need_s = reinterpret_cast<uint32_t*>(ep_lds + 2 * hsize + 8);
+    uint32_t* need_s = reinterpret_cast<uint32_t*>(ep_lds + 2 * hsize + 32);
     const int nneed = (lv.tmax * lv.tmax + 31) >> 5;
     if (mark) for (int i = tid; i < nneed; i += 256) need_s[i] = 0u;
     const double c = lv.theta_cos[it], s = lv.theta_sin[it];
     const int nc = lv.ncell;
-    const int per = n / 256;                               // beams per thread, contiguous: [tid*per, tid*per + per)
+    const int per = n / 256;                               // beams per thread, interleaved: beam = q * 256 + tid, so that a
+    //                                                        wave's loads and stores are contiguous (at 1081 beams the
+    //                                                        thread-contiguous mapping cost 32 cache lines per wave-load)
     // np.linspace(theta - fov/2, theta + fov/2, num=B)  (:82-83)
     const double eth = est[(size_t)p * estride + 2];
     const double a0 = eth - lid.fov / 2, a1 = eth + lid.fov / 2;
     const double astep = (a1 - a0) / (double)(B - 1);
-    int key[SLAM2D_MAX_BEAMS / 256], slot[SLAM2D_MAX_BEAMS / 256];
+    constexpr int QMAX = SLAM2D_MAX_BEAMS / 256;
+    int key[QMAX], slot[QMAX];
     bool bad = false;
 #pragma unroll
-    for (int q = 0; q < SLAM2D_MAX_BEAMS / 256; ++q) {
+    for (int q = 0; q < QMAX; ++q) {
         key[q] = INT_MAX; slot[q] = 0;
-        const int b = tid * per + q;
+        const int b = q * 256 + tid;
         if (q < per && b < B) {
             const double rg = ranges[b];
             if (rg < lid.max_range) {                                               // :84
@@ -978,7 +981,7 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
     __syncthreads();
     DBG_CLOCK(41, it == 0 && p == 0);
 #pragma unroll
-    for (int q = 0; q < SLAM2D_MAX_BEAMS / 256; ++q) {
+    for (int q = 0; q < QMAX; ++q) {
         if (key[q] == INT_MAX) continue;
         int h = (int)(((unsigned)key[q] * 2654435761u) >> 7) & hmask;
         for (;;) {
@@ -987,7 +990,7 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
             h = (h + 1) & hmask;
         }
         slot[q] = h;
-        atomicMin(&hown[h], tid * per + q);
+        atomicMin(&hown[h], q * 256 + tid);
         if (mark) {                                        // tiles of the (2 nc + 1)^2 patch at (x0, y0)
             const int y0 = key[q] / lv.fpitch, x0 = key[q] - y0 * lv.fpitch;
             // branch and bound: gmin2 summarises the aligned 8x8 blocks around the 4x4 windows of the pose tiles, which
@@ -1014,37 +1017,45 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
             uint32_t* g = need_bitmap(lv, lv.occ_gen, gridDim.y, p, nneed) + i;
             if (v && (__hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & v) != v) atomicOr(g, v);
         }
-    int keep = 0, mine = 0;
+    // ordered compaction, beam order = (q, wave, lane): per (q, wave) survivor counts through ballots, one barrier, then
+    // every survivor's position = survivors of the steps / waves before + survivors of lower lanes of its own ballot
+    const int wv = tid >> 6, lane = tid & 63;
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    unsigned long long kmask[QMAX];
+    int* qcnt = cnt_s;                                      // [per][4] counts (per <= 8: 32 ints; the LDS slice has room: see host)
 #pragma unroll
-    for (int q = 0; q < SLAM2D_MAX_BEAMS / 256; ++q)
-        if (key[q] != INT_MAX && hown[slot[q]] == tid * per + q) { keep |= 1 << q; ++mine; }
-    int incl = mine;                                       // inclusive scan inside the wave ...
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-        const int up = __shfl_up(incl, o);
-        if ((tid & 63) >= o) incl += up;
+    for (int q = 0; q < QMAX; ++q) {
+        kmask[q] = 0ull;
+        if (q < per) {
+            const bool k = key[q] != INT_MAX && hown[slot[q]] == q * 256 + tid;
+            kmask[q] = __ballot(k);
+            if (lane == 0) qcnt[q * 4 + wv] = __popcll(kmask[q]);
+        }
     }
-    if ((tid & 63) == 63) cnt_s[(tid >> 6) + 1] = incl;
-    if (tid == 0) cnt_s[0] = 0;
     __syncthreads();
-    const int wv = tid >> 6;
-    int pos = incl - mine;                                 // ... plus the waves before
-    for (int w2 = 1; w2 <= wv; ++w2) pos += cnt_s[w2];
     int* out = lv.cells + ((size_t)p * lv.ntheta + it) * lv.kmax;
     int* pout = lv.bnb ? lv.pcells + ((size_t)p * lv.ntheta + it) * lv.kmax : nullptr;
     const int gp = lv.tmax << 2;
+    int run = 0, pos_end = 0;
 #pragma unroll
-    for (int q = 0; q < SLAM2D_MAX_BEAMS / 256; ++q)
-        if ((keep >> q) & 1) {
-            if (pos < lv.kmax) {
-                out[pos] = key[q];
-                if (pout) {                                    // the block of the patch corner, as a byte offset into gmin2
-                    const int y0 = key[q] / lv.fpitch, x0 = key[q] - y0 * lv.fpitch;
-                    pout[pos] = ((y0 >> 2) * gp + (x0 >> 2)) * 4;
+    for (int q = 0; q < QMAX; ++q) {
+        if (q < per) {
+            int before = run;
+            for (int w2 = 0; w2 < 4; ++w2) { const int c2 = qcnt[q * 4 + w2]; if (w2 < wv) before += c2; run += c2; }
+            if ((kmask[q] >> lane) & 1ull) {
+                const int pos = before + __popcll(kmask[q] & below);
+                if (pos < lv.kmax) {
+                    out[pos] = key[q];
+                    if (pout) {                                // the block of the patch corner, as a byte offset into gmin2
+                        const int y0 = key[q] / lv.fpitch, x0 = key[q] - y0 * lv.fpitch;
+                        pout[pos] = ((y0 >> 2) * gp + (x0 >> 2)) * 4;
+                    }
                 }
             }
-            ++pos;
         }
+    }
+    pos_end = run;
+    const int pos = pos_end;
     DBG_CLOCK(43, it == 0 && p == 0);
     if (tid == 255) {
         int K = pos;                                       // the last thread ends at the total
@@ -2474,7 +2485,7 @@ static void launch_endpoints(const Slam2dLidar& lid, const Slam2dLevel& lv, int 
     while (n < lid.beams) n <<= 1;
     int hsize = 512;
     while (hsize < lid.beams + (lid.beams >> 1)) hsize <<= 1;
-    const size_t ep_lds = (size_t)(2 * hsize + 8 + (mark ? (lv.tmax * lv.tmax + 31) / 32 : 0)) * sizeof(int);
+    const size_t ep_lds = (size_t)(2 * hsize + 32 + (mark ? (lv.tmax * lv.tmax + 31) / 32 : 0)) * sizeof(int);
     k_endpoints<<<dim3(lv.ntheta + (own_frame_maps ? 2 : 1), P), 256, ep_lds, s>>>(lid, lv, d_est, est_stride, d_ranges, d_flags, est_moving_dist,
                                                         lv.fine ? nullptr : d_psi_cs, mark ? 1 : 0, prune ? 1 : 0,
                                                         beam_table && lv.beam_xy ? 1 : 0, own_frame_maps);
