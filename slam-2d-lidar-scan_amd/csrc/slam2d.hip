@@ -1021,15 +1021,15 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
     // every survivor's position = survivors of the steps / waves before + survivors of lower lanes of its own ballot
     const int wv = tid >> 6, lane = tid & 63;
     const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
-    unsigned long long kmask[QMAX];
-    int* qcnt = cnt_s;                                      // [per][4] counts (per <= 8: 32 ints; the LDS slice has room: see host)
+    int* qcnt = cnt_s;                                      // [per][4] counts (per <= 8: 32 ints)
+    unsigned owner = 0u;                                    // bit q: this thread's beam of step q owns its cell
 #pragma unroll
     for (int q = 0; q < QMAX; ++q) {
-        kmask[q] = 0ull;
         if (q < per) {
             const bool k = key[q] != INT_MAX && hown[slot[q]] == q * 256 + tid;
-            kmask[q] = __ballot(k);
-            if (lane == 0) qcnt[q * 4 + wv] = __popcll(kmask[q]);
+            owner |= (k ? 1u : 0u) << q;
+            const unsigned long long km = __ballot(k);
+            if (lane == 0) qcnt[q * 4 + wv] = __popcll(km);
         }
     }
     __syncthreads();
@@ -1042,8 +1042,9 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
         if (q < per) {
             int before = run;
             for (int w2 = 0; w2 < 4; ++w2) { const int c2 = qcnt[q * 4 + w2]; if (w2 < wv) before += c2; run += c2; }
-            if ((kmask[q] >> lane) & 1ull) {
-                const int pos = before + __popcll(kmask[q] & below);
+            const unsigned long long km = __ballot((owner >> q) & 1u);
+            if ((owner >> q) & 1u) {
+                const int pos = before + __popcll(km & below);
                 if (pos < lv.kmax) {
                     out[pos] = key[q];
                     if (pout) {                                // the block of the patch corner, as a byte offset into gmin2
