@@ -201,9 +201,14 @@ typedef struct {
     double*  bounds;         /* [P][ntheta][nb][4*ceil(nb/4)] upper bound of the score of every pose tile, nb = ceil(nx/4) */
     double*  tile_pmax;      /* [P][nb][4*ceil(nb/4)] largest rv + thetaWeight of a pose tile (+inf if one is NaN) */
     unsigned long long* bnb_best; /* [P] order-preserving bits of the best exact score of the seed tiles */
+    /* two-level bounds (bnb == 2: long cell lists): */
+    uint32_t* gmin3d;        /* [P][4][2*tmax][2*tmax] min(gmin[Y..Y+2][X..X+2]) >> 12, decimated by two in four phase planes
+                                (plane (Y & 1) * 2 + (X & 1), element [Y >> 1][X >> 1]): bounds a tile of 8 x 8 poses */
+    int32_t* p3cells;        /* [P][ntheta][kmax] the endpoint cells as byte offsets into a particle's gmin3d */
+    double*  bounds1;        /* [P][ntheta][8][8] upper bounds of the 8 x 8-pose tiles */
     double*  beam_xy;        /* [P][beams][2] scratch of slam2d_match (may be NULL): beam endpoints of the pose estimate
                                 (covertMeasureToXY, Utils/ScanMatcher_OGBased.py:81-89), evaluated once per particle */
-    int32_t bnb;             /* 1: slam2d_match scores this level by branch and bound */
+    int32_t bnb;             /* 1: slam2d_match scores this level by branch and bound; 2: with two-level bounds */
     int32_t _pad_bnb;
     int32_t occ_gen;         /* 0: occ + tilemask are cleared at every build.  1..255: generation stamp -- an
                                 occ / tilemask byte means "occupied" only when it equals occ_gen, so nothing is

@@ -701,6 +701,15 @@ __device__ __forceinline__ void gmin2_pass(const Slam2dLevel& lv, const int p, c
         const int Y1 = min(Y + 1, gp - 1), X1 = min(X + 1, gp - 1);
         const uint32_t v = min(min(G[(size_t)Y * gp + X], G[(size_t)Y * gp + X1]), min(G[(size_t)Y1 * gp + X], G[(size_t)Y1 * gp + X1]));
         G2[(size_t)Y * gp + X] = v >> 12;
+        if (lv.bnb == 2) {
+            // two-level bounds: the 8x8 cell window of an 8x8-pose tile lies inside blocks Y..Y+2 x X..X+2; stored decimated by
+            // two in four phase planes, so that the tiles of one row (block stride 2) are contiguous
+            const int Y2 = min(Y + 2, gp - 1), X2 = min(X + 2, gp - 1);
+            uint32_t v3 = min(v, min(G[(size_t)Y * gp + X2], G[(size_t)Y1 * gp + X2]));
+            v3 = min(v3, min(min(G[(size_t)Y2 * gp + X], G[(size_t)Y2 * gp + X1]), G[(size_t)Y2 * gp + X2]));
+            const int hp = gp >> 1;
+            lv.gmin3d[(size_t)p * gp * gp + ((size_t)(((Y & 1) << 1) | (X & 1)) * hp + (Y >> 1)) * hp + (X >> 1)] = v3 >> 12;
+        }
     }
 }
 
@@ -995,7 +1004,8 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
             const int y0 = key[q] / lv.fpitch, x0 = key[q] - y0 * lv.fpitch;
             // branch and bound: gmin2 summarises the aligned 8x8 blocks around the 4x4 windows of the pose tiles, which
             // reach from 3 cells before the patch to 4 * ceil(nx / 4) + 3 cells after its corner
-            const int lead = lv.bnb ? 3 : 0, span = lv.bnb ? 4 * ((2 * nc + 4) >> 2) + 3 : 2 * nc;
+            // (two-level bounds: 8x8-pose tiles, 3x3 blocks: up to 8 * ceil(nx / 8) + 3)
+            const int lead = lv.bnb ? 3 : 0, span = lv.bnb == 2 ? 8 * ((2 * nc + 8) >> 3) + 3 : lv.bnb ? 4 * ((2 * nc + 4) >> 2) + 3 : 2 * nc;
             const int tx0 = max(x0 - lead, 0) >> BLUR_SHIFT, tx1 = min((x0 + span) >> BLUR_SHIFT, lv.tmax - 1);
             for (int ty = max(y0 - lead, 0) >> BLUR_SHIFT; ty <= min((y0 + span) >> BLUR_SHIFT, lv.tmax - 1); ++ty)
                 for (int tx = tx0; tx <= tx1;) {           // runs of bits inside one 32-bit word
@@ -1049,7 +1059,12 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
                     out[pos] = key[q];
                     if (pout) {                                // the block of the patch corner, as a byte offset into gmin2
                         const int y0 = key[q] / lv.fpitch, x0 = key[q] - y0 * lv.fpitch;
-                        pout[pos] = ((y0 >> 2) * gp + (x0 >> 2)) * 4;
+                        const int Y0 = y0 >> 2, X0 = x0 >> 2;
+                        pout[pos] = (Y0 * gp + X0) * 4;
+                        if (lv.bnb == 2) {                     // ... and into the phase planes of gmin3d
+                            const int hp = gp >> 1;
+                            lv.p3cells[((size_t)p * lv.ntheta + it) * lv.kmax + pos] = ((((Y0 & 1) << 1 | (X0 & 1)) * hp + (Y0 >> 1)) * hp + (X0 >> 1)) * 4;
+                        }
                     }
                 }
             }
@@ -1749,6 +1764,191 @@ __global__ __launch_bounds__(64) void k_bound(Slam2dLevel lv, int P) {
     DBG_CLOCK(4, b == 0);
 }
 
+// Two-level bounds for long cell lists (Slam2dLevel.bnb == 2; K ~ 1000 at 1081 beams, where k_bound sits at its
+// texture-path bound of one load instruction per cell and theta).  Level 1: tiles of 8 x 8 poses, bounded through gmin3d
+// (the 8 x 8 cell window of such a tile lies inside 3 x 3 aligned 4 x 4 blocks); a tile row is 2 quads, a cell 12-16 lanes,
+// so ONE load instruction serves 4-5 cells.  Level 2 (k_bound2): the four 4 x 4-pose children of the few level-1 tiles that
+// survive (0.3 per theta at config 5) get their gmin2 bound; every other 4 x 4 tile's bound is -inf.  k_exact_select is
+// unchanged.  The seed: best level-1 tile -> its best child by level-2 bound -> exact.
+// u32 sum over the 16 lanes of a DPP row, in every lane
+__device__ __forceinline__ unsigned row16_sum_u32(unsigned v) {
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);
+    return v;
+}
+// level-2 bounds of the four children of level-1 tile (R, Cx): lane = (child c = lane / 16, cell slice lane % 16); returns
+// the child's bound in every lane of its row (-inf for a child outside the cube)
+__device__ __forceinline__ double children_bounds(const Slam2dLevel& lv, const __amdgpu_buffer_rsrc_t rg2, const int* __restrict__ pcl,
+                                                  const int K, const int R, const int Cx, const double* __restrict__ pm,
+                                                  const int nbt, const int nbq4, const int gp, const double inv) {
+    const int lane = threadIdx.x & 63, c = lane >> 4, sl = lane & 15;
+    const int cy = 2 * R + (c >> 1), cx = 2 * Cx + (c & 1);
+    const bool valid = cy < nbt && cx < nbt;
+    const int lanepart = (cy * gp + cx) * 4;
+    unsigned sum = 0u;
+    for (int k = sl; k < K; k += 16 * 8) {
+        int off[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) off[i] = (valid && k + 16 * i < K) ? lanepart + pcl[k + 16 * i] : 0x7ffffff0;
+        unsigned v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b32(rg2, off[i], 0, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sum += v[i];
+    }
+    sum = row16_sum_u32(sum);
+    return valid ? (-(((double)sum * 4096.0) * inv) + pm[cy * nbq4 + cx]) + 1e-9 : -INFINITY;
+}
+
+#define B1_DEPTH 16
+__global__ __launch_bounds__(64) void k_bound1(Slam2dLevel lv, int P) {
+    extern __shared__ __attribute__((aligned(16))) int b1_lds[];      // [64 * 4] partial sums, then [kmax] cell offsets
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int p = (slot / lv.ntheta) * 8 + xcd, it = slot % lv.ntheta;
+    if (p >= P) return;
+    const int lane = threadIdx.x;
+    const int nx = 2 * lv.ncell + 1, npose = nx * nx;
+    const int nbt = (nx + 3) >> 2, nbq4 = ((nbt + 3) >> 2) << 2;
+    const int nb1 = (nx + 7) >> 3, nq1 = (nb1 + 3) >> 2, L = nb1 * nq1, C = WAVE / L;
+    const int gp = lv.tmax << 2, hp = gp >> 1;
+    const int K = lv.kcount[p * lv.ntheta + it];
+    const int* __restrict__ p3 = lv.p3cells + ((size_t)p * lv.ntheta + it) * lv.kmax;
+    const int* __restrict__ pcl = lv.pcells + ((size_t)p * lv.ntheta + it) * lv.kmax;
+    const int* __restrict__ cl = lv.cells + ((size_t)p * lv.ntheta + it) * lv.kmax;
+    unsigned* red = reinterpret_cast<unsigned*>(b1_lds);
+    int* cs = b1_lds + WAVE * 4;
+    for (int k = lane; k < K; k += WAVE) cs[k] = p3[k];
+    const __amdgpu_buffer_rsrc_t rg3 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(lv.gmin3d + (size_t)p * gp * gp), (short)0, (int)((size_t)gp * gp * sizeof(uint32_t)), 0x00020000);
+    const int g = lane / L, l2 = lane - g * L, r = l2 / nq1, q = l2 - r * nq1;
+    const bool active = g < C;
+    const int lanepart = (r * hp + 4 * q) * 4;
+    unsigned sum[4] = {0u, 0u, 0u, 0u};
+    __syncthreads();
+    for (int k0 = 0; k0 < K; k0 += C * B1_DEPTH) {
+        int off[B1_DEPTH];
+#pragma unroll
+        for (int i = 0; i < B1_DEPTH; ++i) {
+            const int k = k0 + i * C + g;
+            off[i] = (active && k < K) ? lanepart + cs[k] : 0x7ffffff0;
+        }
+        u32x4 v[B1_DEPTH];
+#pragma unroll
+        for (int i = 0; i < B1_DEPTH; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rg3, off[i], 0, 0);
+#pragma unroll
+        for (int i = 0; i < B1_DEPTH; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum[e] += v[i][e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[e * WAVE + lane] = sum[e];
+    __syncthreads();
+    const double inv = 1.0 / lv.cost_scale;
+    const double* __restrict__ pm = lv.tile_pmax + (size_t)p * nbt * nbq4;
+    double* __restrict__ b1 = lv.bounds1 + ((size_t)p * lv.ntheta + it) * 64;
+    Best me{-INFINITY, INT_MAX, 0};
+    if (lane < L) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c1 = 4 * q + e;
+            if (c1 < 8) {
+                unsigned tot = 0u;
+                for (int g2 = 0; g2 < C; ++g2) tot += red[e * WAVE + g2 * L + lane];
+                // largest prior of the tile's children (+inf if a child holds a NaN prior, -inf for a tile outside the cube)
+                double pmx = -INFINITY;
+                for (int a = 0; a < 2; ++a)
+                    for (int bb = 0; bb < 2; ++bb)
+                        if (2 * r + a < nbt && 2 * c1 + bb < nbt) pmx = fmax(pmx, pm[(2 * r + a) * nbq4 + 2 * c1 + bb]);
+                const double U = (-(((double)tot * 4096.0) * inv) + pmx) + 1e-9;
+                b1[r * 8 + c1] = U;
+                Best cand{U, r * 8 + c1, 0};
+                if (c1 < nb1 && better(cand, me)) me = cand;
+            }
+        }
+    }
+    if (lane >= L && lane < 64) {                           // level-1 tiles beyond the cube: never survive
+        for (int t = lane - L; t < 64; t += 64 - L) {
+            const int r1 = t >> 3, c1 = t & 7;
+            if (r1 >= nb1 || c1 >= 4 * nq1) b1[t] = -INFINITY;
+        }
+    }
+    me = wave_best_ordered(me);
+    // seed: the best level-1 tile's best child (by its level-2 bound), exactly
+    const int R = me.i >> 3, Cx = me.i & 7;
+    const __amdgpu_buffer_rsrc_t rg2 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(lv.gmin2 + (size_t)p * gp * gp), (short)0, (int)((size_t)gp * gp * sizeof(uint32_t)), 0x00020000);
+    const double u2 = children_bounds(lv, rg2, pcl, K, R, Cx, pm, nbt, nbq4, gp, inv);
+    const double u0 = readlane_f64(u2, 0), u1 = readlane_f64(u2, 16), u2b = readlane_f64(u2, 32), u3 = readlane_f64(u2, 48);
+    int best = 0;
+    double ub = u0;
+    if (u1 > ub) { ub = u1; best = 1; }
+    if (u2b > ub) { ub = u2b; best = 2; }
+    if (u3 > ub) { ub = u3; best = 3; }
+    const int sby = 2 * R + (best >> 1), sbx = 2 * Cx + (best & 1);
+    const int dy = 4 * sby + (lane >> 4);
+    const bool leader = (lane & 15) == 0 && dy < nx;
+    const double* __restrict__ pr = lv.prior + (size_t)p * 2 * npose;
+    double prv[4], ptw[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int qq = min(dy, nx - 1) * nx + min(4 * sbx + e, nx - 1);
+        prv[e] = pr[qq]; ptw[e] = pr[npose + qq];
+    }
+    const size_t image = (size_t)lv.fmax * lv.fpitch;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(lv.field + (size_t)p * image), (short)0, (int)(image * sizeof(uint32_t)), 0x00020000);
+    int pre[8];
+    tile_prefetch<8>(cl, K, pre);
+    unsigned long long acc[4];
+    tile_exact<8>(lv, rsrc, cl, K, sby, sbx, pre, acc);
+    double val = -INFINITY;
+    if (leader) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * sbx + e < nx) {
+                const double sc = (-((double)acc[e] * inv) + prv[e]) + ptw[e];
+                if (!isnan(sc)) val = fmax(val, sc);
+            }
+    }
+    val = fmax(val, __shfl_xor(val, 16));
+    val = fmax(val, __shfl_xor(val, 32));
+    if (lane == 0 && val > -INFINITY) atomicMax(&lv.bnb_best[p], order_bits(val));
+}
+
+__global__ __launch_bounds__(64) void k_bound2(Slam2dLevel lv, int P) {
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int p = (slot / lv.ntheta) * 8 + xcd, it = slot % lv.ntheta;
+    if (p >= P) return;
+    const int lane = threadIdx.x;
+    const int nx = 2 * lv.ncell + 1;
+    const int nbt = (nx + 3) >> 2, nbq4 = ((nbt + 3) >> 2) << 2, nt = nbt * nbq4;
+    const int gp = lv.tmax << 2;
+    const double thr = unorder_bits(lv.bnb_best[p]) - SLAM2D_BNB_MARGIN;
+    double* __restrict__ bnd = lv.bounds + ((size_t)p * lv.ntheta + it) * nt;
+    for (int t = lane; t < nt; t += WAVE) bnd[t] = -INFINITY;
+    const double u1 = lv.bounds1[((size_t)p * lv.ntheta + it) * 64 + lane];
+    unsigned long long todo = __ballot(u1 >= thr);
+    if (!todo) return;
+    const int K = lv.kcount[p * lv.ntheta + it];
+    const int* __restrict__ pcl = lv.pcells + ((size_t)p * lv.ntheta + it) * lv.kmax;
+    const double* __restrict__ pm = lv.tile_pmax + (size_t)p * nbt * nbq4;
+    const __amdgpu_buffer_rsrc_t rg2 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(lv.gmin2 + (size_t)p * gp * gp), (short)0, (int)((size_t)gp * gp * sizeof(uint32_t)), 0x00020000);
+    const double inv = 1.0 / lv.cost_scale;
+    while (todo) {
+        const int t1 = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int R = t1 >> 3, Cx = t1 & 7;
+        const double u2 = children_bounds(lv, rg2, pcl, K, R, Cx, pm, nbt, nbq4, gp, inv);
+        const int c = lane >> 4, cy = 2 * R + (c >> 1), cx = 2 * Cx + (c & 1);
+        if ((lane & 15) == 0 && cy < nbt && cx < nbt) bnd[cy * nbq4 + cx] = u2;
+    }
+}
+
 // One block per particle: the tiles whose bound reaches bnb_best - SLAM2D_BNB_MARGIN, exactly, then the selection
 // (np.argmax / np.random.choice / confidence, :133-143).  Everything serial in a single wave is slow here (an fp64
 // exp is ~0.25 us when no other wave hides its latency, a vector-memory instruction costs the CU 16 clocks), so
@@ -2431,6 +2631,7 @@ static int check_field_args(const Slam2dLevel& lv, int P, bool lazy) {
         const int nx = 2 * lv.ncell + 1;
         if (!lazy || !lv.gmin || !lv.gmin2 || !lv.pcells || !lv.bounds || !lv.tile_pmax || !lv.bnb_best || !lv.prune_state)
             return SLAM2D_E_BADARG;
+        if (lv.bnb == 2 && (!lv.gmin3d || !lv.p3cells || !lv.bounds1 || (lv.tmax & 0) != 0)) return SLAM2D_E_BADARG;
         if (nx < 9 || nx > 64 || lv.tmax * 16 != lv.fpitch) return SLAM2D_E_BADARG;
         if (lv.ntheta > SLAM2D_BNB_MAX_THETA) return SLAM2D_E_TOOLARGE;
         if ((long long)lv.ntheta * ((nx + 3) / 4) * (((nx + 3) / 4 + 3) / 4 * 4) > (long long)XS_THREADS * XS_MAX_PER) return SLAM2D_E_TOOLARGE;
@@ -2623,7 +2824,11 @@ int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2
         launch_endpoints(*lidar, lv, P, d_est, est_stride, d_ranges, est_moving_dist, d_psi_cs, d_flags, true, false, s, framed, own);
         launch_field(lv, d_maps, P, d_flags, true, s);
         const unsigned grid = (unsigned)cdiv(P, 8) * 8 * lv.ntheta;
-        {
+        if (lv.bnb == 2) {
+            StageScope prof(SLAM2D_STAGE_BOUND, s);
+            k_bound1<<<grid, WAVE, (size_t)(WAVE * 4 + lv.kmax) * sizeof(int), s>>>(lv, P);
+            k_bound2<<<grid, WAVE, 0, s>>>(lv, P);
+        } else {
             StageScope prof(SLAM2D_STAGE_BOUND, s);
             k_bound<<<grid, WAVE, 0, s>>>(lv, P);
         }

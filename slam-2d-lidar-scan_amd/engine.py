@@ -463,6 +463,13 @@ class SearchLevel:
         # limits of k_exact_select: one thread scans <= 32 tile bounds, per-theta sums live in LDS (256 thetas)
         applicable = 9 <= self.nx <= 64 and self.ntheta <= 256 and self.ntheta * nbt_ * 4 * ((nbt_ + 3) // 4) <= 32768
         self.bnb = (bnb_default(self.nx, self.ntheta, lidar.beams, self.tmax) if bnb is None else bool(bnb)) and applicable
+        # two-level bounds pay where one load instruction per cell and theta is the bottleneck (k_bound at its texture-path
+        # bound: ~1000-cell lists); SLAM2D_BNB_LEVELS=1 / 2 forces the choice
+        import os
+        lv_env = os.environ.get("SLAM2D_BNB_LEVELS", "auto")
+        self.bnb_levels = 0 if not self.bnb else (int(lv_env) if lv_env in ("1", "2") else (2 if lidar.beams >= 512 else 1))
+        if self.bnb_levels == 2 and self.nx < 17:
+            self.bnb_levels = 1
         nbt = (self.nx + 3) // 4
         nbq4 = 4 * ((nbt + 3) // 4)
         i32, f64 = torch.int32, torch.float64
@@ -503,6 +510,12 @@ class SearchLevel:
                 tile_pmax=torch.zeros((P, nbt, nbq4), dtype=f64, device=device),
                 bnb_best=torch.zeros(P, dtype=torch.int64, device=device),
             )
+            if self.bnb_levels == 2:    # long cell lists: 8x8-pose tiles first
+                t.update(
+                    gmin3d=torch.zeros((P, 4, 2 * self.tmax, 2 * self.tmax), dtype=i32, device=device),
+                    p3cells=torch.zeros((P, self.ntheta, self.kmax), dtype=i32, device=device),
+                    bounds1=torch.zeros((P, self.ntheta, 64), dtype=f64, device=device),
+                )
         self.c = Slam2dLevel(
             step=step, reach=self.reach, log_miss=self.log_miss, floor_value=self.floor_value,
             cost_scale=self.cost_scale, blur_radius=self.blur_radius, fmax=self.fmax, fpitch=self.fpitch, wmax=self.wmax,
@@ -517,7 +530,8 @@ class SearchLevel:
             tilemin=t["tilemin"].data_ptr(), tilemax=t["tilemax"].data_ptr(), tilelist=t["tilelist"].data_ptr(),
             tilecount=t["tilecount"].data_ptr(),
             tileneed=t["tileneed"].data_ptr(), freerow=t["freerow"].data_ptr(), ring=t["ring"].data_ptr(), prune_state=t["prune_state"].data_ptr(),
-            ring_cap=self.nx * ((self.nx + 3) // 4), bnb=int(self.bnb), beam_xy=t["beam_xy"].data_ptr(),
+            ring_cap=self.nx * ((self.nx + 3) // 4), bnb=self.bnb_levels, beam_xy=t["beam_xy"].data_ptr(),
+            **({k: t[k].data_ptr() for k in ("gmin3d", "p3cells", "bounds1")} if self.bnb_levels == 2 else {}),
             **({k: t[k].data_ptr() for k in ("gmin", "gmin2", "pcells", "bounds", "tile_pmax", "bnb_best")} if self.bnb else {}))
 
     def next_generation(self):
