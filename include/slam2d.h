@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define SLAM2D_ABI_VERSION 8
+#define SLAM2D_ABI_VERSION 9
 #define SLAM2D_SPOKE_BAND 16         /* radial band width of the beam-major spoke table, in cells */
 
 /* library error codes (negative; positive values are hipError_t) */
@@ -206,6 +206,7 @@ typedef struct {
                                 (plane (Y & 1) * 2 + (X & 1), element [Y >> 1][X >> 1]): bounds a tile of 8 x 8 poses */
     int32_t* p3cells;        /* [P][ntheta][kmax] the endpoint cells as byte offsets into a particle's gmin3d */
     double*  bounds1;        /* [P][ntheta][8][8] upper bounds of the 8 x 8-pose tiles */
+    unsigned long long* seed_key; /* [P] best finite 8 x 8-tile bound of the particle, packed with its (theta, tile): the seed */
     double*  beam_xy;        /* [P][beams][2] scratch of slam2d_match (may be NULL): beam endpoints of the pose estimate
                                 (covertMeasureToXY, Utils/ScanMatcher_OGBased.py:81-89), evaluated once per particle */
     int32_t bnb;             /* 1: slam2d_match scores this level by branch and bound; 2: with two-level bounds */

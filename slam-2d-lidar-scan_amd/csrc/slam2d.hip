@@ -213,6 +213,7 @@ __global__ void k_frame_axis(Slam2dLidar lid, Slam2dLevel lv, const Slam2dMap* _
         lv.frames[p] = fr;
         lv.tilecount[2 * p] = 0; lv.tilecount[2 * p + 1] = 0;
         if (lv.bnb) lv.bnb_best[p] = order_bits(-INFINITY);
+        if (lv.bnb == 2) lv.seed_key[p] = 0ull;
         if (f) atomicOr(&flags[p], f);
     }
     const int n = axis == 0 ? fr.mx1 - fr.mx0 : fr.my1 - fr.my0;
@@ -879,6 +880,7 @@ __device__ __forceinline__ void frame_duties(const Slam2dLidar& lid, const Slam2
         lv.frames[p] = fr;
         lv.tilecount[2 * p] = 0; lv.tilecount[2 * p + 1] = 0;
         if (lv.bnb) lv.bnb_best[p] = order_bits(-INFINITY);
+        if (lv.bnb == 2) lv.seed_key[p] = 0ull;
         if (f) atomicOr(&flags[p], f);
     }
     bool bad = false;
@@ -1810,14 +1812,12 @@ __global__ __launch_bounds__(64) void k_bound1(Slam2dLevel lv, int P) {
     const int p = (slot / lv.ntheta) * 8 + xcd, it = slot % lv.ntheta;
     if (p >= P) return;
     const int lane = threadIdx.x;
-    const int nx = 2 * lv.ncell + 1, npose = nx * nx;
+    const int nx = 2 * lv.ncell + 1;
     const int nbt = (nx + 3) >> 2, nbq4 = ((nbt + 3) >> 2) << 2;
     const int nb1 = (nx + 7) >> 3, nq1 = (nb1 + 3) >> 2, L = nb1 * nq1, C = WAVE / L;
     const int gp = lv.tmax << 2, hp = gp >> 1;
     const int K = lv.kcount[p * lv.ntheta + it];
     const int* __restrict__ p3 = lv.p3cells + ((size_t)p * lv.ntheta + it) * lv.kmax;
-    const int* __restrict__ pcl = lv.pcells + ((size_t)p * lv.ntheta + it) * lv.kmax;
-    const int* __restrict__ cl = lv.cells + ((size_t)p * lv.ntheta + it) * lv.kmax;
     unsigned* red = reinterpret_cast<unsigned*>(b1_lds);
     int* cs = b1_lds + WAVE * 4;
     for (int k = lane; k < K; k += WAVE) cs[k] = p3[k];
@@ -1876,18 +1876,152 @@ __global__ __launch_bounds__(64) void k_bound1(Slam2dLevel lv, int P) {
         }
     }
     me = wave_best_ordered(me);
-    // seed: the best level-1 tile's best child (by its level-2 bound), exactly
-    const int R = me.i >> 3, Cx = me.i & 7;
+    // candidate seed of the particle: its best finite level-1 bound over all theta (k_seed scores it exactly); the low
+    // 14 bits of the bound make room for (theta, tile) -- this only picks WHERE the threshold is measured
+    if (lane == 0 && me.v > -INFINITY && me.v < INFINITY)
+        atomicMax(&lv.seed_key[p], (order_bits(me.v) & ~0x3FFFull) | (unsigned long long)((it << 6) | me.i));
+}
+
+// The threshold of a particle (bnb == 2): the level-1 tile with the best bound over all theta -> its best child by level-2
+// bound -> that 4 x 4 tile exactly; the best of its 16 scores is a lower bound of the cube's maximum.  One block per
+// particle, thread = cell (one seed per PARTICLE: the per-theta seeds of k_bound cost a third of its cache-line touches).
+#define SEED_THREADS 1024
+__global__ __launch_bounds__(SEED_THREADS) void k_seed(Slam2dLevel lv, int P) {
+    __shared__ unsigned csum[4];
+    __shared__ unsigned long long acc_s[16];
+    __shared__ int best_s;
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const unsigned long long key = lv.seed_key[p];
+    if (!key) return;                                       // no finite bound anywhere: no threshold, every tile is scored
+    const int it = (int)(key >> 6) & 0xFF, t1 = (int)key & 63, R = t1 >> 3, Cx = t1 & 7;
+    const int nx = 2 * lv.ncell + 1, npose = nx * nx;
+    const int nbt = (nx + 3) >> 2, nbq4 = ((nbt + 3) >> 2) << 2;
+    const int gp = lv.tmax << 2;
+    const int K = lv.kcount[p * lv.ntheta + it];
+    const int* __restrict__ pcl = lv.pcells + ((size_t)p * lv.ntheta + it) * lv.kmax;
+    const int* __restrict__ cl = lv.cells + ((size_t)p * lv.ntheta + it) * lv.kmax;
+    if (tid < 4) csum[tid] = 0u;
+    if (tid < 16) acc_s[tid] = 0ull;
+    __syncthreads();
+    {
+        const __amdgpu_buffer_rsrc_t rg2 = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(lv.gmin2 + (size_t)p * gp * gp), (short)0, (int)((size_t)gp * gp * sizeof(uint32_t)), 0x00020000);
+        unsigned s4[4] = {0u, 0u, 0u, 0u};
+        for (int k = tid; k < K; k += SEED_THREADS) {
+            const int off = pcl[k];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int cy = 2 * R + (c >> 1), cx = 2 * Cx + (c & 1);
+                if (cy < nbt && cx < nbt) s4[c] += __builtin_amdgcn_raw_buffer_load_b32(rg2, (cy * gp + cx) * 4 + off, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const unsigned t = row16_sum_u32(s4[c]);
+            if ((tid & 15) == 0 && t) atomicAdd(&csum[c], t);
+        }
+    }
+    __syncthreads();
+    const double inv = 1.0 / lv.cost_scale;
+    if (tid == 0) {
+        const double* __restrict__ pm = lv.tile_pmax + (size_t)p * nbt * nbq4;
+        int best = -1;
+        double ub = -INFINITY;
+        for (int c = 0; c < 4; ++c) {
+            const int cy = 2 * R + (c >> 1), cx = 2 * Cx + (c & 1);
+            if (cy >= nbt || cx >= nbt) continue;
+            const double u = (-(((double)csum[c] * 4096.0) * inv) + pm[cy * nbq4 + cx]) + 1e-9;
+            if (best < 0 || u > ub) { ub = u; best = c; }
+        }
+        best_s = best < 0 ? 0 : best;
+    }
+    __syncthreads();
+    const int sby = 2 * R + (best_s >> 1), sbx = 2 * Cx + (best_s & 1);
+    {
+        const size_t image = (size_t)lv.fmax * lv.fpitch;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(lv.field + (size_t)p * image), (short)0, (int)(image * sizeof(uint32_t)), 0x00020000);
+        unsigned long long a[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[i] = 0ull;
+        for (int k = tid; k < K; k += SEED_THREADS) {
+            const int off = cl[k] * 4;
+            u32x4 v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((4 * sby + r) * lv.fpitch + 4 * sbx) * 4 + off, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[r * 4 + e] += v[r][e];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const unsigned long long t = row16_sum_u64(a[i]);
+            if ((tid & 15) == 0 && t) atomicAdd(&acc_s[i], t);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const double* __restrict__ pr = lv.prior + (size_t)p * 2 * npose;
+        double val = -INFINITY;
+        for (int r = 0; r < 4; ++r)
+            for (int e = 0; e < 4; ++e) {
+                const int dy = 4 * sby + r, dx = 4 * sbx + e;
+                if (dy >= nx || dx >= nx) continue;
+                const double sc = (-((double)acc_s[r * 4 + e] * inv) + pr[dy * nx + dx]) + pr[npose + dy * nx + dx];
+                if (!isnan(sc)) val = fmax(val, sc);
+            }
+        if (val > -INFINITY) lv.bnb_best[p] = order_bits(val);
+    }
+}
+
+// Level 2: the children of the level-1 tiles that reach the threshold get their gmin2 bounds (every other 4 x 4 tile: -inf);
+// then the theta's best child is scored exactly when its bound still reaches the particle's best score, which tightens the
+// threshold k_exact_select works with.  bnb_best rises while the kernel runs; the reads are racy on purpose: a tile or a
+// seed that is skipped because of a fresher value has a bound below the FINAL best, so neither the final bnb_best (the
+// maximum over all candidate seeds) nor the set of tiles k_exact_select keeps depends on the timing.
+__global__ __launch_bounds__(64) void k_bound2(Slam2dLevel lv, int P) {
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int p = (slot / lv.ntheta) * 8 + xcd, it = slot % lv.ntheta;
+    if (p >= P) return;
+    const int lane = threadIdx.x;
+    const int nx = 2 * lv.ncell + 1, npose = nx * nx;
+    const int nbt = (nx + 3) >> 2, nbq4 = ((nbt + 3) >> 2) << 2, nt = nbt * nbq4;
+    const int gp = lv.tmax << 2;
+    const double thr = unorder_bits(__hip_atomic_load(&lv.bnb_best[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - SLAM2D_BNB_MARGIN;
+    double* __restrict__ bnd = lv.bounds + ((size_t)p * lv.ntheta + it) * nt;
+    for (int t = lane; t < nt; t += WAVE) bnd[t] = -INFINITY;
+    const double u1 = lv.bounds1[((size_t)p * lv.ntheta + it) * 64 + lane];
+    unsigned long long todo = __ballot(u1 >= thr);
+    if (!todo) return;
+    const int K = lv.kcount[p * lv.ntheta + it];
+    const int* __restrict__ pcl = lv.pcells + ((size_t)p * lv.ntheta + it) * lv.kmax;
+    const int* __restrict__ cl = lv.cells + ((size_t)p * lv.ntheta + it) * lv.kmax;
+    const double* __restrict__ pm = lv.tile_pmax + (size_t)p * nbt * nbq4;
     const __amdgpu_buffer_rsrc_t rg2 = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(lv.gmin2 + (size_t)p * gp * gp), (short)0, (int)((size_t)gp * gp * sizeof(uint32_t)), 0x00020000);
-    const double u2 = children_bounds(lv, rg2, pcl, K, R, Cx, pm, nbt, nbq4, gp, inv);
-    const double u0 = readlane_f64(u2, 0), u1 = readlane_f64(u2, 16), u2b = readlane_f64(u2, 32), u3 = readlane_f64(u2, 48);
-    int best = 0;
-    double ub = u0;
-    if (u1 > ub) { ub = u1; best = 1; }
-    if (u2b > ub) { ub = u2b; best = 2; }
-    if (u3 > ub) { ub = u3; best = 3; }
-    const int sby = 2 * R + (best >> 1), sbx = 2 * Cx + (best & 1);
+    const double inv = 1.0 / lv.cost_scale;
+    int pre[8];
+    tile_prefetch<8>(cl, K, pre);                           // for the seed below
+    double ub = -INFINITY;
+    int seed = -1;
+    while (todo) {
+        const int t1 = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int R = t1 >> 3, Cx = t1 & 7;
+        const double u2 = children_bounds(lv, rg2, pcl, K, R, Cx, pm, nbt, nbq4, gp, inv);
+        const int c = lane >> 4, cy = 2 * R + (c >> 1), cx = 2 * Cx + (c & 1);
+        if ((lane & 15) == 0 && cy < nbt && cx < nbt) bnd[cy * nbq4 + cx] = u2;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {                    // (-inf for a child outside the cube)
+            const double u = readlane_f64(u2, 16 * cc);
+            if (u > ub) { ub = u; seed = (2 * R + (cc >> 1)) * nbq4 + 2 * Cx + (cc & 1); }
+        }
+    }
+    if (seed < 0) return;
+    if (ub < unorder_bits(__hip_atomic_load(&lv.bnb_best[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return;
+    const int sby = seed / nbq4, sbx = seed - sby * nbq4;
     const int dy = 4 * sby + (lane >> 4);
     const bool leader = (lane & 15) == 0 && dy < nx;
     const double* __restrict__ pr = lv.prior + (size_t)p * 2 * npose;
@@ -1900,8 +2034,6 @@ __global__ __launch_bounds__(64) void k_bound1(Slam2dLevel lv, int P) {
     const size_t image = (size_t)lv.fmax * lv.fpitch;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(lv.field + (size_t)p * image), (short)0, (int)(image * sizeof(uint32_t)), 0x00020000);
-    int pre[8];
-    tile_prefetch<8>(cl, K, pre);
     unsigned long long acc[4];
     tile_exact<8>(lv, rsrc, cl, K, sby, sbx, pre, acc);
     double val = -INFINITY;
@@ -1916,37 +2048,6 @@ __global__ __launch_bounds__(64) void k_bound1(Slam2dLevel lv, int P) {
     val = fmax(val, __shfl_xor(val, 16));
     val = fmax(val, __shfl_xor(val, 32));
     if (lane == 0 && val > -INFINITY) atomicMax(&lv.bnb_best[p], order_bits(val));
-}
-
-__global__ __launch_bounds__(64) void k_bound2(Slam2dLevel lv, int P) {
-    const int b = blockIdx.x;
-    const int xcd = b & 7, slot = b >> 3;
-    const int p = (slot / lv.ntheta) * 8 + xcd, it = slot % lv.ntheta;
-    if (p >= P) return;
-    const int lane = threadIdx.x;
-    const int nx = 2 * lv.ncell + 1;
-    const int nbt = (nx + 3) >> 2, nbq4 = ((nbt + 3) >> 2) << 2, nt = nbt * nbq4;
-    const int gp = lv.tmax << 2;
-    const double thr = unorder_bits(lv.bnb_best[p]) - SLAM2D_BNB_MARGIN;
-    double* __restrict__ bnd = lv.bounds + ((size_t)p * lv.ntheta + it) * nt;
-    for (int t = lane; t < nt; t += WAVE) bnd[t] = -INFINITY;
-    const double u1 = lv.bounds1[((size_t)p * lv.ntheta + it) * 64 + lane];
-    unsigned long long todo = __ballot(u1 >= thr);
-    if (!todo) return;
-    const int K = lv.kcount[p * lv.ntheta + it];
-    const int* __restrict__ pcl = lv.pcells + ((size_t)p * lv.ntheta + it) * lv.kmax;
-    const double* __restrict__ pm = lv.tile_pmax + (size_t)p * nbt * nbq4;
-    const __amdgpu_buffer_rsrc_t rg2 = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(lv.gmin2 + (size_t)p * gp * gp), (short)0, (int)((size_t)gp * gp * sizeof(uint32_t)), 0x00020000);
-    const double inv = 1.0 / lv.cost_scale;
-    while (todo) {
-        const int t1 = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        const int R = t1 >> 3, Cx = t1 & 7;
-        const double u2 = children_bounds(lv, rg2, pcl, K, R, Cx, pm, nbt, nbq4, gp, inv);
-        const int c = lane >> 4, cy = 2 * R + (c >> 1), cx = 2 * Cx + (c & 1);
-        if ((lane & 15) == 0 && cy < nbt && cx < nbt) bnd[cy * nbq4 + cx] = u2;
-    }
 }
 
 // One block per particle: the tiles whose bound reaches bnb_best - SLAM2D_BNB_MARGIN, exactly, then the selection
@@ -2631,7 +2732,7 @@ static int check_field_args(const Slam2dLevel& lv, int P, bool lazy) {
         const int nx = 2 * lv.ncell + 1;
         if (!lazy || !lv.gmin || !lv.gmin2 || !lv.pcells || !lv.bounds || !lv.tile_pmax || !lv.bnb_best || !lv.prune_state)
             return SLAM2D_E_BADARG;
-        if (lv.bnb == 2 && (!lv.gmin3d || !lv.p3cells || !lv.bounds1 || (lv.tmax & 0) != 0)) return SLAM2D_E_BADARG;
+        if (lv.bnb == 2 && (!lv.gmin3d || !lv.p3cells || !lv.bounds1 || !lv.seed_key || (lv.tmax & 0) != 0)) return SLAM2D_E_BADARG;
         if (nx < 9 || nx > 64 || lv.tmax * 16 != lv.fpitch) return SLAM2D_E_BADARG;
         if (lv.ntheta > SLAM2D_BNB_MAX_THETA) return SLAM2D_E_TOOLARGE;
         if ((long long)lv.ntheta * ((nx + 3) / 4) * (((nx + 3) / 4 + 3) / 4 * 4) > (long long)XS_THREADS * XS_MAX_PER) return SLAM2D_E_TOOLARGE;
@@ -2827,6 +2928,7 @@ int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2
         if (lv.bnb == 2) {
             StageScope prof(SLAM2D_STAGE_BOUND, s);
             k_bound1<<<grid, WAVE, (size_t)(WAVE * 4 + lv.kmax) * sizeof(int), s>>>(lv, P);
+            k_seed<<<P, SEED_THREADS, 0, s>>>(lv, P);
             k_bound2<<<grid, WAVE, 0, s>>>(lv, P);
         } else {
             StageScope prof(SLAM2D_STAGE_BOUND, s);

@@ -515,6 +515,7 @@ class SearchLevel:
                     gmin3d=torch.zeros((P, 4, 2 * self.tmax, 2 * self.tmax), dtype=i32, device=device),
                     p3cells=torch.zeros((P, self.ntheta, self.kmax), dtype=i32, device=device),
                     bounds1=torch.zeros((P, self.ntheta, 64), dtype=f64, device=device),
+                    seed_key=torch.zeros(P, dtype=torch.int64, device=device),
                 )
         self.c = Slam2dLevel(
             step=step, reach=self.reach, log_miss=self.log_miss, floor_value=self.floor_value,
@@ -531,7 +532,7 @@ class SearchLevel:
             tilecount=t["tilecount"].data_ptr(),
             tileneed=t["tileneed"].data_ptr(), freerow=t["freerow"].data_ptr(), ring=t["ring"].data_ptr(), prune_state=t["prune_state"].data_ptr(),
             ring_cap=self.nx * ((self.nx + 3) // 4), bnb=self.bnb_levels, beam_xy=t["beam_xy"].data_ptr(),
-            **({k: t[k].data_ptr() for k in ("gmin3d", "p3cells", "bounds1")} if self.bnb_levels == 2 else {}),
+            **({k: t[k].data_ptr() for k in ("gmin3d", "p3cells", "bounds1", "seed_key")} if self.bnb_levels == 2 else {}),
             **({k: t[k].data_ptr() for k in ("gmin", "gmin2", "pcells", "bounds", "tile_pmax", "bnb_best")} if self.bnb else {}))
 
     def next_generation(self):
