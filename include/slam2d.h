@@ -179,11 +179,9 @@ typedef struct {
     double*  tilemax;        /* [P][tmax][tmax] scratch: per-tile maximum of the field as stored */
     int32_t* tilelist;       /* [P][2][tmax*tmax] scratch: work lists (tiles to blur, tiles to fill) */
     int32_t* tilecount;      /* [P][2] scratch: their lengths */
-    uint32_t* tileneed;      /* [2][P][ceil(tmax*tmax/32)] scratch of slam2d_match: bit t set = the pose scoring reads
-                                field tile t.  Double-buffered by the parity of occ_gen: a call uses bitmap (occ_gen & 1)
-                                and clears the other one for the next call, so consecutive calls must alternate parity
-                                (count 1 .. 254) and the buffers start zeroed (may be NULL when only
-                                slam2d_field_build is used) */
+    uint32_t* tileneed;      /* [P][ntheta][ceil(tmax*tmax/32)] scratch of slam2d_match: bit t of slice (p, theta) set = the
+                                poses of that angle read field tile t; every call rewrites every word, the field build
+                                ORs the slices of a particle (may be NULL when only slam2d_field_build is used) */
     unsigned long long* freerow; /* [P][64] scratch (used when tmax <= 64): bit tx of word ty = field tile (ty, tx)
                                 holds the free-space constant; lets the sweep skip loads.  NULL disables */
     int32_t* ring;           /* [1 + ring_cap] scratch of SLAM2D_MATCH_PRUNE_BY_PRIOR: length, then the ascending

@@ -11,7 +11,7 @@ import subprocess
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
-LIB_PATH = os.path.join(PKG_DIR, "libslam2d_hip.so")
+LIB_PATH = os.environ.get("SLAM2D_LIB") or os.path.join(PKG_DIR, "libslam2d_hip.so")   # SLAM2D_LIB: another build of the same ABI
 SRC_PATH = os.path.join(PKG_DIR, "csrc", "slam2d.hip")
 INCLUDE_DIR = os.path.join(REPO_DIR, "include")
 

@@ -80,10 +80,11 @@ __device__ __forceinline__ double unorder_bits(unsigned long long k) {
 // The occupied-field image and the tile flags are not cleared between builds: a cell / tile is
 // occupied when its byte equals the build's generation stamp (Slam2dLevel.occ_gen, 1..255).
 __device__ __forceinline__ uint8_t occ_stamp(const Slam2dLevel& lv) { return (uint8_t)(lv.occ_gen ? lv.occ_gen : 1); }
-// The needed-tile bitmap is double-buffered by the generation's parity: a call marks and reads bitmap (occ_gen & 1) and
-// its triage clears the OTHER one for the next call -- no clearing launch, and the bitmap of the last call stays readable.
-__device__ __forceinline__ uint32_t* need_bitmap(const Slam2dLevel& lv, const int which, const int P, const int p, const int nneed) {
-    return lv.tileneed + ((size_t)(which & 1) * P + p) * nneed;
+// The needed-tile bitmap of slam2d_match: one slice per (particle, theta), written whole by that theta's k_endpoints block
+// with plain stores (every call overwrites every word: nothing to clear) and OR-ed over theta by the triage.  One shared
+// bitmap per particle cost k_endpoints half of its time at 139 angles: every block's atomics met on the same few lines.
+__device__ __forceinline__ uint32_t* need_slice(const Slam2dLevel& lv, const int p, const int it, const int nneed) {
+    return lv.tileneed + ((size_t)p * lv.ntheta + it) * nneed;
 }
 // 0x01 in every byte of v that equals the stamp byte (exact per byte), 0x00 elsewhere
 __device__ __forceinline__ uint32_t bytes_equal(const uint32_t v, const uint8_t stamp) {
@@ -184,14 +185,10 @@ __device__ __forceinline__ Slam2dFrame make_frame(const Slam2dLidar& lid, const 
 // K2a+b  frame geometry (:21-28) and the field index of every window column / row (:32-36,173-176)
 // ------------------------------------------------------------------------------------
 __global__ void k_frame_axis(Slam2dLidar lid, Slam2dLevel lv, const Slam2dMap* __restrict__ maps,
-                             const double* __restrict__ centre, int cstride, uint32_t* flags, int clear_need,
+                             const double* __restrict__ centre, int cstride, uint32_t* flags,
                              const double* __restrict__ ranges) {
     const int p = blockIdx.y, axis = blockIdx.z;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (clear_need && axis == 1) {                     // the needed-tile bitmap of slam2d_match
-        const int nneed = (lv.tmax * lv.tmax + 31) >> 5;
-        for (int w = j; w < nneed; w += gridDim.x * blockDim.x) need_bitmap(lv, lv.occ_gen, gridDim.y, p, nneed)[w] = 0u;
-    }
     if (ranges && axis == 0) {
         // covertMeasureToXY (Utils/ScanMatcher_OGBased.py:81-89) once per particle: k_endpoints' ntheta blocks of the
         // particle would otherwise each evaluate the same cos / sin (a third of its time at 1081 beams x 139 angles)
@@ -598,14 +595,18 @@ __global__ __launch_bounds__(TRIAGE_THREADS) void k_tile_triage(Slam2dLevel lv, 
     {
         const uint8_t* tiles = lv.tilemask + (size_t)p * ntile;
         for (int t = tid; t < ntile; t += TRIAGE_THREADS) { tiles_s[t] = tiles[t] == stamp; state_s[t] = state[t]; }
-        if (lazy)
-            for (int w = tid; w < nneed; w += TRIAGE_THREADS) {
-                need_s[w] = need_bitmap(lv, lv.occ_gen, gridDim.x, p, nneed)[w];
-                need_bitmap(lv, lv.occ_gen + 1, gridDim.x, p, nneed)[w] = 0u;       // clean for the next call's k_endpoints
-            }
+        if (lazy) for (int w = tid; w < nneed; w += TRIAGE_THREADS) need_s[w] = 0u;
     }
     if (tid < 2) base[tid] = 0;
     __syncthreads();
+    if (lazy) {                                            // the particle's needed tiles: OR over the theta slices
+        const uint32_t* __restrict__ sl = need_slice(lv, p, 0, nneed);
+        for (int i = tid; i < nneed * lv.ntheta; i += TRIAGE_THREADS) {
+            const uint32_t v = sl[i];
+            if (v) { const int w = i % nneed; if ((need_s[w] & v) != v) atomicOr(&need_s[w], v); }
+        }
+        __syncthreads();
+    }
     uint32_t liveb = 0u, anyb = 0u;
     int has_free = 0;
     for (int it = 0; it < iters; ++it) {
@@ -906,6 +907,20 @@ __device__ __forceinline__ void frame_duties(const Slam2dLidar& lid, const Slam2
 //      A cell is stored as the offset of the corner of its (2*ncell+1)^2 patch:
 //      (cy - ncell) * fpitch + (cx - ncell).
 // ------------------------------------------------------------------------------------
+#define EP_MARK_TMAX 192             // fields up to 3072 cells an edge dilate their tile marks in LDS (6 * tmax * ceil(tmax / 32) + tmax^2 / 32 words)
+// the tiles of the patch at (x0, y0), straight into the particle's bitmap (slow path of k_endpoints' marking)
+__device__ __forceinline__ void mark_tiles_direct(uint32_t* need_g, const int x0, const int y0, const int lead, const int span, const int tmax) {
+    const int tx0 = max(x0 - lead, 0) >> BLUR_SHIFT, tx1 = min((x0 + span) >> BLUR_SHIFT, tmax - 1);
+    for (int ty = max(y0 - lead, 0) >> BLUR_SHIFT; ty <= min((y0 + span) >> BLUR_SHIFT, tmax - 1); ++ty)
+        for (int tx = tx0; tx <= tx1;) {                   // runs of bits inside one 32-bit word
+            const int bit = ty * tmax + tx;
+            const int len = min(tx1 - tx + 1, 32 - (bit & 31));
+            const uint32_t m = (len == 32 ? ~0u : ((1u << len) - 1u)) << (bit & 31);
+            uint32_t* g = need_g + (bit >> 5);
+            if ((__hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & m) != m) atomicOr(g, m);
+            tx += len;
+        }
+}
 __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel lv, const double* __restrict__ est,
                                                    int estride, const double* __restrict__ ranges, uint32_t* flags,
                                                    double est_dist, const double* __restrict__ psi_cs, int mark, int prune,
@@ -917,8 +932,8 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
     // coherent (neighbouring beams hit neighbouring cells) and deterministic.  Scores are exact
     // integer sums, so the order of the list cannot change a result.
     // mark != 0 (slam2d_match): the block also ORs the 16x16 field tiles its patches touch into
-    // lv.tileneed, through an LDS bitmap, so that the field build can skip every other tile.
-    extern __shared__ __attribute__((aligned(16))) int ep_lds[];     // [hsize] keys, [hsize] owners, [32] (step, wave) counts, [nneed] tiles
+    // lv.tileneed (corner bits in LDS, dilated once per block), so that the field build can skip every other tile.
+    extern __shared__ __attribute__((aligned(16))) int ep_lds[];     // [hsize] keys, [hsize] owners, [32] (step, wave) counts, tile-marking scratch
     const int it = blockIdx.x, p = blockIdx.y, tid = threadIdx.x;
     if (it == lv.ntheta) {                                 // the extra block of every particle: motion priors (+ ring)
         write_priors(lv, p, est_dist, psi_cs, prune);
@@ -949,9 +964,25 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
     int* hown = ep_lds + hsize;
     int* cnt_s = ep_lds + 2 * hsize;
     for (int i = tid; i < hsize; i += 256) { hkey[i] = INT_MAX; hown[i] = INT_MAX; }
-    uint32_t* need_s = reinterpret_cast<uint32_t*>(ep_lds + 2 * hsize + 32);
+    // tile marking scratch: the patch of a beam covers tiles [tx0, tx0 + n + cx] x [ty0, ty0 + n + cy] with cx, cy in {0, 1}
+    // (n = (lead + span) / 16), so a beam sets ONE bit -- its corner tile, in the bitmap of its class (cy, cx) -- and the
+    // block dilates the four bitmaps afterwards (rows padded to whole words).  Walking the tile rows per beam was half of
+    // this kernel's time at 1081 beams.
     const int nneed = (lv.tmax * lv.tmax + 31) >> 5;
-    if (mark) for (int i = tid; i < nneed; i += 256) need_s[i] = 0u;
+    const int wp = (lv.tmax + 31) >> 5;                    // words per tile row
+    const bool lds_mark = mark && lv.tmax <= EP_MARK_TMAX;
+    uint32_t* corner_s = reinterpret_cast<uint32_t*>(ep_lds + 2 * hsize + 32);       // [2 cy][2 cx][tmax][wp]
+    uint32_t* hd_s = corner_s + 4 * lv.tmax * wp;                                   // [2 cy][tmax][wp] after the horizontal pass
+    uint32_t* lin_s = hd_s + 2 * lv.tmax * wp;                                      // [nneed] the block's bitmap (bit = ty * tmax + tx)
+    uint32_t* const need_g = mark ? need_slice(lv, p, it, nneed) : nullptr;
+    if (lds_mark) for (int i = tid; i < 6 * lv.tmax * wp + nneed; i += 256) corner_s[i] = 0u;
+    else if (mark) for (int i = tid; i < nneed; i += 256) need_g[i] = 0u;            // huge field: marked in place, below
+    // branch and bound: gmin2 summarises the aligned 8x8 blocks around the 4x4 windows of the pose tiles, which
+    // reach from 3 cells before the patch to 4 * ceil(nx / 4) + 3 cells after its corner
+    // (two-level bounds: 8x8-pose tiles, 3x3 blocks: up to 8 * ceil(nx / 8) + 3)
+    const int lead = lv.bnb ? 3 : 0;
+    const int span = lv.bnb == 2 ? 8 * ((2 * lv.ncell + 8) >> 3) + 3 : lv.bnb ? 4 * ((2 * lv.ncell + 4) >> 2) + 3 : 2 * lv.ncell;
+    const int ntl = (lead + span) >> BLUR_SHIFT;
     const double c = lv.theta_cos[it], s = lv.theta_sin[it];
     const int nc = lv.ncell;
     const int per = n / 256;                               // beams per thread, interleaved: beam = q * 256 + tid, so that a
@@ -1004,31 +1035,57 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
         atomicMin(&hown[h], q * 256 + tid);
         if (mark) {                                        // tiles of the (2 nc + 1)^2 patch at (x0, y0)
             const int y0 = key[q] / lv.fpitch, x0 = key[q] - y0 * lv.fpitch;
-            // branch and bound: gmin2 summarises the aligned 8x8 blocks around the 4x4 windows of the pose tiles, which
-            // reach from 3 cells before the patch to 4 * ceil(nx / 4) + 3 cells after its corner
-            // (two-level bounds: 8x8-pose tiles, 3x3 blocks: up to 8 * ceil(nx / 8) + 3)
-            const int lead = lv.bnb ? 3 : 0, span = lv.bnb == 2 ? 8 * ((2 * nc + 8) >> 3) + 3 : lv.bnb ? 4 * ((2 * nc + 4) >> 2) + 3 : 2 * nc;
-            const int tx0 = max(x0 - lead, 0) >> BLUR_SHIFT, tx1 = min((x0 + span) >> BLUR_SHIFT, lv.tmax - 1);
-            for (int ty = max(y0 - lead, 0) >> BLUR_SHIFT; ty <= min((y0 + span) >> BLUR_SHIFT, lv.tmax - 1); ++ty)
-                for (int tx = tx0; tx <= tx1;) {           // runs of bits inside one 32-bit word
-                    const int bit = ty * lv.tmax + tx;
-                    const int len = min(tx1 - tx + 1, 32 - (bit & 31));
-                    const uint32_t m = (len == 32 ? ~0u : ((1u << len) - 1u)) << (bit & 31);
-                    // neighbouring beams mark the same tiles: a plain read first, the atomic only for new bits (the word
-                    // is a 64-way conflict otherwise -- measured at 1081 beams)
-                    if ((need_s[bit >> 5] & m) != m) atomicOr(&need_s[bit >> 5], m);
-                    tx += len;
-                }
+            // (a patch clipped by the field's low edge keeps its full extent: at most one tile row / column too many)
+            const int xa = max(x0 - lead, 0), ya = max(y0 - lead, 0);
+            if (lds_mark) {
+                const int tx0 = xa >> BLUR_SHIFT, ty0 = ya >> BLUR_SHIFT;
+                const int cx = (((xa & (BLUR_TILE - 1)) + lead + span) >> BLUR_SHIFT) - ntl;
+                const int cy = (((ya & (BLUR_TILE - 1)) + lead + span) >> BLUR_SHIFT) - ntl;
+                uint32_t* w = corner_s + ((cy * 2 + cx) * lv.tmax + ty0) * wp + (tx0 >> 5);
+                const uint32_t m = 1u << (tx0 & 31);
+                // neighbouring beams share the corner tile: a plain read first, the atomic only for a new bit
+                if (!(*w & m)) atomicOr(w, m);
+            } else {                                       // a huge field: this block's slice, in place
+                mark_tiles_direct(need_g, x0, y0, lead, span, lv.tmax);
+            }
         }
     }
     __syncthreads();
     DBG_CLOCK(42, it == 0 && p == 0);
-    if (mark)
-        for (int i = tid; i < nneed; i += 256) {
-            const uint32_t v = need_s[i];
-            uint32_t* g = need_bitmap(lv, lv.occ_gen, gridDim.y, p, nneed) + i;
-            if (v && (__hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & v) != v) atomicOr(g, v);
+    if (lds_mark) {
+        const int nitem = lv.tmax * wp;
+        for (int i = tid; i < 2 * nitem; i += 256) {      // horizontal: class cx covers tx0 .. tx0 + ntl + cx
+            const int cy = i / nitem, rj = i - cy * nitem, j = rj % wp;
+            unsigned long long d = 0ull;
+#pragma unroll
+            for (int cx = 0; cx < 2; ++cx) {
+                const uint32_t* c = corner_s + (cy * 2 + cx) * nitem + rj;
+                unsigned long long v = ((unsigned long long)c[0] << 32) | (j ? c[-1] : 0u);
+                for (int k = 0; k < ntl + cx; ++k) v |= v << 1;
+                d |= v;
+            }
+            hd_s[i] = (uint32_t)(d >> 32);
         }
+        __syncthreads();
+        for (int i = tid; i < nitem; i += 256) {          // vertical: class cy covers ty0 .. ty0 + ntl + cy; then to the particle's bitmap
+            const int row = i / wp, j = i - row * wp;
+            uint32_t v = 0u;
+            for (int dy = 0; dy <= ntl + 1 && dy <= row; ++dy) {
+                if (dy <= ntl) v |= hd_s[i - dy * wp];
+                v |= hd_s[nitem + i - dy * wp];
+            }
+            const int left = lv.tmax - 32 * j;             // tiles of this word inside the row
+            if (left < 32) v &= (1u << left) - 1u;
+            if (v) {
+                const int start = row * lv.tmax + 32 * j, sh = start & 31;
+                const uint32_t lo = v << sh, hi = sh ? v >> (32 - sh) : 0u;
+                if (lo) atomicOr(&lin_s[start >> 5], lo);
+                if (hi) atomicOr(&lin_s[(start >> 5) + 1], hi);
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < nneed; i += 256) need_g[i] = lin_s[i];
+    }
     // ordered compaction, beam order = (q, wave, lane): per (q, wave) survivor counts through ballots, one barrier, then
     // every survivor's position = survivors of the steps / waves before + survivors of lower lanes of its own ballot
     const int wv = tid >> 6, lane = tid & 63;
@@ -2745,7 +2802,7 @@ static int launch_frames(const Slam2dLidar& lid, const Slam2dLevel& lv, const Sl
                          const double* d_centre, int centre_stride, uint32_t* d_flags, bool lazy, hipStream_t s,
                          const double* d_ranges = nullptr) {
     if (d_ranges && (!lv.beam_xy || centre_stride < 3)) d_ranges = nullptr;
-    k_frame_axis<<<dim3(cdiv(lv.wmax, 256), P, 2), 256, 0, s>>>(lid, lv, d_maps, d_centre, centre_stride, d_flags, lazy ? 1 : 0, d_ranges);
+    k_frame_axis<<<dim3(cdiv(lv.wmax, 256), P, 2), 256, 0, s>>>(lid, lv, d_maps, d_centre, centre_stride, d_flags, d_ranges);
     if (lv.occ_gen < 0 || lv.occ_gen > 255) return SLAM2D_E_BADARG;
     if (lv.occ_gen != 0) return 0;                     // generation stamps: nothing to clear
     return (int)hipMemsetAsync(lv.occ, 0, (size_t)P * lv.fmax * lv.fpitch + (size_t)P * lv.tmax * lv.tmax, s);
@@ -2788,7 +2845,7 @@ static void launch_endpoints(const Slam2dLidar& lid, const Slam2dLevel& lv, int 
     while (n < lid.beams) n <<= 1;
     int hsize = 512;
     while (hsize < lid.beams + (lid.beams >> 1)) hsize <<= 1;
-    const size_t ep_lds = (size_t)(2 * hsize + 32 + (mark ? (lv.tmax * lv.tmax + 31) / 32 : 0)) * sizeof(int);
+    const size_t ep_lds = (size_t)(2 * hsize + 32 + (mark && lv.tmax <= EP_MARK_TMAX ? 6 * lv.tmax * ((lv.tmax + 31) / 32) + (lv.tmax * lv.tmax + 31) / 32 : 0)) * sizeof(int);
     k_endpoints<<<dim3(lv.ntheta + (own_frame_maps ? 2 : 1), P), 256, ep_lds, s>>>(lid, lv, d_est, est_stride, d_ranges, d_flags, est_moving_dist,
                                                         lv.fine ? nullptr : d_psi_cs, mark ? 1 : 0, prune ? 1 : 0,
                                                         beam_table && lv.beam_xy ? 1 : 0, own_frame_maps);

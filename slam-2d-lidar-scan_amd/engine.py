@@ -495,7 +495,7 @@ class SearchLevel:
             tilemax=torch.zeros((P, self.tmax, self.tmax), dtype=f64, device=device),
             tilelist=torch.zeros((P, 2, self.tmax * self.tmax), dtype=i32, device=device),
             tilecount=torch.zeros((P, 2), dtype=i32, device=device),
-            tileneed=torch.zeros((2, P, (self.tmax * self.tmax + 31) // 32), dtype=i32, device=device),   # by generation parity
+            tileneed=torch.zeros((P, self.ntheta, (self.tmax * self.tmax + 31) // 32), dtype=i32, device=device),   # one slice per angle
             freerow=torch.zeros((P, 64), dtype=torch.int64, device=device),
             ring=torch.zeros(1 + self.nx * ((self.nx + 3) // 4), dtype=i32, device=device),
             prune_state=torch.zeros(P, dtype=i32, device=device),

@@ -660,7 +660,7 @@ def test_large_synthetic_properties(pkg):
 
 def _tile_bits(level, p):
     """Needed-tile bitmap of slam2d_match for particle p as a bool [tmax, tmax] array."""
-    words = level.t["tileneed"][level.c.occ_gen & 1, p].cpu().numpy().view(np.uint32)      # the last call's bitmap
+    words = np.bitwise_or.reduce(level.t["tileneed"][p].cpu().numpy().view(np.uint32), axis=0)    # over the angles' slices
     bits = np.unpackbits(words.view(np.uint8), bitorder="little")[:level.tmax * level.tmax]
     return bits.reshape(level.tmax, level.tmax).astype(bool)
 
