@@ -406,6 +406,9 @@ int slam2d_device_sincos(const double* d_angles, int32_t n, double* d_cos, doubl
 #define SLAM2D_STAGE_COUNT     8
 int  slam2d_prof_enable(uint32_t stage_mask, int32_t capacity);
 int  slam2d_prof_collect(int32_t stage, double* total_ms, int32_t* launches);
+/* Sample: only every `every`-th launch of an enabled stage gets its event pair (default 1).  An event pair costs the
+ * stream ~6 us on each side of the kernel; a timed region that must not carry that on every step samples instead. */
+int  slam2d_prof_every(int32_t every);
 void slam2d_prof_disable(void);
 
 /* Timing helper for bench.py: HIP events on the caller's stream.

@@ -132,6 +132,7 @@ SIGNATURES = {
     "slam2d_device_sincos": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp]),
     "slam2d_prof_enable": (C.c_int, [C.c_uint32, C.c_int32]),
     "slam2d_prof_collect": (C.c_int, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "slam2d_prof_every": (C.c_int, [C.c_int32]),
     "slam2d_prof_disable": (None, []),
     "slam2d_timer_create": (_vp, []),
     "slam2d_timer_destroy": (None, [_vp]),

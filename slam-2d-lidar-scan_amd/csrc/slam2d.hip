@@ -32,16 +32,18 @@ struct StageProf {
     hipEvent_t* stop = nullptr;
     int capacity = 0;
     int used = 0;
+    int seen = 0;                    // launches of the stage since slam2d_prof_enable
 };
 StageProf g_prof[SLAM2D_STAGE_COUNT];
 unsigned g_prof_mask = 0;
+int g_prof_every = 1;                // an event pair around every g_prof_every-th launch of an enabled stage
 
 struct StageScope {
     int stage; hipStream_t s; int slot = -1;
     StageScope(int st, hipStream_t stream) : stage(st), s(stream) {
         if (st >= 0 && ((g_prof_mask >> st) & 1u)) {
             StageProf& p = g_prof[st];
-            if (p.used < p.capacity) { slot = p.used++; (void)hipEventRecord(p.start[slot], s); }
+            if (p.seen++ % g_prof_every == 0 && p.used < p.capacity) { slot = p.used++; (void)hipEventRecord(p.start[slot], s); }
         }
     }
     ~StageScope() { if (slot >= 0) (void)hipEventRecord(g_prof[stage].stop[slot], s); }
@@ -1728,12 +1730,15 @@ __device__ __forceinline__ void tile_exact(const Slam2dLevel& lv, const __amdgpu
 // is the instruction count, 1/8 of the brute-force sweep's.  The cell list is read 64 cells at a time, one per
 // lane, and handed to the loads with v_readlane: no scalar-memory round trip per batch.
 #define BOUND_BATCH 32
-__global__ __launch_bounds__(64) void k_bound(Slam2dLevel lv, int P) {
+#define BOUND_GROUP 2                // waves per block = adjacent angles of one particle (measured: 1 -> 31.4 us, 2 -> 30.2, 4 -> 33.5,
+//                                      8 -> 38.3 at config 2: sharing L1 lines buys little, spreading over the CUs matters)
+__global__ __launch_bounds__(64 * BOUND_GROUP) void k_bound(Slam2dLevel lv, int P) {
     const int b = blockIdx.x;
+    const int ngroup = (lv.ntheta + BOUND_GROUP - 1) / BOUND_GROUP;
     const int xcd = b & 7, slot = b >> 3;
-    const int p = (slot / lv.ntheta) * 8 + xcd, it = slot % lv.ntheta;
-    if (p >= P) return;
-    const int lane = threadIdx.x;
+    const int p = (slot / ngroup) * 8 + xcd, it = (slot % ngroup) * BOUND_GROUP + (threadIdx.x >> 6);
+    if (p >= P || it >= lv.ntheta) return;
+    const int lane = threadIdx.x & 63;
     const int nx = 2 * lv.ncell + 1, npose = nx * nx;
     const int nbt = (nx + 3) >> 2, nq = (nbt + 3) >> 2, nbq4 = nq << 2;
     const int gp = lv.tmax << 2;
@@ -1757,6 +1762,9 @@ __global__ __launch_bounds__(64) void k_bound(Slam2dLevel lv, int P) {
     for (int base = 0; base < K; base += WAVE) {
         const int cur = cv;
         if (base + WAVE < K) cv = base + WAVE + lane < K ? pcl[base + WAVE + lane] : 0x7ffffff0;     // next 64 cells
+        // (straight-line double-buffered chunks that keep 16-32 loads in flight across the whole list measured SLOWER,
+        // 31.9 vs 28.4 us: the loop is bound by the L1's tag lookups -- ~19 64-byte sectors per load, 89 % hits -- not by
+        // latency, and the padding loads of the last chunk are not free)
 #pragma unroll
         for (int j0 = 0; j0 < WAVE; j0 += BOUND_BATCH) {
             if (base + j0 < K) {                            // (wave-uniform)
@@ -2989,7 +2997,7 @@ int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2
             k_bound2<<<grid, WAVE, 0, s>>>(lv, P);
         } else {
             StageScope prof(SLAM2D_STAGE_BOUND, s);
-            k_bound<<<grid, WAVE, 0, s>>>(lv, P);
+            k_bound<<<(unsigned)cdiv(P, 8) * 8 * cdiv(lv.ntheta, BOUND_GROUP), WAVE * BOUND_GROUP, 0, s>>>(lv, P);
         }
         {
             StageScope prof(SLAM2D_STAGE_EXACT, s);
@@ -3125,8 +3133,15 @@ int slam2d_prof_enable(uint32_t stage_mask, int32_t capacity) {
             p.capacity = capacity;
         }
         p.used = 0;
+        p.seen = 0;
     }
     g_prof_mask = stage_mask;
+    return 0;
+}
+
+int slam2d_prof_every(int32_t every) {
+    if (every < 1) return SLAM2D_E_BADARG;
+    g_prof_every = every;
     return 0;
 }
 

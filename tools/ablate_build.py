@@ -20,6 +20,9 @@ VARIANTS = {
         slot[q] = h;
         hown[h] = q * 256 + tid;""")],
     "ep_nomin": [("        atomicMin(&hown[h], q * 256 + tid);", "        hown[h] = q * 256 + tid;")],
+    "bg1": [("#define BOUND_GROUP 4 ", "#define BOUND_GROUP 1 ")],
+    "bg2": [("#define BOUND_GROUP 4 ", "#define BOUND_GROUP 2 ")],
+    "bg8": [("#define BOUND_GROUP 4 ", "#define BOUND_GROUP 8 ")],
     "ep_nostore": [("                    out[pos] = key[q];\n                    if (pout) {", "                    if (pout && pos < 0) {")],
 }
 def main():
