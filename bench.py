@@ -166,7 +166,10 @@ class HotPath:
         E = self.E
         if self.sharded:
             if self.normalizer is None:
-                self.normalizer = self.par.ShardedNormalizer(self.L, E._lib.check, self.d_logw.device, self.total_particles)
+                self.normalizer = self.par.ShardedNormalizer(self.L, E._lib.check, self.d_logw.device, self.total_particles,
+                                                             overlap=os.environ.get("SLAM2D_BENCH_OVERLAP", "0") == "1")
+                # (overlap: collective + merge on a side stream.  Bit-identical, but at one rank its events and stream
+                # switches cost the host more than the collective's latency: 0.207 vs 0.187 ms/step -- off by default)
             self.normalizer(self.d_logw, self.m_coarse.data_ptr() + 32, E.MATCH_DOUBLES, self.d_w, self.d_stats)   # +32: log_confidence
         else:
             E._lib.check(self.L.slam2d_weights_normalize(E._ptr(self.d_logw), C.c_void_p(self.m_coarse.data_ptr() + 32),

@@ -81,20 +81,47 @@ class ShardedNormalizer:
     normalise this rank's particles, variance over all N).  The torch-op version above costs a dozen
     small launches per scan (measured 77 us on one MI355X -- a quarter of a config-2 step)."""
 
-    def __init__(self, lib, check, device, total, group=None):
+    def __init__(self, lib, check, device, total, group=None, overlap=False):
         self.lib, self.check, self.total, self.group = lib, check, int(total), group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.part = torch.zeros(3, dtype=torch.float64, device=device)
         self.parts = torch.zeros(3 * self.world, dtype=torch.float64, device=device)
         self.via_host = dist.is_initialized() and dist.get_backend(group) == "gloo"
+        # overlap: the collective and the merge run on a side stream, so the launch stream goes straight on to the next
+        # scan's match (which needs no weight); the results are ordered by events -- the next call waits for this merge
+        # before it touches logw, readers of w / stats call wait() first
+        self.overlap = bool(overlap) and dist.is_initialized() and not self.via_host
+        if self.overlap:
+            self.side = torch.cuda.Stream(device)
+            self.ev_local, self.ev_merged = torch.cuda.Event(), torch.cuda.Event()
+            self.pending = False
+
+    def wait(self):
+        """Order the current stream behind the last overlapped merge (no-op otherwise)."""
+        if self.overlap and self.pending:
+            torch.cuda.current_stream(self.part.device).wait_event(self.ev_merged)
 
     def __call__(self, logw, logconf_ptr, logconf_stride, w, stats):
         """In place on ``logw`` (this rank's log-weights); writes ``w`` and ``stats`` =
         [sum over all particles of (w - 1/N)^2, log of the pre-normalisation sum]."""
-        stream = torch.cuda.current_stream(logw.device).cuda_stream
+        main = torch.cuda.current_stream(logw.device)
+        stream = main.cuda_stream
         n = logw.numel()
+        if self.overlap:
+            self.wait()                                       # logw, part: the previous scan's merge is done with them
         self.check(self.lib.slam2d_weights_local(logw.data_ptr(), logconf_ptr, logconf_stride, n,
                                                  self.part.data_ptr(), stream), "slam2d_weights_local")
+        if self.overlap:
+            self.ev_local.record(main)
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self.ev_local)
+                dist.all_gather_into_tensor(self.parts, self.part, group=self.group)
+                self.check(self.lib.slam2d_weights_merge(logw.data_ptr(), n, self.parts.data_ptr(), self.world, self.total,
+                                                         w.data_ptr(), stats.data_ptr(), self.side.cuda_stream),
+                           "slam2d_weights_merge")
+                self.ev_merged.record(self.side)
+            self.pending = True
+            return
         if not dist.is_initialized():
             self.parts.copy_(self.part)
         elif self.via_host:                                   # gloo: the 24 bytes hop through host memory

@@ -80,3 +80,67 @@ def test_two_rank_filter_reproduces_the_golden_run(tmp_path, golden, n_scans):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(2, _free_port(), golden, n_scans, str(tmp_path)), nprocs=2, join=True)
     assert [open(os.path.join(str(tmp_path), f"ok{r}")).read() for r in range(2)] == ["True", "True"]
+
+
+def _rccl_worker(port, out_path):
+    """One rank over the nccl (= RCCL) backend: the overlapped normaliser against the in-order one and against
+    slam2d_weights_normalize, over a sequence of scans (the carried log-weights make every scan depend on the last)."""
+    import ctypes as C
+    import torch.distributed as dist
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        E = importlib.import_module("slam-2d-lidar-scan_amd.engine")
+        par = importlib.import_module("slam-2d-lidar-scan_amd.parallel")
+        L = E._lib.lib()
+        n, scans = 64, 25
+        rng = np.random.default_rng(5)
+        conf = torch.from_numpy(rng.normal(-40.0, 6.0, size=(scans, n))).to(dev)
+        res = {}
+        for mode in ("plain", "inorder", "overlap"):
+            logw = torch.full((n,), -np.log(n), dtype=torch.float64, device=dev)
+            w = torch.zeros(n, dtype=torch.float64, device=dev)
+            stats = torch.zeros(2, dtype=torch.float64, device=dev)
+            norm = None if mode == "plain" else par.ShardedNormalizer(L, E._lib.check, dev, n, overlap=mode == "overlap")
+            assert norm is None or norm.overlap == (mode == "overlap")
+            hist = []
+            for s in range(scans):
+                if norm is None:
+                    E._lib.check(L.slam2d_weights_normalize(E._ptr(logw), C.c_void_p(conf[s].data_ptr()), 1, n, E._ptr(w),
+                                                            E._ptr(stats), E._stream()), "weights")
+                else:
+                    norm(logw, conf[s].data_ptr(), 1, w, stats)
+                    if s % 7 == 3:                                   # a reader in the middle of the sequence
+                        norm.wait()
+                        hist.append(w.clone())
+            if norm is not None:
+                norm.wait()
+            torch.cuda.synchronize()
+            res[mode] = (logw.cpu().numpy(), w.cpu().numpy(), stats.cpu().numpy(), [h.cpu().numpy() for h in hist])
+        ok = all(np.array_equal(res["inorder"][i], res["overlap"][i]) for i in range(3))
+        ok &= all(np.array_equal(a, b) for a, b in zip(res["inorder"][3], res["overlap"][3])) and len(res["overlap"][3]) == 4
+        close = np.allclose(res["plain"][1], res["overlap"][1], rtol=1e-12, atol=0) and abs(res["overlap"][1].sum() - 1) < 1e-12
+        open(out_path, "w").write(f"{int(ok)} {int(close)}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_normaliser_over_rccl(tmp_path):
+    """parallel.ShardedNormalizer(overlap=True) -- the collective and the merge on a side stream, ordered by events -- is
+    bit-identical to the in-order version and agrees with the single-GPU normaliser; through the nccl backend (one rank:
+    this box has one GPU; the stream / event ordering is what is under test)."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "rccl.txt")
+    ctx = mp.get_context("spawn")
+    pr = ctx.Process(target=_rccl_worker, args=(_free_port(), out))
+    pr.start()
+    pr.join(300)
+    if pr.is_alive():
+        pr.terminate()
+        pytest.fail("the RCCL worker hung")
+    assert pr.exitcode == 0
+    assert open(out).read() == "1 1"
