@@ -852,7 +852,7 @@ __device__ __forceinline__ void write_priors(const Slam2dLevel& lv, const int p,
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) ring_base = 0;
     __syncthreads();
-    for (int s0 = 0; s0 < nslot; s0 += 256) {
+    for (int s0 = 0; s0 < nslot; s0 += (int)blockDim.x) {
         const int u = s0 + threadIdx.x;
         bool in = false;
         if (u < nslot) {
@@ -866,7 +866,7 @@ __device__ __forceinline__ void write_priors(const Slam2dLevel& lv, const int p,
         for (int w2 = 0; w2 < wave; ++w2) pos += ring_cnt[w2];
         if (in && pos < lv.ring_cap) lv.ring[1 + pos] = u;
         __syncthreads();
-        if (threadIdx.x == 0) ring_base += ring_cnt[0] + ring_cnt[1] + ring_cnt[2] + ring_cnt[3];
+        if (threadIdx.x == 0) for (int w2 = 0; w2 < (int)(blockDim.x >> 6); ++w2) ring_base += ring_cnt[w2];
         __syncthreads();
     }
     if (threadIdx.x == 0) lv.ring[0] = ring_base <= lv.ring_cap ? ring_base : -1;     // -1: does not fit, sweep in full
@@ -923,7 +923,10 @@ __device__ __forceinline__ void mark_tiles_direct(uint32_t* need_g, const int x0
             tx += len;
         }
 }
-__global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel lv, const double* __restrict__ est,
+// NT threads: 256, or 192 for scans of up to 192 beams (one beam per thread; 10 blocks per CU instead of 8 hold all the
+// 36 x 64 + 128 blocks of config 2 at once -- no second, nearly empty round)
+template <int NT>
+__global__ __launch_bounds__(NT) void k_endpoints(Slam2dLidar lid, Slam2dLevel lv, const double* __restrict__ est,
                                                    int estride, const double* __restrict__ ranges, uint32_t* flags,
                                                    double est_dist, const double* __restrict__ psi_cs, int mark, int prune,
                                                    int beam_table, const Slam2dMap* __restrict__ maps) {
@@ -959,13 +962,14 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
     DBG_CLOCK(40, it == 0 && p == 0);
     int n = 256;
     while (n < B) n <<= 1;
+    constexpr int NW = NT / 64;
     int hsize = 512;                                       // power of two >= 1.5 * beams (load factor <= 2/3)
     while (hsize < B + (B >> 1)) hsize <<= 1;
     const int hmask = hsize - 1;
     int* hkey = ep_lds;
     int* hown = ep_lds + hsize;
     int* cnt_s = ep_lds + 2 * hsize;
-    for (int i = tid; i < hsize; i += 256) { hkey[i] = INT_MAX; hown[i] = INT_MAX; }
+    for (int i = tid; i < hsize; i += NT) { hkey[i] = INT_MAX; hown[i] = INT_MAX; }
     // tile marking scratch: the patch of a beam covers tiles [tx0, tx0 + n + cx] x [ty0, ty0 + n + cy] with cx, cy in {0, 1}
     // (n = (lead + span) / 16), so a beam sets ONE bit -- its corner tile, in the bitmap of its class (cy, cx) -- and the
     // block dilates the four bitmaps afterwards (rows padded to whole words).  Walking the tile rows per beam was half of
@@ -977,8 +981,8 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
     uint32_t* hd_s = corner_s + 4 * lv.tmax * wp;                                   // [2 cy][tmax][wp] after the horizontal pass
     uint32_t* lin_s = hd_s + 2 * lv.tmax * wp;                                      // [nneed] the block's bitmap (bit = ty * tmax + tx)
     uint32_t* const need_g = mark ? need_slice(lv, p, it, nneed) : nullptr;
-    if (lds_mark) for (int i = tid; i < 6 * lv.tmax * wp + nneed; i += 256) corner_s[i] = 0u;
-    else if (mark) for (int i = tid; i < nneed; i += 256) need_g[i] = 0u;            // huge field: marked in place, below
+    if (lds_mark) for (int i = tid; i < 6 * lv.tmax * wp + nneed; i += NT) corner_s[i] = 0u;
+    else if (mark) for (int i = tid; i < nneed; i += NT) need_g[i] = 0u;            // huge field: marked in place, below
     // branch and bound: gmin2 summarises the aligned 8x8 blocks around the 4x4 windows of the pose tiles, which
     // reach from 3 cells before the patch to 4 * ceil(nx / 4) + 3 cells after its corner
     // (two-level bounds: 8x8-pose tiles, 3x3 blocks: up to 8 * ceil(nx / 8) + 3)
@@ -987,20 +991,20 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
     const int ntl = (lead + span) >> BLUR_SHIFT;
     const double c = lv.theta_cos[it], s = lv.theta_sin[it];
     const int nc = lv.ncell;
-    const int per = n / 256;                               // beams per thread, interleaved: beam = q * 256 + tid, so that a
+    const int per = NT == 256 ? n / 256 : 1;               // beams per thread, interleaved: beam = q * NT + tid, so that a
     //                                                        wave's loads and stores are contiguous (at 1081 beams the
     //                                                        thread-contiguous mapping cost 32 cache lines per wave-load)
     // np.linspace(theta - fov/2, theta + fov/2, num=B)  (:82-83)
     const double eth = est[(size_t)p * estride + 2];
     const double a0 = eth - lid.fov / 2, a1 = eth + lid.fov / 2;
     const double astep = (a1 - a0) / (double)(B - 1);
-    constexpr int QMAX = SLAM2D_MAX_BEAMS / 256;
+    constexpr int QMAX = NT == 256 ? SLAM2D_MAX_BEAMS / 256 : 1;
     int key[QMAX], slot[QMAX];
     bool bad = false;
 #pragma unroll
     for (int q = 0; q < QMAX; ++q) {
         key[q] = INT_MAX; slot[q] = 0;
-        const int b = q * 256 + tid;
+        const int b = q * NT + tid;
         if (q < per && b < B) {
             const double rg = ranges[b];
             if (rg < lid.max_range) {                                               // :84
@@ -1034,7 +1038,7 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
             h = (h + 1) & hmask;
         }
         slot[q] = h;
-        atomicMin(&hown[h], q * 256 + tid);
+        atomicMin(&hown[h], q * NT + tid);
         if (mark) {                                        // tiles of the (2 nc + 1)^2 patch at (x0, y0)
             const int y0 = key[q] / lv.fpitch, x0 = key[q] - y0 * lv.fpitch;
             // (a patch clipped by the field's low edge keeps its full extent: at most one tile row / column too many)
@@ -1056,7 +1060,7 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
     DBG_CLOCK(42, it == 0 && p == 0);
     if (lds_mark) {
         const int nitem = lv.tmax * wp;
-        for (int i = tid; i < 2 * nitem; i += 256) {      // horizontal: class cx covers tx0 .. tx0 + ntl + cx
+        for (int i = tid; i < 2 * nitem; i += NT) {      // horizontal: class cx covers tx0 .. tx0 + ntl + cx
             const int cy = i / nitem, rj = i - cy * nitem, j = rj % wp;
             unsigned long long d = 0ull;
 #pragma unroll
@@ -1069,7 +1073,7 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
             hd_s[i] = (uint32_t)(d >> 32);
         }
         __syncthreads();
-        for (int i = tid; i < nitem; i += 256) {          // vertical: class cy covers ty0 .. ty0 + ntl + cy; then to the particle's bitmap
+        for (int i = tid; i < nitem; i += NT) {          // vertical: class cy covers ty0 .. ty0 + ntl + cy; then to the particle's bitmap
             const int row = i / wp, j = i - row * wp;
             uint32_t v = 0u;
             for (int dy = 0; dy <= ntl + 1 && dy <= row; ++dy) {
@@ -1086,7 +1090,7 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
             }
         }
         __syncthreads();
-        for (int i = tid; i < nneed; i += 256) need_g[i] = lin_s[i];
+        for (int i = tid; i < nneed; i += NT) need_g[i] = lin_s[i];
     }
     // ordered compaction, beam order = (q, wave, lane): per (q, wave) survivor counts through ballots, one barrier, then
     // every survivor's position = survivors of the steps / waves before + survivors of lower lanes of its own ballot
@@ -1097,10 +1101,10 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
 #pragma unroll
     for (int q = 0; q < QMAX; ++q) {
         if (q < per) {
-            const bool k = key[q] != INT_MAX && hown[slot[q]] == q * 256 + tid;
+            const bool k = key[q] != INT_MAX && hown[slot[q]] == q * NT + tid;
             owner |= (k ? 1u : 0u) << q;
             const unsigned long long km = __ballot(k);
-            if (lane == 0) qcnt[q * 4 + wv] = __popcll(km);
+            if (lane == 0) qcnt[q * NW + wv] = __popcll(km);
         }
     }
     __syncthreads();
@@ -1112,7 +1116,7 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
     for (int q = 0; q < QMAX; ++q) {
         if (q < per) {
             int before = run;
-            for (int w2 = 0; w2 < 4; ++w2) { const int c2 = qcnt[q * 4 + w2]; if (w2 < wv) before += c2; run += c2; }
+            for (int w2 = 0; w2 < NW; ++w2) { const int c2 = qcnt[q * NW + w2]; if (w2 < wv) before += c2; run += c2; }
             const unsigned long long km = __ballot((owner >> q) & 1u);
             if ((owner >> q) & 1u) {
                 const int pos = before + __popcll(km & below);
@@ -1134,7 +1138,7 @@ __global__ __launch_bounds__(256) void k_endpoints(Slam2dLidar lid, Slam2dLevel 
     pos_end = run;
     const int pos = pos_end;
     DBG_CLOCK(43, it == 0 && p == 0);
-    if (tid == 255) {
+    if (tid == NT - 1) {
         int K = pos;                                       // the last thread ends at the total
         if (K > lv.kmax) { K = lv.kmax; bad = true; }
         lv.kcount[p * lv.ntheta + it] = K;
@@ -2854,9 +2858,13 @@ static void launch_endpoints(const Slam2dLidar& lid, const Slam2dLevel& lv, int 
     int hsize = 512;
     while (hsize < lid.beams + (lid.beams >> 1)) hsize <<= 1;
     const size_t ep_lds = (size_t)(2 * hsize + 32 + (mark && lv.tmax <= EP_MARK_TMAX ? 6 * lv.tmax * ((lv.tmax + 31) / 32) + (lv.tmax * lv.tmax + 31) / 32 : 0)) * sizeof(int);
-    k_endpoints<<<dim3(lv.ntheta + (own_frame_maps ? 2 : 1), P), 256, ep_lds, s>>>(lid, lv, d_est, est_stride, d_ranges, d_flags, est_moving_dist,
-                                                        lv.fine ? nullptr : d_psi_cs, mark ? 1 : 0, prune ? 1 : 0,
-                                                        beam_table && lv.beam_xy ? 1 : 0, own_frame_maps);
+    const dim3 grid(lv.ntheta + (own_frame_maps ? 2 : 1), P);
+    if (lid.beams <= 192)
+        k_endpoints<192><<<grid, 192, ep_lds, s>>>(lid, lv, d_est, est_stride, d_ranges, d_flags, est_moving_dist, lv.fine ? nullptr : d_psi_cs,
+                                                   mark ? 1 : 0, prune ? 1 : 0, beam_table && lv.beam_xy ? 1 : 0, own_frame_maps);
+    else
+        k_endpoints<256><<<grid, 256, ep_lds, s>>>(lid, lv, d_est, est_stride, d_ranges, d_flags, est_moving_dist, lv.fine ? nullptr : d_psi_cs,
+                                                   mark ? 1 : 0, prune ? 1 : 0, beam_table && lv.beam_xy ? 1 : 0, own_frame_maps);
 }
 
 // cube sweep + selection
