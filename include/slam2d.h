@@ -179,8 +179,8 @@ typedef struct {
     double*  tilemax;        /* [P][tmax][tmax] scratch: per-tile maximum of the field as stored */
     int32_t* tilelist;       /* [P][2][tmax*tmax] scratch: work lists (tiles to blur, tiles to fill) */
     int32_t* tilecount;      /* [P][2] scratch: their lengths */
-    uint32_t* tileneed;      /* [P][ntheta][ceil(tmax*tmax/32)] scratch of slam2d_match: bit t of slice (p, theta) set = the
-                                poses of that angle read field tile t; every call rewrites every word, the field build
+    uint32_t* tileneed;      /* [P][ceil(ntheta/ep_group)][ceil(tmax*tmax/32)] scratch of slam2d_match: bit t of slice (p, g) set
+                                = the poses of that group of angles read field tile t; every call rewrites every word, the field build
                                 ORs the slices of a particle (may be NULL when only slam2d_field_build is used) */
     unsigned long long* freerow; /* [P][64] scratch (used when tmax <= 64): bit tx of word ty = field tile (ty, tx)
                                 holds the free-space constant; lets the sweep skip loads.  NULL disables */
@@ -208,7 +208,7 @@ typedef struct {
     double*  beam_xy;        /* [P][beams][2] scratch of slam2d_match (may be NULL): beam endpoints of the pose estimate
                                 (covertMeasureToXY, Utils/ScanMatcher_OGBased.py:81-89), evaluated once per particle */
     int32_t bnb;             /* 1: slam2d_match scores this level by branch and bound; 2: with two-level bounds */
-    int32_t _pad_bnb;
+    int32_t ep_group;        /* angles per k_endpoints block (>= 1; 0 = 1): tileneed holds ceil(ntheta / ep_group) slices per particle */
     int32_t occ_gen;         /* 0: occ + tilemask are cleared at every build.  1..255: generation stamp -- an
                                 occ / tilemask byte means "occupied" only when it equals occ_gen, so nothing is
                                 cleared; the caller passes a value unused since the buffers were last zeroed

@@ -82,11 +82,15 @@ __device__ __forceinline__ double unorder_bits(unsigned long long k) {
 // The occupied-field image and the tile flags are not cleared between builds: a cell / tile is
 // occupied when its byte equals the build's generation stamp (Slam2dLevel.occ_gen, 1..255).
 __device__ __forceinline__ uint8_t occ_stamp(const Slam2dLevel& lv) { return (uint8_t)(lv.occ_gen ? lv.occ_gen : 1); }
-// The needed-tile bitmap of slam2d_match: one slice per (particle, theta), written whole by that theta's k_endpoints block
+// The needed-tile bitmap of slam2d_match: one slice per (particle, group of ep_group angles), written whole by that group's k_endpoints block
 // with plain stores (every call overwrites every word: nothing to clear) and OR-ed over theta by the triage.  One shared
 // bitmap per particle cost k_endpoints half of its time at 139 angles: every block's atomics met on the same few lines.
-__device__ __forceinline__ uint32_t* need_slice(const Slam2dLevel& lv, const int p, const int it, const int nneed) {
-    return lv.tileneed + ((size_t)p * lv.ntheta + it) * nneed;
+__device__ __forceinline__ int need_slices(const Slam2dLevel& lv) {
+    const int G = max(lv.ep_group, 1);
+    return (lv.ntheta + G - 1) / G;
+}
+__device__ __forceinline__ uint32_t* need_slice(const Slam2dLevel& lv, const int p, const int grp, const int nneed) {
+    return lv.tileneed + ((size_t)p * need_slices(lv) + grp) * nneed;
 }
 // 0x01 in every byte of v that equals the stamp byte (exact per byte), 0x00 elsewhere
 __device__ __forceinline__ uint32_t bytes_equal(const uint32_t v, const uint8_t stamp) {
@@ -603,7 +607,7 @@ __global__ __launch_bounds__(TRIAGE_THREADS) void k_tile_triage(Slam2dLevel lv, 
     __syncthreads();
     if (lazy) {                                            // the particle's needed tiles: OR over the theta slices
         const uint32_t* __restrict__ sl = need_slice(lv, p, 0, nneed);
-        for (int i = tid; i < nneed * lv.ntheta; i += TRIAGE_THREADS) {
+        for (int i = tid; i < nneed * need_slices(lv); i += TRIAGE_THREADS) {
             const uint32_t v = sl[i];
             if (v) { const int w = i % nneed; if ((need_s[w] & v) != v) atomicOr(&need_s[w], v); }
         }
@@ -939,15 +943,19 @@ __global__ __launch_bounds__(NT) void k_endpoints(Slam2dLidar lid, Slam2dLevel l
     // mark != 0 (slam2d_match): the block also ORs the 16x16 field tiles its patches touch into
     // lv.tileneed (corner bits in LDS, dilated once per block), so that the field build can skip every other tile.
     extern __shared__ __attribute__((aligned(16))) int ep_lds[];     // [hsize] keys, [hsize] owners, [32] (step, wave) counts, tile-marking scratch
-    const int it = blockIdx.x, p = blockIdx.y, tid = threadIdx.x;
-    if (it == lv.ntheta) {                                 // the extra block of every particle: motion priors (+ ring)
+    // A block walks lv.ep_group adjacent angles one after the other: the beam endpoints (and, below 512 beams, their
+    // cos / sin) are evaluated once per block, and the tile marks of all its angles are dilated and stored once.
+    const int grp = blockIdx.x, p = blockIdx.y, tid = threadIdx.x;
+    const int G = max(lv.ep_group, 1), ngrp = (lv.ntheta + G - 1) / G;
+    if (grp == ngrp) {                                     // the extra block of every particle: motion priors (+ ring)
         write_priors(lv, p, est_dist, psi_cs, prune);
         return;
     }
-    if (it == lv.ntheta + 1) {                             // a second one (only when maps != NULL): what k_frame_axis would have done
+    if (grp == ngrp + 1) {                                 // a second one (only when maps != NULL): what k_frame_axis would have done
         frame_duties(lid, lv, maps, est, estride, flags, p);
         return;
     }
+    const int it0 = grp * G, it1 = min(it0 + G, lv.ntheta);
     const double ex = est[(size_t)p * estride], ey = est[(size_t)p * estride + 1];
     Slam2dFrame fr;
     if (maps) {
@@ -959,7 +967,7 @@ __global__ __launch_bounds__(NT) void k_endpoints(Slam2dLidar lid, Slam2dLevel l
         fr = lv.frames[p];
     }
     const int B = lid.beams;
-    DBG_CLOCK(40, it == 0 && p == 0);
+    DBG_CLOCK(40, grp == 0 && p == 0);
     int n = 256;
     while (n < B) n <<= 1;
     constexpr int NW = NT / 64;
@@ -980,7 +988,7 @@ __global__ __launch_bounds__(NT) void k_endpoints(Slam2dLidar lid, Slam2dLevel l
     uint32_t* corner_s = reinterpret_cast<uint32_t*>(ep_lds + 2 * hsize + 32);       // [2 cy][2 cx][tmax][wp]
     uint32_t* hd_s = corner_s + 4 * lv.tmax * wp;                                   // [2 cy][tmax][wp] after the horizontal pass
     uint32_t* lin_s = hd_s + 2 * lv.tmax * wp;                                      // [nneed] the block's bitmap (bit = ty * tmax + tx)
-    uint32_t* const need_g = mark ? need_slice(lv, p, it, nneed) : nullptr;
+    uint32_t* const need_g = mark ? need_slice(lv, p, grp, nneed) : nullptr;
     if (lds_mark) for (int i = tid; i < 6 * lv.tmax * wp + nneed; i += NT) corner_s[i] = 0u;
     else if (mark) for (int i = tid; i < nneed; i += NT) need_g[i] = 0u;            // huge field: marked in place, below
     // branch and bound: gmin2 summarises the aligned 8x8 blocks around the 4x4 windows of the pose tiles, which
@@ -989,7 +997,6 @@ __global__ __launch_bounds__(NT) void k_endpoints(Slam2dLidar lid, Slam2dLevel l
     const int lead = lv.bnb ? 3 : 0;
     const int span = lv.bnb == 2 ? 8 * ((2 * lv.ncell + 8) >> 3) + 3 : lv.bnb ? 4 * ((2 * lv.ncell + 4) >> 2) + 3 : 2 * lv.ncell;
     const int ntl = (lead + span) >> BLUR_SHIFT;
-    const double c = lv.theta_cos[it], s = lv.theta_sin[it];
     const int nc = lv.ncell;
     const int per = NT == 256 ? n / 256 : 1;               // beams per thread, interleaved: beam = q * NT + tid, so that a
     //                                                        wave's loads and stores are contiguous (at 1081 beams the
@@ -1000,10 +1007,11 @@ __global__ __launch_bounds__(NT) void k_endpoints(Slam2dLidar lid, Slam2dLevel l
     const double astep = (a1 - a0) / (double)(B - 1);
     constexpr int QMAX = NT == 256 ? SLAM2D_MAX_BEAMS / 256 : 1;
     int key[QMAX], slot[QMAX];
+    double bdx[QMAX], bdy[QMAX];                           // beam endpoint - estimate (:167-168), NaN: no return (:84)
     bool bad = false;
 #pragma unroll
     for (int q = 0; q < QMAX; ++q) {
-        key[q] = INT_MAX; slot[q] = 0;
+        bdx[q] = NAN; bdy[q] = NAN;
         const int b = q * NT + tid;
         if (q < per && b < B) {
             const double rg = ranges[b];
@@ -1015,7 +1023,21 @@ __global__ __launch_bounds__(NT) void k_endpoints(Slam2dLidar lid, Slam2dLevel l
                     const double a = (b == B - 1) ? a1 : (double)b * astep + a0;
                     px = ex + cos(a) * rg; py = ey + sin(a) * rg;                   // :87-88
                 }
-                const double dx = px - ex, dy = py - ey;
+                bdx[q] = px - ex; bdy[q] = py - ey;
+            }
+        }
+    }
+  for (int it = it0; it < it1; ++it) {                     // (indentation kept: the body is one angle's pass)
+    const double c = lv.theta_cos[it], s = lv.theta_sin[it];
+    if (it > it0) {                                        // the previous angle's compaction is past its barrier: the hash
+        for (int i = tid; i < hsize; i += NT) { hkey[i] = INT_MAX; hown[i] = INT_MAX; }      // set is free again
+    }
+#pragma unroll
+    for (int q = 0; q < QMAX; ++q) {
+        key[q] = INT_MAX; slot[q] = 0;
+        if (q < per) {
+            if (!isnan(bdx[q])) {
+                const double dx = bdx[q], dy = bdy[q];
                 const double qx = ex + c * dx - s * dy;                             // :169
                 const double qy = ey + s * dx + c * dy;                             // :170
                 const int cx = (int)((qx - fr.xlo) / lv.step);                      // :174
@@ -1058,40 +1080,6 @@ __global__ __launch_bounds__(NT) void k_endpoints(Slam2dLidar lid, Slam2dLevel l
     }
     __syncthreads();
     DBG_CLOCK(42, it == 0 && p == 0);
-    if (lds_mark) {
-        const int nitem = lv.tmax * wp;
-        for (int i = tid; i < 2 * nitem; i += NT) {      // horizontal: class cx covers tx0 .. tx0 + ntl + cx
-            const int cy = i / nitem, rj = i - cy * nitem, j = rj % wp;
-            unsigned long long d = 0ull;
-#pragma unroll
-            for (int cx = 0; cx < 2; ++cx) {
-                const uint32_t* c = corner_s + (cy * 2 + cx) * nitem + rj;
-                unsigned long long v = ((unsigned long long)c[0] << 32) | (j ? c[-1] : 0u);
-                for (int k = 0; k < ntl + cx; ++k) v |= v << 1;
-                d |= v;
-            }
-            hd_s[i] = (uint32_t)(d >> 32);
-        }
-        __syncthreads();
-        for (int i = tid; i < nitem; i += NT) {          // vertical: class cy covers ty0 .. ty0 + ntl + cy; then to the particle's bitmap
-            const int row = i / wp, j = i - row * wp;
-            uint32_t v = 0u;
-            for (int dy = 0; dy <= ntl + 1 && dy <= row; ++dy) {
-                if (dy <= ntl) v |= hd_s[i - dy * wp];
-                v |= hd_s[nitem + i - dy * wp];
-            }
-            const int left = lv.tmax - 32 * j;             // tiles of this word inside the row
-            if (left < 32) v &= (1u << left) - 1u;
-            if (v) {
-                const int start = row * lv.tmax + 32 * j, sh = start & 31;
-                const uint32_t lo = v << sh, hi = sh ? v >> (32 - sh) : 0u;
-                if (lo) atomicOr(&lin_s[start >> 5], lo);
-                if (hi) atomicOr(&lin_s[(start >> 5) + 1], hi);
-            }
-        }
-        __syncthreads();
-        for (int i = tid; i < nneed; i += NT) need_g[i] = lin_s[i];
-    }
     // ordered compaction, beam order = (q, wave, lane): per (q, wave) survivor counts through ballots, one barrier, then
     // every survivor's position = survivors of the steps / waves before + survivors of lower lanes of its own ballot
     const int wv = tid >> 6, lane = tid & 63;
@@ -1143,7 +1131,44 @@ __global__ __launch_bounds__(NT) void k_endpoints(Slam2dLidar lid, Slam2dLevel l
         if (K > lv.kmax) { K = lv.kmax; bad = true; }
         lv.kcount[p * lv.ntheta + it] = K;
     }
+  }
     if (bad) atomicOr(&flags[p], SLAM2D_F_ENDPOINT_OUTSIDE);
+    if (!lds_mark) return;                                 // (block-uniform)
+    __syncthreads();                                       // the corner bits of the block's angles are all set
+    {
+        const int nitem = lv.tmax * wp;
+        for (int i = tid; i < 2 * nitem; i += NT) {      // horizontal: class cx covers tx0 .. tx0 + ntl + cx
+            const int cy = i / nitem, rj = i - cy * nitem, j = rj % wp;
+            unsigned long long d = 0ull;
+#pragma unroll
+            for (int cx = 0; cx < 2; ++cx) {
+                const uint32_t* c = corner_s + (cy * 2 + cx) * nitem + rj;
+                unsigned long long v = ((unsigned long long)c[0] << 32) | (j ? c[-1] : 0u);
+                for (int k = 0; k < ntl + cx; ++k) v |= v << 1;
+                d |= v;
+            }
+            hd_s[i] = (uint32_t)(d >> 32);
+        }
+        __syncthreads();
+        for (int i = tid; i < nitem; i += NT) {          // vertical: class cy covers ty0 .. ty0 + ntl + cy; then to the particle's bitmap
+            const int row = i / wp, j = i - row * wp;
+            uint32_t v = 0u;
+            for (int dy = 0; dy <= ntl + 1 && dy <= row; ++dy) {
+                if (dy <= ntl) v |= hd_s[i - dy * wp];
+                v |= hd_s[nitem + i - dy * wp];
+            }
+            const int left = lv.tmax - 32 * j;             // tiles of this word inside the row
+            if (left < 32) v &= (1u << left) - 1u;
+            if (v) {
+                const int start = row * lv.tmax + 32 * j, sh = start & 31;
+                const uint32_t lo = v << sh, hi = sh ? v >> (32 - sh) : 0u;
+                if (lo) atomicOr(&lin_s[start >> 5], lo);
+                if (hi) atomicOr(&lin_s[(start >> 5) + 1], hi);
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < nneed; i += NT) need_g[i] = lin_s[i];
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -2858,7 +2883,8 @@ static void launch_endpoints(const Slam2dLidar& lid, const Slam2dLevel& lv, int 
     int hsize = 512;
     while (hsize < lid.beams + (lid.beams >> 1)) hsize <<= 1;
     const size_t ep_lds = (size_t)(2 * hsize + 32 + (mark && lv.tmax <= EP_MARK_TMAX ? 6 * lv.tmax * ((lv.tmax + 31) / 32) + (lv.tmax * lv.tmax + 31) / 32 : 0)) * sizeof(int);
-    const dim3 grid(lv.ntheta + (own_frame_maps ? 2 : 1), P);
+    const int G = lv.ep_group > 0 ? lv.ep_group : 1;
+    const dim3 grid(cdiv(lv.ntheta, G) + (own_frame_maps ? 2 : 1), P);
     if (lid.beams <= 192)
         k_endpoints<192><<<grid, 192, ep_lds, s>>>(lid, lv, d_est, est_stride, d_ranges, d_flags, est_moving_dist, lv.fine ? nullptr : d_psi_cs,
                                                    mark ? 1 : 0, prune ? 1 : 0, beam_table && lv.beam_xy ? 1 : 0, own_frame_maps);

@@ -470,6 +470,9 @@ class SearchLevel:
         self.bnb_levels = 0 if not self.bnb else (int(lv_env) if lv_env in ("1", "2") else (2 if lidar.beams >= 512 else 1))
         if self.bnb_levels == 2 and self.nx < 17:
             self.bnb_levels = 1
+        # angles per k_endpoints block (the block dilates and stores its tile marks once): SLAM2D_EP_GROUP overrides
+        g_env = os.environ.get("SLAM2D_EP_GROUP", "")
+        self.ep_group = int(g_env) if g_env.isdigit() and int(g_env) >= 1 else (4 if lidar.beams >= 512 else 2)      # measured: 1081 beams 189 / 173 / 163 / 165 us for 1 / 2 / 4 / 8, 180 beams 22.4 / 18.7 / 19.6 for 1 / 2 / 4
         nbt = (self.nx + 3) // 4
         nbq4 = 4 * ((nbt + 3) // 4)
         i32, f64 = torch.int32, torch.float64
@@ -495,7 +498,7 @@ class SearchLevel:
             tilemax=torch.zeros((P, self.tmax, self.tmax), dtype=f64, device=device),
             tilelist=torch.zeros((P, 2, self.tmax * self.tmax), dtype=i32, device=device),
             tilecount=torch.zeros((P, 2), dtype=i32, device=device),
-            tileneed=torch.zeros((P, self.ntheta, (self.tmax * self.tmax + 31) // 32), dtype=i32, device=device),   # one slice per angle
+            tileneed=torch.zeros((P, -(-self.ntheta // self.ep_group), (self.tmax * self.tmax + 31) // 32), dtype=i32, device=device),   # one slice per group of angles
             freerow=torch.zeros((P, 64), dtype=torch.int64, device=device),
             ring=torch.zeros(1 + self.nx * ((self.nx + 3) // 4), dtype=i32, device=device),
             prune_state=torch.zeros(P, dtype=i32, device=device),
@@ -531,7 +534,7 @@ class SearchLevel:
             tilemin=t["tilemin"].data_ptr(), tilemax=t["tilemax"].data_ptr(), tilelist=t["tilelist"].data_ptr(),
             tilecount=t["tilecount"].data_ptr(),
             tileneed=t["tileneed"].data_ptr(), freerow=t["freerow"].data_ptr(), ring=t["ring"].data_ptr(), prune_state=t["prune_state"].data_ptr(),
-            ring_cap=self.nx * ((self.nx + 3) // 4), bnb=self.bnb_levels, beam_xy=t["beam_xy"].data_ptr(),
+            ring_cap=self.nx * ((self.nx + 3) // 4), bnb=self.bnb_levels, ep_group=self.ep_group, beam_xy=t["beam_xy"].data_ptr(),
             **({k: t[k].data_ptr() for k in ("gmin3d", "p3cells", "bounds1", "seed_key")} if self.bnb_levels == 2 else {}),
             **({k: t[k].data_ptr() for k in ("gmin", "gmin2", "pcells", "bounds", "tile_pmax", "bnb_best")} if self.bnb else {}))
 
