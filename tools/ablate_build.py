@@ -7,23 +7,20 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = open(os.path.join(REPO, "slam-2d-lidar-scan_amd/csrc/slam2d.hip")).read()
 VARIANTS = {
     "base": [],
+    "ep_exactdiv": [("    if (fabs(t - rint(t)) < 1e-6 || !(fabs(t) < 1e9)) return (int)(v / step);\n    return (int)t;", "    (void)t; return (int)(v / step);")],
     "ep_nomark": [("        if (mark) {                                        // tiles of the", "        if (false) {                                       // tiles of the")],
-    "ep_nodiv": [("const int cx = (int)((qx - fr.xlo) / lv.step);", "const int cx = (int)((qx - fr.xlo) * (1.0 / lv.step));"),
-                 ("const int cy = (int)((qy - fr.ylo) / lv.step);", "const int cy = (int)((qy - fr.ylo) * (1.0 / lv.step));")],
     "ep_nohash": [("""        for (;;) {
             const int prev = atomicCAS(&hkey[h], INT_MAX, key[q]);
             if (prev == INT_MAX || prev == key[q]) break;
             h = (h + 1) & hmask;
         }
         slot[q] = h;
-        atomicMin(&hown[h], q * 256 + tid);""", """        h = (q * 256 + tid) & hmask; hkey[h] = key[q];
+        atomicMin(&hown[h], q * NT + tid);""", """        h = (q * NT + tid) & hmask; hkey[h] = key[q];
         slot[q] = h;
-        hown[h] = q * 256 + tid;""")],
-    "ep_nomin": [("        atomicMin(&hown[h], q * 256 + tid);", "        hown[h] = q * 256 + tid;")],
-    "bg1": [("#define BOUND_GROUP 4 ", "#define BOUND_GROUP 1 ")],
-    "bg2": [("#define BOUND_GROUP 4 ", "#define BOUND_GROUP 2 ")],
-    "bg8": [("#define BOUND_GROUP 4 ", "#define BOUND_GROUP 8 ")],
-    "ep_nostore": [("                    out[pos] = key[q];\n                    if (pout) {", "                    if (pout && pos < 0) {")],
+        hown[h] = q * NT + tid;""")],
+    "ep_nostore": [("                    out[pos] = y0 * lv.fpitch + x0;\n                    if (pout) {", "                    if (pout && pos < 0) {")],
+    "ep_nokeys": [("                const double qx = ex + c * dx - s * dy;                             // :169", "                const double qx = ex + dx;"),
+                  ("                const double qy = ey + s * dx + c * dy;                             // :170", "                const double qy = ey + dy;")],
 }
 def main():
     names = sys.argv[1:] or list(VARIANTS)
