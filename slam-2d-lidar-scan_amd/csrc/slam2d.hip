@@ -289,7 +289,8 @@ __global__ __launch_bounds__(256) void k_occ_scatter(Slam2dLevel lv, const Slam2
             nz &= nz - 1;
             int sb = -1;
             if (nz) { sb = __ffsll((long long)nz) - 1; nz &= nz - 1; }
-            const uint32_t wa = __shfl(word, sa), wb = sb >= 0 ? __shfl(word, sb) : 0u;
+            // (sa, sb are wave-uniform: v_readlane, not a ds_bpermute round trip per step)
+            const uint32_t wa = (uint32_t)__builtin_amdgcn_readlane((int)word, sa), wb = sb >= 0 ? (uint32_t)__builtin_amdgcn_readlane((int)word, sb) : 0u;
             const uint32_t wsel = half ? wb : wa;
             const int src = half ? sb : sa;
             if ((wsel >> bit) & 1u) {
@@ -655,7 +656,7 @@ __global__ __launch_bounds__(TRIAGE_THREADS) void k_tile_triage(Slam2dLevel lv, 
             if (!mask) continue;
             int start = 0;
             if (lane == 0) start = atomicAdd(&base[which], __popcll(mask));
-            start = __shfl(start, 0);
+            start = __builtin_amdgcn_readfirstlane(start);
             if (mine[which]) list[which * ntile + start + __popcll(mask & below)] = t;
         }
     }
@@ -1575,14 +1576,14 @@ __global__ __launch_bounds__(64) void k_select(Slam2dLevel lv, int chunks, int R
         const double up = __shfl_up(incl, o);
         if (lane >= o) incl += up;
     }
-    const double total = __shfl(incl, WAVE - 1);
+    const double total = readlane_f64(incl, WAVE - 1);
     int pick = me.i;
     if (uniform != nullptr && !isnan(total)) {
         // np.random.choice(n, 1, p): first index whose normalised cdf exceeds u (:137-138)
         const double target = uniform[p] * total;
         const unsigned long long ahead = __ballot(incl > target);
         const int lsel = ahead ? __ffsll((long long)ahead) - 1 : WAVE - 1;
-        double run = __shfl(incl - mine, lsel);                   // cdf before lane lsel's partials
+        double run = readlane_f64(incl - mine, lsel);             // cdf before lane lsel's partials
         const int s0 = min(lsel * per, nW - 1), s1 = max(s0 + 1, min(nW, lsel * per + per));
         int wsel = s1 - 1;
         for (int w = s0; w < s1; ++w) {                           // wave-uniform loop
@@ -1611,7 +1612,7 @@ __global__ __launch_bounds__(64) void k_select(Slam2dLevel lv, int chunks, int R
             const unsigned long long have = __ballot(nvl > 0);
             const int llast = 63 - __clzll((long long)have);                      // chunk's last slot (have != 0)
             const int l2 = hit ? __ffsll((long long)hit) - 1 : llast;
-            double r2 = run + __shfl(linc - lsum, l2);
+            double r2 = run + readlane_f64(linc - lsum, l2);
             int found = -1;
             if (lane == l2) {
                 for (int e = 0; e < nvl; ++e) {
@@ -1620,7 +1621,7 @@ __global__ __launch_bounds__(64) void k_select(Slam2dLevel lv, int chunks, int R
                 }
                 if (found < 0) found = it * npose + q0 + max(0, nvl - 1);         // rounding fallback: last pose
             }
-            pick = __shfl(found, l2);
+            pick = __builtin_amdgcn_readlane(found, l2);
         } else {
         // inside chunk wsel: it covers slots [ch*64*RQ, ...) = a contiguous pose range [qlo, qhi);
         // lane l owns a contiguous run of `per2` poses of it
@@ -1641,7 +1642,7 @@ __global__ __launch_bounds__(64) void k_select(Slam2dLevel lv, int chunks, int R
         pick = it * npose + max(qlo, qhi - 1);                    // rounding fallback: chunk's last pose
         if (hit) {
             const int l2 = __ffsll((long long)hit) - 1;
-            double r2 = run + __shfl(linc - lsum, l2);
+            double r2 = run + readlane_f64(linc - lsum, l2);
             int found = -1;
             if (lane == l2) {
                 for (int q = a0; q < a1; ++q) {
@@ -1650,7 +1651,7 @@ __global__ __launch_bounds__(64) void k_select(Slam2dLevel lv, int chunks, int R
                 }
                 if (found < 0) found = it * npose + max(a0, a1 - 1);
             }
-            pick = __shfl(found, l2);
+            pick = __builtin_amdgcn_readlane(found, l2);
         }
         }
     }
@@ -2273,7 +2274,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_exact_select(Slam2dLevel lv, con
             double mq = scorer && !isnan(sc) ? sc : -INFINITY;
             mq = fmax(mq, __longlong_as_double((long long)dpp_u64<0xB1>((unsigned long long)__double_as_longlong(mq))));
             mq = fmax(mq, __longlong_as_double((long long)dpp_u64<0x4E>((unsigned long long)__double_as_longlong(mq))));
-            const double tmx = fmax(fmax(__shfl(mq, 0), __shfl(mq, 16)), fmax(__shfl(mq, 32), __shfl(mq, 48)));
+            const double tmx = fmax(fmax(readlane_f64(mq, 0), readlane_f64(mq, 16)), fmax(readlane_f64(mq, 32), readlane_f64(mq, 48)));
             const unsigned long long nanm = __ballot(scorer && isnan(sc));
             const unsigned long long eqm = nanm ? nanm : __ballot(scorer && sc == tmx);
             if (lane == 0) {
@@ -2351,7 +2352,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_exact_select(Slam2dLevel lv, con
         const double up = __shfl_up(cinc, o);
         if (lane >= o) cinc += up;
     }
-    const double total = __shfl(cinc, WAVE - 1);
+    const double total = readlane_f64(cinc, WAVE - 1);
     int pick = Mi_s[0];
     if (uniform != nullptr && !isnan(total)) {
         // np.random.choice(n, 1, p): first index whose normalised cdf exceeds u (:137-138); the poses that were not
@@ -2359,7 +2360,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_exact_select(Slam2dLevel lv, con
         const double target = uniform[p] * total;
         const unsigned long long ahead = __ballot(cinc > target);
         const int lsel = ahead ? __ffsll((long long)ahead) - 1 : WAVE - 1;
-        double run = __shfl(cinc - mine, lsel);
+        double run = readlane_f64(cinc - mine, lsel);
         const int s0 = min(lsel * tper, nW - 1), s1 = max(s0 + 1, min(nW, lsel * tper + tper));
         int it = s1 - 1;
         for (int w = s0; w < s1; ++w) {                           // wave-uniform loop
@@ -2402,7 +2403,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_exact_select(Slam2dLevel lv, con
         const unsigned long long have = __ballot(has);
         if (have) {
             const int l2 = hit ? __ffsll((long long)hit) - 1 : 63 - __clzll((long long)have);
-            double r2 = run + __shfl(linc - lsum, l2);
+            double r2 = run + readlane_f64(linc - lsum, l2);
             int found = -1, last = -1;
             if (lane == l2) {
                 if (in_lds) {
@@ -2430,7 +2431,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_exact_select(Slam2dLevel lv, con
                 }
                 if (found < 0) found = last;                      // rounding fallback: the row's last scored pose
             }
-            pick = __shfl(found, l2);
+            pick = __builtin_amdgcn_readlane(found, l2);
         }
     }
     if (lane == 0) {
