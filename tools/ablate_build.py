@@ -7,6 +7,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = open(os.path.join(REPO, "slam-2d-lidar-scan_amd/csrc/slam2d.hip")).read()
 VARIANTS = {
     "base": [],
+    "sc64": [("#define SCATTER_ROWS 32", "#define SCATTER_ROWS 64")],
+    "sc16": [("#define SCATTER_ROWS 32", "#define SCATTER_ROWS 16")],
     "ep_exactdiv": [("    if (fabs(t - rint(t)) < 1e-6 || !(fabs(t) < 1e9)) return (int)(v / step);\n    return (int)t;", "    (void)t; return (int)(v / step);")],
     "ep_nomark": [("        if (mark) {                                        // tiles of the", "        if (false) {                                       // tiles of the")],
     "ep_nohash": [("""        for (;;) {
