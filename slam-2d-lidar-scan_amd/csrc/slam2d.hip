@@ -914,20 +914,6 @@ __device__ __forceinline__ void frame_duties(const Slam2dLidar& lid, const Slam2
 //      A cell is stored as the offset of the corner of its (2*ncell+1)^2 patch:
 //      (cy - ncell) * fpitch + (cx - ncell).
 // ------------------------------------------------------------------------------------
-#define EP_MARK_TMAX 192             // fields up to 3072 cells an edge dilate their tile marks in LDS (6 * tmax * ceil(tmax / 32) + tmax^2 / 32 words)
-// the tiles of the patch at (x0, y0), straight into the particle's bitmap (slow path of k_endpoints' marking)
-__device__ __forceinline__ void mark_tiles_direct(uint32_t* need_g, const int x0, const int y0, const int lead, const int span, const int tmax) {
-    const int tx0 = max(x0 - lead, 0) >> BLUR_SHIFT, tx1 = min((x0 + span) >> BLUR_SHIFT, tmax - 1);
-    for (int ty = max(y0 - lead, 0) >> BLUR_SHIFT; ty <= min((y0 + span) >> BLUR_SHIFT, tmax - 1); ++ty)
-        for (int tx = tx0; tx <= tx1;) {                   // runs of bits inside one 32-bit word
-            const int bit = ty * tmax + tx;
-            const int len = min(tx1 - tx + 1, 32 - (bit & 31));
-            const uint32_t m = (len == 32 ? ~0u : ((1u << len) - 1u)) << (bit & 31);
-            uint32_t* g = need_g + (bit >> 5);
-            if ((__hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & m) != m) atomicOr(g, m);
-            tx += len;
-        }
-}
 // NT threads: 256, or 192 for scans of up to 192 beams (one beam per thread; 10 blocks per CU instead of 8 hold all the
 // 36 x 64 + 128 blocks of config 2 at once -- no second, nearly empty round)
 template <int NT>
@@ -985,13 +971,12 @@ __global__ __launch_bounds__(NT) void k_endpoints(Slam2dLidar lid, Slam2dLevel l
     // this kernel's time at 1081 beams.
     const int nneed = (lv.tmax * lv.tmax + 31) >> 5;
     const int wp = (lv.tmax + 31) >> 5;                    // words per tile row
-    const bool lds_mark = mark && lv.tmax <= EP_MARK_TMAX;
+    const bool lds_mark = mark != 0;                       // (tmax^2 <= 28000, check_field_args: the scratch is <= 28 KB)
     uint32_t* corner_s = reinterpret_cast<uint32_t*>(ep_lds + 2 * hsize + 32);       // [2 cy][2 cx][tmax][wp]
     uint32_t* hd_s = corner_s + 4 * lv.tmax * wp;                                   // [2 cy][tmax][wp] after the horizontal pass
     uint32_t* lin_s = hd_s + 2 * lv.tmax * wp;                                      // [nneed] the block's bitmap (bit = ty * tmax + tx)
     uint32_t* const need_g = mark ? need_slice(lv, p, grp, nneed) : nullptr;
     if (lds_mark) for (int i = tid; i < 6 * lv.tmax * wp + nneed; i += NT) corner_s[i] = 0u;
-    else if (mark) for (int i = tid; i < nneed; i += NT) need_g[i] = 0u;            // huge field: marked in place, below
     // branch and bound: gmin2 summarises the aligned 8x8 blocks around the 4x4 windows of the pose tiles, which
     // reach from 3 cells before the patch to 4 * ceil(nx / 4) + 3 cells after its corner
     // (two-level bounds: 8x8-pose tiles, 3x3 blocks: up to 8 * ceil(nx / 8) + 3)
@@ -1076,8 +1061,6 @@ __global__ __launch_bounds__(NT) void k_endpoints(Slam2dLidar lid, Slam2dLevel l
                 const uint32_t m = 1u << (tx0 & 31);
                 // neighbouring beams share the corner tile: a plain read first, the atomic only for a new bit
                 if (!(*w & m)) atomicOr(w, m);
-            } else {                                       // a huge field: this block's slice, in place
-                mark_tiles_direct(need_g, x0, y0, lead, span, lv.tmax);
             }
         }
     }
@@ -2885,7 +2868,7 @@ static void launch_endpoints(const Slam2dLidar& lid, const Slam2dLevel& lv, int 
     while (n < lid.beams) n <<= 1;
     int hsize = 512;
     while (hsize < lid.beams + (lid.beams >> 1)) hsize <<= 1;
-    const size_t ep_lds = (size_t)(2 * hsize + 32 + (mark && lv.tmax <= EP_MARK_TMAX ? 6 * lv.tmax * ((lv.tmax + 31) / 32) + (lv.tmax * lv.tmax + 31) / 32 : 0)) * sizeof(int);
+    const size_t ep_lds = (size_t)(2 * hsize + 32 + (mark ? 6 * lv.tmax * ((lv.tmax + 31) / 32) + (lv.tmax * lv.tmax + 31) / 32 : 0)) * sizeof(int);
     const int G = lv.ep_group > 0 ? lv.ep_group : 1;
     const dim3 grid(cdiv(lv.ntheta, G) + (own_frame_maps ? 2 : 1), P);
     if (lid.beams <= 192)
