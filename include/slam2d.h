@@ -291,7 +291,13 @@ int slam2d_sweep(const Slam2dLidar* lidar, const Slam2dLevel* level, int32_t P,
  * skipped scores < max - 30: it cannot be the arg-max, and all skipped poses together (<= 2.4e5 of them at the
  * largest configuration) change confidence and the soft-max draw by < 2.4e5 * exp(-30) = 2.2e-8 relative -- the bar
  * is 1e-5.  A tile holding a NaN prior is always scored (np.argmax returns the first NaN).  level->cube
- * then holds only the scored tiles. */
+ * then holds only the scored tiles.
+ * bnb == 2 (long cell lists, ~1000 beams): the bounds come in two levels.  Tiles of 8 x 8 poses are bounded first
+ * through gmin3d (their 8 x 8 cell window lies inside 3 x 3 aligned 4 x 4 blocks); one exact seed per particle (the
+ * best child of the tile with the best 8 x 8 bound, seed_key) gives a first threshold; the 4 x 4 children of the
+ * 8 x 8 tiles that reach it get their gmin2 bounds (all other 4 x 4 tiles: -inf), and every theta whose best child
+ * still reaches the running maximum is seeded exactly and raises it.  The maximum over all candidate seeds and the
+ * tile set scored exactly do not depend on the order in which the waves run. */
 int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2dMap* d_maps, int32_t P,
                  const double* d_est, int32_t est_stride, const double* d_ranges,
                  double est_moving_dist, const double* d_psi_cs, const double* d_uniform,
