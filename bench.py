@@ -159,7 +159,11 @@ class HotPath:
             (e.match if self.lazy else e.sweep)(self.fine, self.m_coarse, E.MATCH_DOUBLES, rng, float(self.dist[s]),
                                                 None, None, self.m_fine)
             final = self.m_fine
-        e.grid_update(final, E.MATCH_DOUBLES, rng)
+        if self.sharded:
+            e.grid_update(final, E.MATCH_DOUBLES, rng)
+        else:       # one launch: the normaliser rides beside the update (it reads only what the match wrote)
+            e.grid_update_weights(final, E.MATCH_DOUBLES, rng, self.d_logw, self.m_coarse.data_ptr() + 32, E.MATCH_DOUBLES,
+                                  self.d_w, self.d_stats)         # +32: log_confidence
 
     def normalise(self):
         """weight *= confidence, then the normaliser over all particles of the job."""
@@ -171,10 +175,7 @@ class HotPath:
                 # (overlap: collective + merge on a side stream.  Bit-identical, but at one rank its events and stream
                 # switches cost the host more than the collective's latency: 0.207 vs 0.187 ms/step -- off by default)
             self.normalizer(self.d_logw, self.m_coarse.data_ptr() + 32, E.MATCH_DOUBLES, self.d_w, self.d_stats)   # +32: log_confidence
-        else:
-            E._lib.check(self.L.slam2d_weights_normalize(E._ptr(self.d_logw), C.c_void_p(self.m_coarse.data_ptr() + 32),
-                                                         E.MATCH_DOUBLES, self.P, E._ptr(self.d_w),
-                                                         E._ptr(self.d_stats), E._stream()), "weights")
+        # (one GPU: the normaliser went out with the map update, match_and_update)
 
     def step(self, s):
         self.match_and_update(s)

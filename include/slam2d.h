@@ -349,6 +349,11 @@ int slam2d_post_match(const Slam2dMatch* d_fine, const Slam2dMatch* d_coarse, in
  *   d_stats[2]   out: [variance = sum (w - 1/N)^2, log of the pre-normalisation weight sum] */
 int slam2d_weights_normalize(double* d_logw, const double* d_logconf, int32_t logconf_stride, int32_t N,
                              double* d_w, double* d_stats, void* stream);
+/* slam2d_grid_update and slam2d_weights_normalize in ONE launch (the normaliser is one extra block beside the
+ * update's: it only reads the log-weights and the log-confidences, which the match wrote).  N = P. */
+int slam2d_grid_update_weights(const Slam2dLidar* lidar, const Slam2dMap* d_maps, int32_t P, const double* d_pose,
+                               int32_t pose_stride, const double* d_ranges, uint32_t* d_flags, double* d_logw,
+                               const double* d_logconf, int32_t logconf_stride, double* d_w, double* d_stats, void* stream);
 
 /* One scan of Particle.update for P particles in two calls (Algorithm/FastSlam.py:122-135), so that a host loop pays two
  * library calls per scan instead of six:
@@ -356,8 +361,10 @@ int slam2d_weights_normalize(double* d_logw, const double* d_logconf, int32_t lo
  *                         the coarse result, arg-max) -- reads the maps, changes no filter state; `options` as slam2d_match
  *                         (coarse level);
  *   slam2d_scan_commit  = slam2d_post_match + slam2d_grid_update at the matched poses + (d_w != NULL) slam2d_weights_normalize
- *                         over these P particles, whose launch also moves the scan's fault bits from d_flags (cleared) into
- *                         d_flag_snapshot[P], so that one asynchronous download returns everything the host reads.
+ *                         over these P particles (in the update's launch), which also moves the scan's fault bits from
+ *                         d_flags into d_flag_snapshot[P] with an atomic exchange, so that one asynchronous download
+ *                         returns everything the host reads; a bit the update raises after the exchange stays in d_flags
+ *                         and is reported with the next call.
  * Arguments as in the calls they bundle. */
 int slam2d_scan_match(const Slam2dLidar* lidar, const Slam2dLevel* coarse, const Slam2dLevel* fine, const Slam2dMap* d_maps,
                       int32_t P, const double* d_prev_pose, double raw_theta, double prev_raw_theta, int32_t has_turn,

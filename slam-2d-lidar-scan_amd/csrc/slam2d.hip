@@ -2436,6 +2436,61 @@ __global__ __launch_bounds__(XS_THREADS) void k_exact_select(Slam2dLevel lv, con
 }
 
 // ------------------------------------------------------------------------------------
+// K4  weights                                        (Algorithm/FastSlam.py:30-48,135)
+// ------------------------------------------------------------------------------------
+// One 256-thread block.  `exchange`: the block runs beside the update blocks of the same launch (slam2d_scan_commit,
+// slam2d_grid_update_weights), which may still raise bits: they are taken with an atomic exchange, so a bit raised
+// after it stays in flags and is reported with the next scan instead of being lost.
+struct WeightsJob {
+    double* logw; const double* logconf; int cstride; int N; double* w; double* stats; uint32_t* flags; uint32_t* flag_snapshot;
+};
+__device__ __forceinline__ void weights_body(double* logw, const double* __restrict__ logconf, const int cstride, const int N,
+                                             double* w, double* stats, uint32_t* flags, uint32_t* flag_snapshot, const bool exchange) {
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    if (flags)                                         // slam2d_scan_commit: the scan's fault bits move into the report
+        for (int i = tid; i < N; i += 256) {
+            if (exchange) flag_snapshot[i] = atomicExch(&flags[i], 0u);
+            else { flag_snapshot[i] = flags[i]; flags[i] = 0u; }
+        }
+    double mx = -INFINITY;
+    for (int i = tid; i < N; i += 256) {
+        double v = logw[i] + (logconf ? logconf[(size_t)i * cstride] : 0.0);
+        logw[i] = v;
+        mx = fmax(mx, v);
+    }
+    red[tid] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] = fmax(red[tid], red[tid + o]); __syncthreads(); }
+    mx = red[0];
+    __syncthreads();
+    double s = 0.0;
+    for (int i = tid; i < N; i += 256) s += exp(logw[i] - mx);
+    red[tid] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    const double total = red[0];
+    __syncthreads();
+    const double lse = mx + log(total);
+    double var = 0.0;
+    for (int i = tid; i < N; i += 256) {
+        const double wi = exp(logw[i] - mx) / total;                                 // :47-48
+        w[i] = wi;
+        logw[i] = logw[i] - lse;
+        const double d = wi - 1.0 / (double)N;                                       // :34
+        var += d * d;
+    }
+    red[tid] = var;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    if (tid == 0) { stats[0] = red[0]; stats[1] = lse; }
+}
+__global__ __launch_bounds__(256) void k_weights(double* logw, const double* __restrict__ logconf, int cstride, int N,
+                                                 double* w, double* stats, uint32_t* flags, uint32_t* flag_snapshot) {
+    weights_body(logw, logconf, cstride, N, w, stats, flags, flag_snapshot, false);
+}
+
+// ------------------------------------------------------------------------------------
 // K3  occupancy-grid update                         (Utils/OccupancyGrid.py:127-152)
 // ------------------------------------------------------------------------------------
 // Beam-major update: the reference's own formulation (:134-152 walks the cells of each beam's spoke).
@@ -2465,7 +2520,11 @@ __global__ __launch_bounds__(256) void k_grid_update(Slam2dLidar lid, const Slam
                                                            const double* __restrict__ pose, int pstride,
                                                            const double* __restrict__ ranges,
                                                            const int32_t* __restrict__ beam_shift, uint32_t* flags,
-                                                           int groups) {
+                                                           int groups, WeightsJob wj) {
+    if (wj.logw && blockIdx.x == gridDim.x - 1) {          // one extra block: the normaliser, beside the update (one launch less)
+        weights_body(wj.logw, wj.logconf, wj.cstride, wj.N, wj.w, wj.stats, wj.flags, wj.flag_snapshot, true);
+        return;
+    }
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int p = (q / groups) * 8 + xcd, g = q % groups;
     if (p >= P) return;
@@ -2593,48 +2652,6 @@ __global__ __launch_bounds__(256) void k_grid_update(Slam2dLidar lid, const Slam
         }
     }
     if (f) atomicOr(&flags[p], f);
-}
-
-// ------------------------------------------------------------------------------------
-// K4  weights                                        (Algorithm/FastSlam.py:30-48,135)
-// ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_weights(double* logw, const double* __restrict__ logconf, int cstride, int N,
-                                                 double* w, double* stats, uint32_t* flags, uint32_t* flag_snapshot) {
-    __shared__ double red[256];
-    const int tid = threadIdx.x;
-    if (flags)                                         // slam2d_scan_commit: the scan's fault bits move into the report
-        for (int i = tid; i < N; i += 256) { flag_snapshot[i] = flags[i]; flags[i] = 0u; }
-    double mx = -INFINITY;
-    for (int i = tid; i < N; i += 256) {
-        double v = logw[i] + (logconf ? logconf[(size_t)i * cstride] : 0.0);
-        logw[i] = v;
-        mx = fmax(mx, v);
-    }
-    red[tid] = mx;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] = fmax(red[tid], red[tid + o]); __syncthreads(); }
-    mx = red[0];
-    __syncthreads();
-    double s = 0.0;
-    for (int i = tid; i < N; i += 256) s += exp(logw[i] - mx);
-    red[tid] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
-    const double total = red[0];
-    __syncthreads();
-    const double lse = mx + log(total);
-    double var = 0.0;
-    for (int i = tid; i < N; i += 256) {
-        const double wi = exp(logw[i] - mx) / total;                                 // :47-48
-        w[i] = wi;
-        logw[i] = logw[i] - lse;
-        const double d = wi - 1.0 / (double)N;                                       // :34
-        var += d * d;
-    }
-    red[tid] = var;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
-    if (tid == 0) { stats[0] = red[0]; stats[1] = lse; }
 }
 
 // Sharded normaliser, rank-local half: log-weights += log-confidence, then this rank's
@@ -3033,9 +3050,8 @@ int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2
     return launch_status();
 }
 
-int slam2d_grid_update(const Slam2dLidar* lidar, const Slam2dMap* d_maps, int32_t P, const double* d_pose,
-                       int32_t pose_stride, const double* d_ranges, const int32_t* d_beam_shift, uint32_t* d_flags,
-                       void* stream) {
+static int launch_update(const Slam2dLidar* lidar, const Slam2dMap* d_maps, int32_t P, const double* d_pose, int32_t pose_stride,
+                         const double* d_ranges, const int32_t* d_beam_shift, uint32_t* d_flags, const WeightsJob& wj, void* stream) {
     if (!lidar || !d_maps || !d_pose || !d_ranges || !d_flags || P <= 0 || pose_stride < 3) return SLAM2D_E_BADARG;
     if (lidar->beams < 1 || lidar->beams > SLAM2D_MAX_BEAMS) return SLAM2D_E_TOOLARGE;
     if (!lidar->spoke_band || !lidar->spoke_cells || !lidar->spoke_r || lidar->num_bands < 1 || lidar->lut_w > 65535)
@@ -3043,9 +3059,23 @@ int slam2d_grid_update(const Slam2dLidar* lidar, const Slam2dMap* d_maps, int32_
     hipStream_t s = (hipStream_t)stream;
     const int groups = cdiv(lidar->beams, UPDB_BEAMS);
     StageScope prof(SLAM2D_STAGE_UPDATE, s);
-    k_grid_update<<<8 * cdiv(P, 8) * groups, 64 * UPDB_BEAMS, 0, s>>>(*lidar, d_maps, P, d_pose, pose_stride, d_ranges,
-                                                                           d_beam_shift, d_flags, groups);
+    k_grid_update<<<8 * cdiv(P, 8) * groups + (wj.logw ? 1 : 0), 64 * UPDB_BEAMS, 0, s>>>(*lidar, d_maps, P, d_pose, pose_stride, d_ranges,
+                                                                                         d_beam_shift, d_flags, groups, wj);
     return launch_status();
+}
+
+int slam2d_grid_update(const Slam2dLidar* lidar, const Slam2dMap* d_maps, int32_t P, const double* d_pose,
+                       int32_t pose_stride, const double* d_ranges, const int32_t* d_beam_shift, uint32_t* d_flags,
+                       void* stream) {
+    return launch_update(lidar, d_maps, P, d_pose, pose_stride, d_ranges, d_beam_shift, d_flags, WeightsJob{}, stream);
+}
+
+int slam2d_grid_update_weights(const Slam2dLidar* lidar, const Slam2dMap* d_maps, int32_t P, const double* d_pose,
+                               int32_t pose_stride, const double* d_ranges, uint32_t* d_flags, double* d_logw,
+                               const double* d_logconf, int32_t logconf_stride, double* d_w, double* d_stats, void* stream) {
+    if (!d_logw || !d_w || !d_stats || (d_logconf && logconf_stride < 1)) return SLAM2D_E_BADARG;
+    return launch_update(lidar, d_maps, P, d_pose, pose_stride, d_ranges, nullptr, d_flags,
+                         WeightsJob{d_logw, d_logconf, logconf_stride, P, d_w, d_stats, nullptr, nullptr}, stream);
 }
 
 int slam2d_prior(const double* d_prev_pose, double raw_theta, double prev_raw_theta, int32_t has_turn,
@@ -3092,11 +3122,12 @@ int slam2d_scan_commit(const Slam2dLidar* lidar, const Slam2dMap* d_maps, int32_
                        void* stream) {
     int rc = slam2d_post_match(d_fine, d_coarse, P, d_prev_pose, d_heading, d_logw, d_report, stream);
     if (rc) return rc;
-    if ((rc = slam2d_grid_update(lidar, d_maps, P, d_prev_pose, 3, d_ranges, nullptr, d_flags, stream))) return rc;
-    if (!d_w) return 0;                                // sharded filters run their own normaliser (a collective sits in it)
+    if (!d_w)                                          // sharded filters run their own normaliser (a collective sits in it)
+        return slam2d_grid_update(lidar, d_maps, P, d_prev_pose, 3, d_ranges, nullptr, d_flags, stream);
     if (!d_stats || !d_flag_snapshot) return SLAM2D_E_BADARG;
-    k_weights<<<1, 256, 0, (hipStream_t)stream>>>(d_logw, nullptr, 1, P, d_w, d_stats, d_flags, d_flag_snapshot);
-    return launch_status();
+    // the normaliser only needs the log-weights k_post_match just wrote: it rides in the update's launch
+    return launch_update(lidar, d_maps, P, d_prev_pose, 3, d_ranges, nullptr, d_flags,
+                         WeightsJob{d_logw, nullptr, 1, P, d_w, d_stats, d_flags, d_flag_snapshot}, stream);
 }
 
 int slam2d_weights_local(double* d_logw, const double* d_logconf, int32_t logconf_stride, int32_t N, double* d_part,

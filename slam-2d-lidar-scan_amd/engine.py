@@ -682,6 +682,13 @@ class ParticleEngine:
             for m in self.maps:
                 m.bits_valid = False
 
+    def grid_update_weights(self, d_pose, stride, d_ranges, d_logw, logconf_ptr, logconf_stride, d_w, d_stats):
+        """Map update + (weight *= confidence, normalise) of all particles in one launch (slam2d_grid_update_weights)."""
+        self.refresh_bits()
+        check(self.L.slam2d_grid_update_weights(C.byref(self.lidar_c), _ptr(self.d_maps), self.P, _ptr(d_pose), stride,
+                                                _ptr(d_ranges), _ptr(self.flags), _ptr(d_logw), C.c_void_p(logconf_ptr),
+                                                logconf_stride, _ptr(d_w), _ptr(d_stats), _stream()), "slam2d_grid_update_weights")
+
     def take_flags(self, fatal=_lib.FATAL_FLAGS):
         """Synchronise, fetch and clear the per-particle fault bits; raise on fatal ones."""
         f = self.flags.cpu().numpy().view(np.uint32).copy()

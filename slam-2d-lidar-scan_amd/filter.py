@@ -360,6 +360,7 @@ class ParticleFilter:
         if pending is not None:
             if finish(pending):
                 resamples.append((pending[0], self.resample()))
+        eng.take_flags()        # a bit the last update raised after its launch's snapshot (slam2d_scan_commit) is still there
         return resamples
 
     def _enqueue_match(self, reading, prev_raw, dist, has_turn, turn):
