@@ -2443,7 +2443,25 @@ __global__ __launch_bounds__(XS_THREADS) void k_exact_select(Slam2dLevel lv, con
 // after it stays in flags and is reported with the next scan instead of being lost.
 struct WeightsJob {
     double* logw; const double* logconf; int cstride; int N; double* w; double* stats; uint32_t* flags; uint32_t* flag_snapshot;
+    // slam2d_scan_commit: the same block first does the scan's bookkeeping (k_post_match's work) for all particles
+    const Slam2dMatch* fine; const Slam2dMatch* coarse; double* prev; double* heading; double* report;
 };
+// pose / heading / log-weight bookkeeping of one particle after its match (Algorithm/FastSlam.py:110-117,134-135)
+__device__ __forceinline__ void post_match_one(const Slam2dMatch* __restrict__ fine, const Slam2dMatch* __restrict__ coarse, const int p,
+                                               double* prev, double* heading, double* logw, double* report) {
+    const double x = fine[p].x, y = fine[p].y;
+    const double mx = x - prev[3 * p], my = y - prev[3 * p + 1];                    // :110-111
+    const double move = sqrt(mx * mx + my * my);
+    double h = NAN;
+    if (move != 0.0) h = my > 0.0 ? acos(mx / move) : -acos(mx / move);             // :113-117
+    heading[p] = h;
+    prev[3 * p] = x; prev[3 * p + 1] = y; prev[3 * p + 2] = fine[p].theta;          // :134
+    logw[p] += coarse[p].log_confidence;                                            // :135
+    if (report) {                                      // what the caller downloads once per scan
+        report[5 * p] = x; report[5 * p + 1] = y; report[5 * p + 2] = fine[p].theta;
+        report[5 * p + 3] = coarse[p].confidence; report[5 * p + 4] = coarse[p].log_confidence;       // :79 (coarse)
+    }
+}
 __device__ __forceinline__ void weights_body(double* logw, const double* __restrict__ logconf, const int cstride, const int N,
                                              double* w, double* stats, uint32_t* flags, uint32_t* flag_snapshot, const bool exchange) {
     __shared__ double red[256];
@@ -2521,11 +2539,18 @@ __global__ __launch_bounds__(256) void k_grid_update(Slam2dLidar lid, const Slam
                                                            const double* __restrict__ ranges,
                                                            const int32_t* __restrict__ beam_shift, uint32_t* flags,
                                                            int groups, WeightsJob wj) {
-    if (wj.logw && blockIdx.x == gridDim.x - 1) {          // one extra block: the normaliser, beside the update (one launch less)
+    if (wj.logw && blockIdx.x == 0) {                      // one extra block: the normaliser, beside the update (one launch less;
+        //                                                    block 0, so that it starts with the launch and not as its tail)
+        if (wj.fine) {                                     // ... after the scan's bookkeeping (the update blocks take their
+            for (int i = threadIdx.x; i < wj.N; i += blockDim.x)          // poses from the match buffer themselves)
+                post_match_one(wj.fine, wj.coarse, i, wj.prev, wj.heading, wj.logw, wj.report);
+            __syncthreads();
+        }
         weights_body(wj.logw, wj.logconf, wj.cstride, wj.N, wj.w, wj.stats, wj.flags, wj.flag_snapshot, true);
         return;
     }
-    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int bidx = blockIdx.x - (wj.logw ? 1 : 0);       // (a particle's blocks still share blockIdx.x % 8, i.e. their XCD)
+    const int xcd = bidx & 7, q = bidx >> 3;
     const int p = (q / groups) * 8 + xcd, g = q % groups;
     if (p >= P) return;
     const int W = lid.lut_w, S = lid.num_spokes, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -2733,19 +2758,7 @@ __global__ void k_prior(const double* __restrict__ prev, double raw_theta, doubl
 __global__ void k_post_match(const Slam2dMatch* __restrict__ fine, const Slam2dMatch* __restrict__ coarse, int P,
                              double* prev, double* heading, double* logw, double* report) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
-    const double x = fine[p].x, y = fine[p].y;
-    const double mx = x - prev[3 * p], my = y - prev[3 * p + 1];                    // :110-111
-    const double move = sqrt(mx * mx + my * my);
-    double h = NAN;
-    if (move != 0.0) h = my > 0.0 ? acos(mx / move) : -acos(mx / move);             // :113-117
-    heading[p] = h;
-    prev[3 * p] = x; prev[3 * p + 1] = y; prev[3 * p + 2] = fine[p].theta;          // :134
-    logw[p] += coarse[p].log_confidence;                                            // :135
-    if (report) {                                      // what the caller downloads once per scan
-        report[5 * p] = x; report[5 * p + 1] = y; report[5 * p + 2] = fine[p].theta;
-        report[5 * p + 3] = coarse[p].confidence; report[5 * p + 4] = coarse[p].log_confidence;       // :79 (coarse)
-    }
+    if (p < P) post_match_one(fine, coarse, p, prev, heading, logw, report);
 }
 
 // ------------------------------------------------------------------------------------
@@ -3075,7 +3088,7 @@ int slam2d_grid_update_weights(const Slam2dLidar* lidar, const Slam2dMap* d_maps
                                const double* d_logconf, int32_t logconf_stride, double* d_w, double* d_stats, void* stream) {
     if (!d_logw || !d_w || !d_stats || (d_logconf && logconf_stride < 1)) return SLAM2D_E_BADARG;
     return launch_update(lidar, d_maps, P, d_pose, pose_stride, d_ranges, nullptr, d_flags,
-                         WeightsJob{d_logw, d_logconf, logconf_stride, P, d_w, d_stats, nullptr, nullptr}, stream);
+                         WeightsJob{d_logw, d_logconf, logconf_stride, P, d_w, d_stats, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, stream);
 }
 
 int slam2d_prior(const double* d_prev_pose, double raw_theta, double prev_raw_theta, int32_t has_turn,
@@ -3120,14 +3133,19 @@ int slam2d_scan_commit(const Slam2dLidar* lidar, const Slam2dMap* d_maps, int32_
                        const Slam2dMatch* d_coarse, double* d_prev_pose, double* d_heading, double* d_logw, double* d_report,
                        const double* d_ranges, uint32_t* d_flags, double* d_w, double* d_stats, uint32_t* d_flag_snapshot,
                        void* stream) {
-    int rc = slam2d_post_match(d_fine, d_coarse, P, d_prev_pose, d_heading, d_logw, d_report, stream);
-    if (rc) return rc;
-    if (!d_w)                                          // sharded filters run their own normaliser (a collective sits in it)
+    if (!d_w) {                                        // sharded filters run their own normaliser (a collective sits in it)
+        const int rc = slam2d_post_match(d_fine, d_coarse, P, d_prev_pose, d_heading, d_logw, d_report, stream);
+        if (rc) return rc;
         return slam2d_grid_update(lidar, d_maps, P, d_prev_pose, 3, d_ranges, nullptr, d_flags, stream);
-    if (!d_stats || !d_flag_snapshot) return SLAM2D_E_BADARG;
-    // the normaliser only needs the log-weights k_post_match just wrote: it rides in the update's launch
-    return launch_update(lidar, d_maps, P, d_prev_pose, 3, d_ranges, nullptr, d_flags,
-                         WeightsJob{d_logw, nullptr, 1, P, d_w, d_stats, d_flags, d_flag_snapshot}, stream);
+    }
+    if (!d_fine || !d_coarse || !d_prev_pose || !d_heading || !d_logw || !d_stats || !d_flag_snapshot) return SLAM2D_E_BADARG;
+    // ONE launch: the update blocks read the matched poses from d_fine; one extra block does the bookkeeping
+    // (k_post_match's work) and then the normaliser, which needs nothing the update writes
+    static_assert(sizeof(Slam2dMatch) % sizeof(double) == 0, "Slam2dMatch is read as rows of doubles");
+    return launch_update(lidar, d_maps, P, reinterpret_cast<const double*>(d_fine), (int)(sizeof(Slam2dMatch) / sizeof(double)), d_ranges,
+                         nullptr, d_flags,
+                         WeightsJob{d_logw, nullptr, 1, P, d_w, d_stats, d_flags, d_flag_snapshot, d_fine, d_coarse, d_prev_pose, d_heading,
+                                    d_report}, stream);
 }
 
 int slam2d_weights_local(double* d_logw, const double* d_logconf, int32_t logconf_stride, int32_t N, double* d_part,
