@@ -10,7 +10,6 @@ VARIANTS = {
     "blur4w": [("__global__ __launch_bounds__(BLUR_THREADS) void k_blur_clamp(Slam2dLevel lv) {", "__global__ __launch_bounds__(BLUR_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_blur_clamp(Slam2dLevel lv) {")],
     "sc64": [("#define SCATTER_ROWS 32", "#define SCATTER_ROWS 64")],
     "sc16": [("#define SCATTER_ROWS 32", "#define SCATTER_ROWS 16")],
-    "ep_exactdiv": [("    if (fabs(t - rint(t)) < 1e-6 || !(fabs(t) < 1e9)) return (int)(v / step);\n    return (int)t;", "    (void)t; return (int)(v / step);")],
     "ep_nomark": [("        if (mark) {                                        // tiles of the", "        if (false) {                                       // tiles of the")],
     "ep_nohash": [("""        for (;;) {
             const int prev = atomicCAS(&hkey[h], INT_MAX, key[q]);
