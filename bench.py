@@ -159,8 +159,16 @@ class HotPath:
             (e.match if self.lazy else e.sweep)(self.fine, self.m_coarse, E.MATCH_DOUBLES, rng, float(self.dist[s]),
                                                 None, None, self.m_fine)
             final = self.m_fine
-        if self.sharded:
-            e.grid_update(final, E.MATCH_DOUBLES, rng)
+        if self.sharded:   # the rank-local half of the normaliser rides in the update's launch; collective + merge follow
+            if self.normalizer is None:
+                self.normalizer = self.par.ShardedNormalizer(self.L, E._lib.check, self.d_logw.device, self.total_particles,
+                                                             overlap=os.environ.get("SLAM2D_BENCH_OVERLAP", "0") == "1")
+                # (overlap: collective + merge on a side stream.  Bit-identical, but at one rank its events and stream
+                # switches cost the host more than the collective's latency: 0.207 vs 0.187 ms/step -- off by default)
+            if self.normalizer.overlap:
+                self.normalizer.wait()
+            e.grid_update_weights_local(final, E.MATCH_DOUBLES, rng, self.d_logw, self.m_coarse.data_ptr() + 32, E.MATCH_DOUBLES,
+                                        self.normalizer.part)
         else:       # one launch: the normaliser rides beside the update (it reads only what the match wrote)
             e.grid_update_weights(final, E.MATCH_DOUBLES, rng, self.d_logw, self.m_coarse.data_ptr() + 32, E.MATCH_DOUBLES,
                                   self.d_w, self.d_stats)         # +32: log_confidence
@@ -169,12 +177,7 @@ class HotPath:
         """weight *= confidence, then the normaliser over all particles of the job."""
         E = self.E
         if self.sharded:
-            if self.normalizer is None:
-                self.normalizer = self.par.ShardedNormalizer(self.L, E._lib.check, self.d_logw.device, self.total_particles,
-                                                             overlap=os.environ.get("SLAM2D_BENCH_OVERLAP", "0") == "1")
-                # (overlap: collective + merge on a side stream.  Bit-identical, but at one rank its events and stream
-                # switches cost the host more than the collective's latency: 0.207 vs 0.187 ms/step -- off by default)
-            self.normalizer(self.d_logw, self.m_coarse.data_ptr() + 32, E.MATCH_DOUBLES, self.d_w, self.d_stats)   # +32: log_confidence
+            self.normalizer(self.d_logw, self.m_coarse.data_ptr() + 32, E.MATCH_DOUBLES, self.d_w, self.d_stats, local_done=True)
         # (one GPU: the normaliser went out with the map update, match_and_update)
 
     def step(self, s):

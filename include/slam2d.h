@@ -354,6 +354,11 @@ int slam2d_weights_normalize(double* d_logw, const double* d_logconf, int32_t lo
 int slam2d_grid_update_weights(const Slam2dLidar* lidar, const Slam2dMap* d_maps, int32_t P, const double* d_pose,
                                int32_t pose_stride, const double* d_ranges, uint32_t* d_flags, double* d_logw,
                                const double* d_logconf, int32_t logconf_stride, double* d_w, double* d_stats, void* stream);
+/* The same for particles sharded over processes: the extra block is slam2d_weights_local (d_part[3] out); the caller's
+ * all-gather and slam2d_weights_merge follow. */
+int slam2d_grid_update_weights_local(const Slam2dLidar* lidar, const Slam2dMap* d_maps, int32_t P, const double* d_pose,
+                                     int32_t pose_stride, const double* d_ranges, uint32_t* d_flags, double* d_logw,
+                                     const double* d_logconf, int32_t logconf_stride, double* d_part, void* stream);
 
 /* One scan of Particle.update for P particles in two calls (Algorithm/FastSlam.py:122-135), so that a host loop pays two
  * library calls per scan instead of six:

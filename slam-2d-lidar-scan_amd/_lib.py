@@ -120,6 +120,7 @@ SIGNATURES = {
     "slam2d_post_match": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "slam2d_weights_normalize": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     "slam2d_grid_update_weights": (C.c_int, [C.POINTER(Slam2dLidar), _vp, C.c_int32, _vp, C.c_int32, _vp, _vp, _vp, _vp, C.c_int32, _vp, _vp, _vp]),
+    "slam2d_grid_update_weights_local": (C.c_int, [C.POINTER(Slam2dLidar), _vp, C.c_int32, _vp, C.c_int32, _vp, _vp, _vp, _vp, C.c_int32, _vp, _vp]),
     "slam2d_scan_match": (C.c_int, [C.POINTER(Slam2dLidar), C.POINTER(Slam2dLevel), C.POINTER(Slam2dLevel), _vp, C.c_int32, _vp,
                                     C.c_double, C.c_double, C.c_int32, C.c_double, _vp, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp,
                                     _vp, C.c_uint32, _vp]),

@@ -2445,6 +2445,7 @@ struct WeightsJob {
     double* logw; const double* logconf; int cstride; int N; double* w; double* stats; uint32_t* flags; uint32_t* flag_snapshot;
     // slam2d_scan_commit: the same block first does the scan's bookkeeping (k_post_match's work) for all particles
     const Slam2dMatch* fine; const Slam2dMatch* coarse; double* prev; double* heading; double* report;
+    double* part;            // sharded filters: only the rank-local half (k_weights_local's work), the collective follows
 };
 // pose / heading / log-weight bookkeeping of one particle after its match (Algorithm/FastSlam.py:110-117,134-135)
 __device__ __forceinline__ void post_match_one(const Slam2dMatch* __restrict__ fine, const Slam2dMatch* __restrict__ coarse, const int p,
@@ -2503,6 +2504,45 @@ __device__ __forceinline__ void weights_body(double* logw, const double* __restr
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
     if (tid == 0) { stats[0] = red[0]; stats[1] = lse; }
 }
+// Sharded normaliser, rank-local half: log-weights += log-confidence, then this rank's
+// [max log w, sum exp(lw - max), sum exp(2 (lw - max))].  The three doubles of every rank are
+// exchanged by ONE all-gather (24 bytes per rank) and merged by k_weights_merge.
+__device__ __forceinline__ void weights_local_body(double* logw, const double* __restrict__ logconf, const int cstride,
+                                                   const int N, double* part) {
+    __shared__ double red[256];
+    __shared__ double red2[256];
+    const int tid = threadIdx.x;
+    double mx = -INFINITY;
+    for (int i = tid; i < N; i += 256) {
+        double v = logw[i] + (logconf ? logconf[(size_t)i * cstride] : 0.0);
+        logw[i] = v;
+        mx = fmax(mx, v);
+    }
+    red[tid] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] = fmax(red[tid], red[tid + o]); __syncthreads(); }
+    mx = red[0];
+    __syncthreads();
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = tid; i < N; i += 256) {
+        const double e = exp(logw[i] - mx);
+        s1 += e;
+        s2 += e * e;
+    }
+    red[tid] = s1;
+    red2[tid] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { red[tid] += red[tid + o]; red2[tid] += red2[tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) { part[0] = mx; part[1] = red[0]; part[2] = red2[0]; }
+}
+__global__ __launch_bounds__(256) void k_weights_local(double* logw, const double* __restrict__ logconf, int cstride,
+                                                       int N, double* part) {
+    weights_local_body(logw, logconf, cstride, N, part);
+}
+
 __global__ __launch_bounds__(256) void k_weights(double* logw, const double* __restrict__ logconf, int cstride, int N,
                                                  double* w, double* stats, uint32_t* flags, uint32_t* flag_snapshot) {
     weights_body(logw, logconf, cstride, N, w, stats, flags, flag_snapshot, false);
@@ -2546,7 +2586,8 @@ __global__ __launch_bounds__(256) void k_grid_update(Slam2dLidar lid, const Slam
                 post_match_one(wj.fine, wj.coarse, i, wj.prev, wj.heading, wj.logw, wj.report);
             __syncthreads();
         }
-        weights_body(wj.logw, wj.logconf, wj.cstride, wj.N, wj.w, wj.stats, wj.flags, wj.flag_snapshot, true);
+        if (wj.part) weights_local_body(wj.logw, wj.logconf, wj.cstride, wj.N, wj.part);
+        else weights_body(wj.logw, wj.logconf, wj.cstride, wj.N, wj.w, wj.stats, wj.flags, wj.flag_snapshot, true);
         return;
     }
     const int bidx = blockIdx.x - (wj.logw ? 1 : 0);       // (a particle's blocks still share blockIdx.x % 8, i.e. their XCD)
@@ -2677,41 +2718,6 @@ __global__ __launch_bounds__(256) void k_grid_update(Slam2dLidar lid, const Slam
         }
     }
     if (f) atomicOr(&flags[p], f);
-}
-
-// Sharded normaliser, rank-local half: log-weights += log-confidence, then this rank's
-// [max log w, sum exp(lw - max), sum exp(2 (lw - max))].  The three doubles of every rank are
-// exchanged by ONE all-gather (24 bytes per rank) and merged by k_weights_merge.
-__global__ __launch_bounds__(256) void k_weights_local(double* logw, const double* __restrict__ logconf, int cstride,
-                                                       int N, double* part) {
-    __shared__ double red[256];
-    __shared__ double red2[256];
-    const int tid = threadIdx.x;
-    double mx = -INFINITY;
-    for (int i = tid; i < N; i += 256) {
-        double v = logw[i] + (logconf ? logconf[(size_t)i * cstride] : 0.0);
-        logw[i] = v;
-        mx = fmax(mx, v);
-    }
-    red[tid] = mx;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] = fmax(red[tid], red[tid + o]); __syncthreads(); }
-    mx = red[0];
-    __syncthreads();
-    double s1 = 0.0, s2 = 0.0;
-    for (int i = tid; i < N; i += 256) {
-        const double e = exp(logw[i] - mx);
-        s1 += e;
-        s2 += e * e;
-    }
-    red[tid] = s1;
-    red2[tid] = s2;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) { red[tid] += red[tid + o]; red2[tid] += red2[tid + o]; }
-        __syncthreads();
-    }
-    if (tid == 0) { part[0] = mx; part[1] = red[0]; part[2] = red2[0]; }
 }
 
 // Sharded normaliser, merge half: every rank folds the gathered [world][3] partials in rank order
@@ -3088,7 +3094,16 @@ int slam2d_grid_update_weights(const Slam2dLidar* lidar, const Slam2dMap* d_maps
                                const double* d_logconf, int32_t logconf_stride, double* d_w, double* d_stats, void* stream) {
     if (!d_logw || !d_w || !d_stats || (d_logconf && logconf_stride < 1)) return SLAM2D_E_BADARG;
     return launch_update(lidar, d_maps, P, d_pose, pose_stride, d_ranges, nullptr, d_flags,
-                         WeightsJob{d_logw, d_logconf, logconf_stride, P, d_w, d_stats, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, stream);
+                         WeightsJob{d_logw, d_logconf, logconf_stride, P, d_w, d_stats, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, stream);
+}
+
+int slam2d_grid_update_weights_local(const Slam2dLidar* lidar, const Slam2dMap* d_maps, int32_t P, const double* d_pose,
+                                     int32_t pose_stride, const double* d_ranges, uint32_t* d_flags, double* d_logw,
+                                     const double* d_logconf, int32_t logconf_stride, double* d_part, void* stream) {
+    if (!d_logw || !d_part || (d_logconf && logconf_stride < 1)) return SLAM2D_E_BADARG;
+    return launch_update(lidar, d_maps, P, d_pose, pose_stride, d_ranges, nullptr, d_flags,
+                         WeightsJob{d_logw, d_logconf, logconf_stride, P, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                    nullptr, d_part}, stream);
 }
 
 int slam2d_prior(const double* d_prev_pose, double raw_theta, double prev_raw_theta, int32_t has_turn,
@@ -3145,7 +3160,7 @@ int slam2d_scan_commit(const Slam2dLidar* lidar, const Slam2dMap* d_maps, int32_
     return launch_update(lidar, d_maps, P, reinterpret_cast<const double*>(d_fine), (int)(sizeof(Slam2dMatch) / sizeof(double)), d_ranges,
                          nullptr, d_flags,
                          WeightsJob{d_logw, nullptr, 1, P, d_w, d_stats, d_flags, d_flag_snapshot, d_fine, d_coarse, d_prev_pose, d_heading,
-                                    d_report}, stream);
+                                    d_report, nullptr}, stream);
 }
 
 int slam2d_weights_local(double* d_logw, const double* d_logconf, int32_t logconf_stride, int32_t N, double* d_part,

@@ -689,6 +689,14 @@ class ParticleEngine:
                                                 _ptr(d_ranges), _ptr(self.flags), _ptr(d_logw), C.c_void_p(logconf_ptr),
                                                 logconf_stride, _ptr(d_w), _ptr(d_stats), _stream()), "slam2d_grid_update_weights")
 
+    def grid_update_weights_local(self, d_pose, stride, d_ranges, d_logw, logconf_ptr, logconf_stride, d_part):
+        """Map update + the rank-local half of the sharded normaliser in one launch (slam2d_grid_update_weights_local);
+        the all-gather and slam2d_weights_merge follow (parallel.ShardedNormalizer(..., local_done=True))."""
+        self.refresh_bits()
+        check(self.L.slam2d_grid_update_weights_local(C.byref(self.lidar_c), _ptr(self.d_maps), self.P, _ptr(d_pose), stride,
+                                                      _ptr(d_ranges), _ptr(self.flags), _ptr(d_logw), C.c_void_p(logconf_ptr),
+                                                      logconf_stride, _ptr(d_part), _stream()), "slam2d_grid_update_weights_local")
+
     def take_flags(self, fatal=_lib.FATAL_FLAGS):
         """Synchronise, fetch and clear the per-particle fault bits; raise on fatal ones."""
         f = self.flags.cpu().numpy().view(np.uint32).copy()

@@ -101,16 +101,18 @@ class ShardedNormalizer:
         if self.overlap and self.pending:
             torch.cuda.current_stream(self.part.device).wait_event(self.ev_merged)
 
-    def __call__(self, logw, logconf_ptr, logconf_stride, w, stats):
+    def __call__(self, logw, logconf_ptr, logconf_stride, w, stats, local_done=False):
         """In place on ``logw`` (this rank's log-weights); writes ``w`` and ``stats`` =
-        [sum over all particles of (w - 1/N)^2, log of the pre-normalisation sum]."""
+        [sum over all particles of (w - 1/N)^2, log of the pre-normalisation sum].  ``local_done``: the rank-local half
+        already ran and filled ``self.part`` (slam2d_grid_update_weights_local: it rides in the map update's launch)."""
         main = torch.cuda.current_stream(logw.device)
         stream = main.cuda_stream
         n = logw.numel()
         if self.overlap:
             self.wait()                                       # logw, part: the previous scan's merge is done with them
-        self.check(self.lib.slam2d_weights_local(logw.data_ptr(), logconf_ptr, logconf_stride, n,
-                                                 self.part.data_ptr(), stream), "slam2d_weights_local")
+        if not local_done:
+            self.check(self.lib.slam2d_weights_local(logw.data_ptr(), logconf_ptr, logconf_stride, n,
+                                                     self.part.data_ptr(), stream), "slam2d_weights_local")
         if self.overlap:
             self.ev_local.record(main)
             with torch.cuda.stream(self.side):

@@ -1412,3 +1412,53 @@ def test_map_fill_gather_and_timer_entry_points(pkg):
     lib.check(L.slam2d_map_fill(C.c_void_p(dst[0].cells.data_ptr()), dst[0].rows * dst[0].pitch, lib.INIT_CELL, stream), "fill")
     v, t = dst[0].download()
     assert (v == 1).all() and (t == 2).all()
+
+
+def test_update_launch_with_the_normaliser_equals_separate_calls(pkg):
+    """slam2d_grid_update_weights / slam2d_grid_update_weights_local (the normaliser, or its rank-local half, as block 0 of
+    the map update's launch) against slam2d_grid_update followed by slam2d_weights_normalize / slam2d_weights_local:
+    maps, occupancy bits, log-weights, weights, statistics and partials bit-identical, over a few scans with carried
+    log-weights."""
+    import torch
+    synth = importlib.import_module("slam-2d-lidar-scan_amd.synth")
+    lib = E._lib
+    cfg = BNB_CASES["config2"]
+    P, unit = 7, cfg["unit"]
+    origin = (-cfg["map_m"] / 2, -cfg["map_m"] / 2)
+    L = lib.lib()
+    pfs = [_synthetic_filter(pkg, cfg, P, False)[0] for _ in range(3)]
+    world = _synthetic_filter(pkg, cfg, 1, False)[1]
+    poses = synth.random_walk(world, unit, origin, 5, seed=4, step=0.3, max_radius=6.0)
+    rs = np.random.RandomState(11)
+    st = [dict(logw=torch.full((P,), -np.log(P), dtype=torch.float64, device=pf.device),
+               w=torch.zeros(P, dtype=torch.float64, device=pf.device), stats=torch.zeros(2, dtype=torch.float64, device=pf.device),
+               part=torch.zeros(3, dtype=torch.float64, device=pf.device)) for pf in pfs]
+    for s in range(1, 5):
+        ranges = synth.raycast(world, unit, origin, poses[s], cfg["fov"], cfg["beams"], cfg["max_range"])
+        pose = np.column_stack((poses[s][0] + rs.normal(0, 0.2, P), poses[s][1] + rs.normal(0, 0.2, P), poses[s][2] + rs.normal(0, 0.05, P)))
+        conf = rs.normal(-30.0, 5.0, P)
+        for k, (pf, t) in enumerate(zip(pfs, st)):
+            eng = pf.engine
+            d_pose, d_rng, d_conf = eng.to_device(pose), eng.to_device(ranges), eng.to_device(conf)
+            if k == 0:      # separate calls; both normalisers on copies of the same log-weights
+                eng.grid_update(d_pose, 3, d_rng)
+                lw_local = t["logw"].clone()
+                lib.check(L.slam2d_weights_local(E._ptr(lw_local), E._ptr(d_conf), 1, P, E._ptr(t["part"]), E._stream()), "local")
+                lib.check(L.slam2d_weights_normalize(E._ptr(t["logw"]), E._ptr(d_conf), 1, P, E._ptr(t["w"]), E._ptr(t["stats"]),
+                                                     E._stream()), "normalize")
+                t["lw_local"] = lw_local
+            elif k == 1:
+                eng.grid_update_weights(d_pose, 3, d_rng, t["logw"], d_conf.data_ptr(), 1, t["w"], t["stats"])
+            else:
+                t["lw_before"] = t["logw"].clone()
+                eng.grid_update_weights_local(d_pose, 3, d_rng, t["logw"], d_conf.data_ptr(), 1, t["part"])
+            eng.take_flags()
+        a, b, c = st
+        assert torch.equal(a["logw"], b["logw"]) and torch.equal(a["w"], b["w"]) and torch.equal(a["stats"], b["stats"]), f"scan {s}"
+        assert torch.equal(a["part"], c["part"]) and torch.equal(a["lw_local"], c["logw"]), f"scan {s}: rank-local half"
+        c["logw"].copy_(a["logw"])                       # (the merge half is not under test: carry the normalised weights)
+        for p in range(P):
+            for other in pfs[1:]:
+                assert torch.equal(pfs[0].engine.maps[p].cells, other.engine.maps[p].cells), f"scan {s}: map {p}"
+                assert torch.equal(pfs[0].engine.maps[p].bits, other.engine.maps[p].bits), f"scan {s}: bits {p}"
+    assert abs(float(st[1]["w"].sum()) - 1.0) < 1e-12
