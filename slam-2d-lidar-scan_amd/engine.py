@@ -542,7 +542,7 @@ class SearchLevel:
         """Advance the occupancy-image generation stamp (Slam2dLevel.occ_gen) for the next build: the
         image is zeroed once per 254 builds instead of at every build."""
         g = self.c.occ_gen + 1
-        if g > 254:                  # (254, not 255: the needed-tile bitmaps alternate with the generation's parity)
+        if g > 254:
             self.t["occ"].zero_()
             g = 1
         self.c.occ_gen = g
