@@ -7,6 +7,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = open(os.path.join(REPO, "slam-2d-lidar-scan_amd/csrc/slam2d.hip")).read()
 VARIANTS = {
     "base": [],
+    "upd8": [("#define UPDB_UNROLL 4", "#define UPDB_UNROLL 8")],
+    "upd6": [("#define UPDB_UNROLL 4", "#define UPDB_UNROLL 6")],
     "blur4w": [("__global__ __launch_bounds__(BLUR_THREADS) void k_blur_clamp(Slam2dLevel lv) {", "__global__ __launch_bounds__(BLUR_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_blur_clamp(Slam2dLevel lv) {")],
     "sc64": [("#define SCATTER_ROWS 32", "#define SCATTER_ROWS 64")],
     "sc16": [("#define SCATTER_ROWS 32", "#define SCATTER_ROWS 16")],
