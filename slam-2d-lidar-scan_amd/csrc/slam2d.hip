@@ -305,6 +305,94 @@ __global__ __launch_bounds__(256) void k_occ_scatter(Slam2dLevel lv, const Slam2
     }
 }
 
+// (int)(v / step) -- truncation, as astype(int) -- without the fp64 division (~70 issue slots): v * (1/step) differs from
+// v / step by < 4e-16 relative, so the two truncate alike unless the quotient is within 1e-6 of an integer, where the exact
+// division decides.
+__device__ __forceinline__ int trunc_div(const double v, const double step, const double inv_step) {
+    const double t = v * inv_step;
+    if (fabs(t - rint(t)) < 1e-6 || !(fabs(t) < 1e9)) return (int)(v / step);
+    return (int)t;
+}
+// k_occ_scatter's work as a block role of k_endpoints' launch (slam2d_match below 512 beams, where no k_frame_axis
+// precedes it): the block derives the frame itself and evaluates the field index of its columns / rows inline (:32-37)
+// instead of reading the axis tables the frame block of the same launch is still writing.  Block (sbx, sby) of NW waves:
+// wave = 8 rows of the map window, lane = one 32-cell word.  Out-of-range indices are skipped here and flagged by the
+// frame block.
+template <int NW>
+__device__ __forceinline__ void scatter_role(const Slam2dLidar& lid, const Slam2dLevel& lv, const Slam2dMap* __restrict__ maps,
+                                             const double* __restrict__ centre, const int cstride, const int p,
+                                             const int sbx, const int sby, int32_t* ax_s) {
+    const Slam2dMap m = maps[p];
+    uint32_t fignore;
+    const Slam2dFrame fr = make_frame(lid, lv, m, centre[(size_t)p * cstride], centre[(size_t)p * cstride + 1], fignore);
+    const int nrow = fr.my1 - fr.my0;
+    if (fr.mx1 <= fr.mx0 || nrow <= 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int w0 = (fr.mx0 >> 5) + sbx * 64, wlast = (fr.mx1 - 1) >> 5;
+    if (w0 > wlast) return;
+    const int w = w0 + lane;
+    constexpr int NR = 8;
+    const int i0 = sby * (NW * NR) + wave;
+    if (sby * (NW * NR) >= nrow) return;
+    const int ncol = fr.mx1 - fr.mx0;
+    const double inv_step = 1.0 / lv.step;
+    for (int j = threadIdx.x; j < ncol; j += NW * 64) {
+        int idx = trunc_div(m.X[fr.mx0 + j] - fr.xlo, lv.step, inv_step);
+        if (idx < 0) idx += fr.fw;                         // Python negative-index wrap (:37)
+        ax_s[j] = (idx < 0 || idx >= fr.fw) ? -1 : idx;
+    }
+    uint32_t words[NR];
+    int fyk[NR];
+    int fy_lane = -1;                                      // lane k < NR evaluates the field row of the wave's k-th map row
+    if (lane < NR) {
+        const int i = i0 + NW * lane;
+        if (i < nrow) {
+            int idx = trunc_div(m.Y[fr.my0 + i] - fr.ylo, lv.step, inv_step);
+            if (idx < 0) idx += fr.fh;
+            fy_lane = (idx < 0 || idx >= fr.fh) ? -1 : idx;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int i = i0 + NW * k;
+        words[k] = (i < nrow && w <= wlast) ? m.occ_bits[(size_t)(fr.my0 + i) * m.bits_pitch + w] : 0u;
+        fyk[k] = __builtin_amdgcn_readlane(fy_lane, k);
+    }
+    __syncthreads();
+    const int col_base = w << 5;
+    uint32_t edge = ~0u;
+    if (col_base < fr.mx0) edge &= ~0u << (fr.mx0 - col_base);                    // window edges
+    if (col_base + 32 > fr.mx1) edge &= ~0u >> (col_base + 32 - fr.mx1);
+    uint8_t* occ = lv.occ + (size_t)p * lv.fmax * lv.fpitch;
+    uint8_t* tiles = lv.tilemask + (size_t)p * lv.tmax * lv.tmax;
+    const uint8_t stamp = occ_stamp(lv);
+    const int half = lane >> 5, bit = lane & 31;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const uint32_t word = words[k] & edge;
+        unsigned long long nz = __ballot(word != 0u);
+        if (!nz) continue;
+        const int fy = fyk[k];
+        while (nz) {
+            const int sa = __ffsll((long long)nz) - 1;
+            nz &= nz - 1;
+            int sb = -1;
+            if (nz) { sb = __ffsll((long long)nz) - 1; nz &= nz - 1; }
+            const uint32_t wa = (uint32_t)__builtin_amdgcn_readlane((int)word, sa), wb = sb >= 0 ? (uint32_t)__builtin_amdgcn_readlane((int)word, sb) : 0u;
+            const uint32_t wsel = half ? wb : wa;
+            const int src = half ? sb : sa;
+            if ((wsel >> bit) & 1u) {
+                const int col = ((w0 + src) << 5) + bit;
+                const int fx = ax_s[col - fr.mx0];
+                if (fx >= 0 && fy >= 0) {                                          // :36-37
+                    occ[(size_t)fy * lv.fpitch + fx] = stamp;
+                    tiles[(fy >> BLUR_SHIFT) * lv.tmax + (fx >> BLUR_SHIFT)] = stamp;
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_refresh_bits(const Slam2dMap* __restrict__ maps, const int32_t* __restrict__ index) {
     // one wave = 64 consecutive cells of a row: coalesced 256-byte read, one ballot, two words out
     const Slam2dMap m = maps[index ? index[blockIdx.y] : blockIdx.y];
@@ -920,7 +1008,7 @@ template <int NT>
 __global__ __launch_bounds__(NT) void k_endpoints(Slam2dLidar lid, Slam2dLevel lv, const double* __restrict__ est,
                                                    int estride, const double* __restrict__ ranges, uint32_t* flags,
                                                    double est_dist, const double* __restrict__ psi_cs, int mark, int prune,
-                                                   int beam_table, const Slam2dMap* __restrict__ maps) {
+                                                   int beam_table, const Slam2dMap* __restrict__ maps, int scatter_bx) {
     // maps != NULL: this launch is not preceded by k_frame_axis (slam2d_match below 512 beams): the theta blocks derive
     // the frame fields they need themselves, the priors block also writes frames[p], the axis tables and the flags.
     // np.unique (:120) through an LDS hash set: every beam inserts its cell; of the beams that hit one
@@ -940,6 +1028,11 @@ __global__ __launch_bounds__(NT) void k_endpoints(Slam2dLidar lid, Slam2dLevel l
     }
     if (grp == ngrp + 1) {                                 // a second one (only when maps != NULL): what k_frame_axis would have done
         frame_duties(lid, lv, maps, est, estride, flags, p);
+        return;
+    }
+    if (grp > ngrp + 1) {                                  // (scatter_bx > 0) the occupied-cell scatter, beside the angle blocks
+        const int sb = grp - (ngrp + 2);
+        scatter_role<NT / 64>(lid, lv, maps, est, estride, p, sb % scatter_bx, sb / scatter_bx, ep_lds);
         return;
     }
     const int it0 = grp * G, it1 = min(it0 + G, lv.ntheta);
@@ -2868,8 +2961,9 @@ static int launch_frames(const Slam2dLidar& lid, const Slam2dLevel& lv, const Sl
 }
 
 // occupied cells -> field image, tile triage (+ fill), blur + clamp, minimum check
-static void launch_field(const Slam2dLevel& lv, const Slam2dMap* d_maps, int P, uint32_t* d_flags, bool lazy, hipStream_t s) {
-    {
+static void launch_field(const Slam2dLevel& lv, const Slam2dMap* d_maps, int P, uint32_t* d_flags, bool lazy, hipStream_t s,
+                         bool scattered = false) {
+    if (!scattered) {
         StageScope prof(SLAM2D_STAGE_SCATTER, s);
         k_occ_scatter<<<dim3(cdiv(cdiv(lv.wmax, 32) + 1, 64), cdiv(lv.wmax, SCATTER_ROWS), P), dim3(64, 4), (size_t)lv.wmax * sizeof(int32_t), s>>>(lv, d_maps);
     }
@@ -2898,21 +2992,25 @@ static void launch_field(const Slam2dLevel& lv, const Slam2dMap* d_maps, int P, 
 static void launch_endpoints(const Slam2dLidar& lid, const Slam2dLevel& lv, int P, const double* d_est, int est_stride,
                              const double* d_ranges, double est_moving_dist, const double* d_psi_cs, uint32_t* d_flags,
                              bool mark, bool prune, hipStream_t s, bool beam_table = false,
-                             const Slam2dMap* own_frame_maps = nullptr) {
+                             const Slam2dMap* own_frame_maps = nullptr, bool with_scatter = false) {
     StageScope prof(SLAM2D_STAGE_ENDPOINTS, s);
     int n = 256;
     while (n < lid.beams) n <<= 1;
     int hsize = 512;
     while (hsize < lid.beams + (lid.beams >> 1)) hsize <<= 1;
-    const size_t ep_lds = (size_t)(2 * hsize + 32 + (mark ? 6 * lv.tmax * ((lv.tmax + 31) / 32) + (lv.tmax * lv.tmax + 31) / 32 : 0)) * sizeof(int);
+    size_t ep_lds = (size_t)(2 * hsize + 32 + (mark ? 6 * lv.tmax * ((lv.tmax + 31) / 32) + (lv.tmax * lv.tmax + 31) / 32 : 0)) * sizeof(int);
     const int G = lv.ep_group > 0 ? lv.ep_group : 1;
-    const dim3 grid(cdiv(lv.ntheta, G) + (own_frame_maps ? 2 : 1), P);
-    if (lid.beams <= 192)
+    const int nt = lid.beams <= 192 ? 192 : 256;
+    // with_scatter (needs own_frame_maps): the occupied-cell scatter as further blocks of this launch
+    const int sbx = with_scatter ? cdiv(cdiv(lv.wmax, 32) + 1, 64) : 0, sby = with_scatter ? cdiv(lv.wmax, (nt / 64) * 8) : 0;
+    if (with_scatter) ep_lds = ep_lds > (size_t)lv.wmax * sizeof(int32_t) ? ep_lds : (size_t)lv.wmax * sizeof(int32_t);
+    const dim3 grid(cdiv(lv.ntheta, G) + (own_frame_maps ? 2 : 1) + sbx * sby, P);
+    if (nt == 192)
         k_endpoints<192><<<grid, 192, ep_lds, s>>>(lid, lv, d_est, est_stride, d_ranges, d_flags, est_moving_dist, lv.fine ? nullptr : d_psi_cs,
-                                                   mark ? 1 : 0, prune ? 1 : 0, beam_table && lv.beam_xy ? 1 : 0, own_frame_maps);
+                                                   mark ? 1 : 0, prune ? 1 : 0, beam_table && lv.beam_xy ? 1 : 0, own_frame_maps, sbx);
     else
         k_endpoints<256><<<grid, 256, ep_lds, s>>>(lid, lv, d_est, est_stride, d_ranges, d_flags, est_moving_dist, lv.fine ? nullptr : d_psi_cs,
-                                                   mark ? 1 : 0, prune ? 1 : 0, beam_table && lv.beam_xy ? 1 : 0, own_frame_maps);
+                                                   mark ? 1 : 0, prune ? 1 : 0, beam_table && lv.beam_xy ? 1 : 0, own_frame_maps, sbx);
 }
 
 // cube sweep + selection
@@ -3039,12 +3137,15 @@ int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2
     static const bool keep_frame_kernel = [] { const char* e = getenv("SLAM2D_FRAME_KERNEL"); return e && atoi(e) == 1; }();
     const bool framed = lidar->beams >= SLAM2D_BEAM_TABLE_MIN || keep_frame_kernel || lv.occ_gen == 0;
     const Slam2dMap* own = framed ? nullptr : d_maps;
+    // ... and then the occupied-cell scatter rides in the endpoint launch as well (SLAM2D_MERGE_SCATTER=0: its own launch)
+    static const bool merge_scatter = [] { const char* e = getenv("SLAM2D_MERGE_SCATTER"); return !e || atoi(e) != 0; }();
+    const bool merged = own && merge_scatter;
     if (lv.occ_gen < 0 || lv.occ_gen > 255) return SLAM2D_E_BADARG;
     if (lv.bnb) {
         // branch and bound over 4x4 pose tiles: tile bounds + seed tiles, surviving tiles + selection
         if (framed && (rc = launch_frames(*lidar, lv, d_maps, P, d_est, est_stride, d_flags, true, s, d_ranges))) return rc;
-        launch_endpoints(*lidar, lv, P, d_est, est_stride, d_ranges, est_moving_dist, d_psi_cs, d_flags, true, false, s, framed, own);
-        launch_field(lv, d_maps, P, d_flags, true, s);
+        launch_endpoints(*lidar, lv, P, d_est, est_stride, d_ranges, est_moving_dist, d_psi_cs, d_flags, true, false, s, framed, own, merged);
+        launch_field(lv, d_maps, P, d_flags, true, s, merged);
         const unsigned grid = (unsigned)cdiv(P, 8) * 8 * lv.ntheta;
         if (lv.bnb == 2) {
             StageScope prof(SLAM2D_STAGE_BOUND, s);
@@ -3063,8 +3164,8 @@ int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2
     }
     // the endpoints need only the frame, so they run first and tell the field build which tiles matter
     if (framed && (rc = launch_frames(*lidar, lv, d_maps, P, d_est, est_stride, d_flags, true, s, d_ranges))) return rc;
-    launch_endpoints(*lidar, lv, P, d_est, est_stride, d_ranges, est_moving_dist, d_psi_cs, d_flags, true, ring_chunks > 0, s, framed, own);
-    launch_field(lv, d_maps, P, d_flags, true, s);
+    launch_endpoints(*lidar, lv, P, d_est, est_stride, d_ranges, est_moving_dist, d_psi_cs, d_flags, true, ring_chunks > 0, s, framed, own, merged);
+    launch_field(lv, d_maps, P, d_flags, true, s, merged);
     if ((rc = launch_scores(lv, P, d_est, est_stride, d_uniform, d_out, s, ring_chunks))) return rc;
     return launch_status();
 }
