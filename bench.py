@@ -12,15 +12,24 @@ inside it.
 
 Default workload = BASELINE.json configs[1] ("config2": 800x800 @ 0.1 m search field,
 36x41x41 pose cube, 180 beams) with the north-star's 64 particles per GPU.  Prints ONE JSON
-line (rank 0).  N > 1: launched by torch.distributed.run, one rank per GPU, particles
-sharded P per rank (weak scaling), value = whole-job particle-scans/s.
+line (rank 0).  The K-step timed block (barrier + synchronize on both sides) is repeated
+--repeats times; value / ms_per_step are the median block.
+N > 1: one rank per GPU, particles sharded P per rank (weak scaling), value = whole-job
+particle-scans/s.  Under a launcher (torch.distributed.run sets WORLD_SIZE) the ranks are
+taken from the environment; `python bench.py --gpus N` on its own re-executes itself under
+torch.distributed.run with N ranks.  Either way the run FAILS unless exactly N ranks joined.
+`--backend gloo --share-gpu` is a dry mode for boxes with fewer GPUs than ranks.
 """
 import argparse
 import ctypes as C
 import importlib
 import json
 import math
+import hashlib
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -52,7 +61,14 @@ WORKLOADS = {
                     note="2000x2000@0.05m map, 1081 beams over 1.5 pi, coarse 702^2/139x41x41 + fine 1403^2/139x5x5"),
 }
 WORKLOAD_PARTICLES = {"config5": 128}
-PROF_EVERY = 7     # the dominant kernel keeps a HIP event pair around every 7th of its launches inside the timed region
+PROF_EVERY_MAX = 7  # the dominant kernel keeps a HIP event pair around every n-th of its launches inside the timed region (n <= 7,
+#                     chosen so that at least ~20 launches are timed: an event pair holds the stream for ~6 us on each side)
+KERNEL_SOURCE = os.path.join(REPO, "slam-2d-lidar-scan_amd", "csrc", "slam2d.hip")
+
+
+def source_sha256():
+    with open(KERNEL_SOURCE, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
 
 
 def parse():
@@ -67,7 +83,31 @@ def parse():
                     "sweep, reference defaults, config-5 slice, config-3 closed loop)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of each CPU baseline leg")
     ap.add_argument("--cpu-workers", type=int, default=0, help="processes of the all-cores CPU baseline (0: every host core)")
+    ap.add_argument("--repeats", type=int, default=5, help="the K-step timed block is run this many times; value / ms_per_step are the "
+                    "median block (every block is bracketed by barrier + synchronize)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of a multi-rank run "
+                    "(nccl = RCCL over xGMI; gloo: dry mode, the 24-byte all-gather hops through host memory)")
+    ap.add_argument("--share-gpu", action="store_true", help="dry mode: ranks beyond the visible GPUs share them (rank r -> GPU r %% count)")
+    ap.add_argument("--spawn-check", action="store_true", help="launch plumbing only (no GPU work): every rank joins a gloo group, "
+                    "rank 0 prints the rank count it saw")
     return ap.parse_args()
+
+
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU on
+    127.0.0.1 (the form the driver itself uses for N > 1).  Returns the launcher's exit code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
 
 
 class Scenario:
@@ -320,8 +360,15 @@ GPU_CLOCK_GHZ = 2.4
 N_CU = 256
 
 
-def timed_run(hot, lib, E, first, K, stages_mask_of=None):
-    """K steps starting at scan `first`, bracketed by barrier + synchronize; returns (seconds, per-stage event timing)."""
+def _ctl(values, device):
+    """A small tensor for the control collectives (barrier timing, rank census): on the GPU for nccl, on the host for gloo."""
+    on_host = dist.is_initialized() and dist.get_backend() == "gloo"
+    return torch.tensor(values, dtype=torch.float64, device="cpu" if on_host else device)
+
+
+def timed_run(hot, first, K):
+    """K steps starting at scan `first`, bracketed by barrier + synchronize on both sides; returns (seconds = MAX over
+    ranks, this rank's own seconds)."""
     if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
@@ -329,14 +376,159 @@ def timed_run(hot, lib, E, first, K, stages_mask_of=None):
     for s in range(first, first + K):
         hot.step(s)
     torch.cuda.synchronize()
+    mine = time.perf_counter() - t0
     if dist.is_initialized():
         dist.barrier()
     el = time.perf_counter() - t0
     if dist.is_initialized():
-        t = torch.tensor([el], dtype=torch.float64, device=hot.d_logw.device)
+        t = _ctl([el], hot.d_logw.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
-    return el
+    return el, mine
+
+
+def level_stats(hot):
+    """What the last step really touched, per level (device state read back once, outside every timed region): tiles
+    blurred / filled / needed per particle, pose tiles scored exactly, mean unique endpoint cells per angle, occupied
+    field cells."""
+    out = {}
+    for name, lv in (("coarse", hot.coarse), ("fine", hot.fine)):
+        if lv is None:
+            continue
+        st = {a: float(b) for a, b in lv.bnb_stats().items()}
+        need = lv.t["tileneed"].cpu().numpy().view(np.uint32)              # [P, groups, words]
+        need = np.bitwise_or.reduce(need, axis=1)
+        st["needed_tiles"] = float(np.unpackbits(need.view(np.uint8), axis=1).sum(axis=1).mean())
+        st["kbar"] = float(lv.t["kcount"].double().mean().item())
+        P, f = lv.P, lv.fmax * lv.fpitch
+        occ = lv.t["occ"][:P * f].view(P, f)
+        st["occupied_field_cells"] = float((occ == lv.c.occ_gen).sum(dim=1).double().mean().item())
+        out[name] = st
+    return out
+
+
+def processed_bytes(hot, scen, stats):
+    """Bytes one particle-scan REALLY processes, stage by stage -- SURVEY.md 8(d)'s convention (every array once per
+    direction, real storage) applied to the parts of the arrays the lazy build and the branch and bound touch, not to the
+    whole arrays: tiles built x bytes per tile, surviving pose tiles x K x 64 B, touched cells x 8 B."""
+    lid, out = hot.lidar, {}
+    for name, lv in (("coarse", hot.coarse), ("fine", hot.fine)):
+        if lv is None:
+            continue
+        st = stats[name]
+        wm = int(2 * lv.reach / lid.unit)
+        nbt = (lv.nx + 3) // 4
+        nneed = (lv.tmax * lv.tmax + 31) // 32
+        groups = -(-lv.ntheta // lv.ep_group)
+        d = dict(
+            endpoints=8 * lid.beams + (8 if lv.bnb else 4) * lv.ntheta * st["kbar"] + 4 * groups * nneed,     # ranges in; cell lists + tile slices out
+            scatter=wm * wm // 8 + 2 * st["occupied_field_cells"],                                              # map bits in; stamped bytes + tile flags out
+            triage=2 * lv.tmax * lv.tmax + 4 * groups * nneed + 4 * (st["blur_tiles"] + st["fill_tiles"]),
+            blur=256 * (1 + 4) * st["blur_tiles"] + 256 * 4 * st["fill_tiles"],                                 # occupied image in, field out
+            check=(2 * 16 * 4) * (st["blur_tiles"] + st["fill_tiles"]) if lv.bnb else 0.0)                      # block minima in, gmin2 out
+        if lv.bnb:
+            d["bound"] = 16 * 4 * st["needed_tiles"] + 4 * lv.ntheta * st["kbar"] + 8 * lv.ntheta * nbt * 4 * ((nbt + 3) // 4)
+            d["exact"] = 64 * st["kbar"] * st.get("kept_per_particle", 0.0) + 4 * lv.ntheta * st["kbar"] + 8 * 16 * st.get("kept_per_particle", 0.0)
+        else:
+            d["sweep"] = 256 * 4 * st["needed_tiles"] + 4 * lv.ntheta * st["kbar"] + 8 * lv.ntheta * lv.nx * lv.nx
+        d["bnb"] = bool(lv.bnb)
+        out[name] = d
+    ab = hot.algorithmic_bytes(scen)["update"]
+    out["update"] = dict(per_particle=ab["per_particle"], table_per_launch=12 * ab["touched_cells"], touched_cells=ab["touched_cells"])
+    return out
+
+
+STAGE_OF_KERNEL = {"k_sweep": "sweep", "k_blur_clamp": "blur", "k_occ_scatter": "scatter", "k_bound": "bound", "k_exact": "exact",
+                   "k_endpoints": "endpoints"}
+
+
+def stage_bytes_per_launch(kernel, pb, P, launches_per_step, merged_scatter=True):
+    """Processed bytes of one launch of `kernel` (all particles): the per-level figures of the levels it serves, divided
+    over its launches of a step."""
+    if kernel == "k_grid_update":
+        return pb["update"]["per_particle"] * P + pb["update"]["table_per_launch"]
+    key = STAGE_OF_KERNEL.get(kernel)
+    if key is None:
+        return 0.0
+    tot = sum(v.get(key, 0.0) for k, v in pb.items() if k != "update")
+    if kernel == "k_endpoints" and merged_scatter:              # the occupied-cell scatter rides in this launch
+        tot += sum(v.get("scatter", 0.0) for k, v in pb.items() if k != "update")
+    return tot * P / max(launches_per_step, 1e-9)
+
+
+def step_processed_bytes(pb):
+    lev = [v for k, v in pb.items() if k != "update"]
+    return sum(sum(x for kk, x in v.items() if kk != "bnb") for v in lev) + pb["update"]["per_particle"]
+
+
+def load_traffic(workload):
+    """Per-launch HBM bytes of every kernel from the PMC passes (profiles/traffic.json, written by
+    tools/summarize_profiles.py from rocprofv3 --pmc runs of this very command).  Refused when the kernels have changed
+    since: the file records the SHA-256 of slam2d.hip it was measured on."""
+    path = os.path.join(REPO, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return {}, "profiles/traffic.json is missing"
+    doc = json.load(open(path))
+    if doc.get("source_sha256") != source_sha256():
+        return {}, "profiles/traffic.json was measured on another build of slam2d.hip (source hash differs): refused"
+    pre = workload + ":"
+    return {k[len(pre):]: v for k, v in doc.get("entries", {}).items() if k.startswith(pre)}, None
+
+
+def roofline_of(hot, scen, P, ms_per_step, stage_ms, launches_per_step_of, workload, overhead_us=0.0):
+    """The roofline block of the JSON line: dominant kernel (largest summed event time) against the HBM peak by the bytes it
+    REALLY processes, the PMC-measured traffic beside it, and the whole step both ways."""
+    stats = level_stats(hot)
+    pb = processed_bytes(hot, scen, stats)
+    traffic_all, traffic_note = load_traffic(workload)
+    out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    if stage_ms:
+        dom = max(stage_ms, key=lambda k: stage_ms[k]["total_ms"])
+        lps = launches_per_step_of.get(dom, 1.0)
+        raw_us = stage_ms[dom]["avg_us"]
+        t_us = max(raw_us - overhead_us, 1e-3)
+        proc = stage_bytes_per_launch(dom, pb, P, lps)
+        ab = hot.algorithmic_bytes(scen)
+        lev = {k: v for k, v in ab.items() if k != "update"}
+        whole_array = {"k_sweep": sum(v["sweep"] for v in lev.values() if not v["bnb"]), "k_blur_clamp": sum(v["blur"] for v in lev.values()),
+                       "k_occ_scatter": sum(v["scatter"] for v in lev.values()), "k_bound": sum(v["bound"] for v in lev.values() if v["bnb"]),
+                       "k_exact": sum(v["exact"] for v in lev.values() if v["bnb"]), "k_grid_update": ab["update"]["per_particle"]}.get(dom, 0) * P / lps
+        name = {"k_exact": "k_exact_select"}.get(dom, dom)
+        tr = (traffic_all.get(name) or {}).get("hbm_bytes_corrected")
+        achieved = proc / (t_us * 1e-6) / 1e9
+        out.update(kernel=dom, achieved=achieved, frac=achieved / HBM_PEAK_GBS, traffic=tr,
+                   measured_hbm_frac=(tr / (t_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if tr else None,
+                   wasted=(tr / proc) if tr and proc else None, traffic_note=traffic_note,
+                   processed_bytes_per_launch=proc, avg_launch_us=t_us, avg_launch_us_with_event_pair=raw_us,
+                   event_pair_overhead_us=overhead_us,
+                   whole_array_convention={"bytes_per_launch": whole_array, "frac": whole_array / (t_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                           "note": "SURVEY 8(d) whole-array bytes / the time of a kernel that touches a fraction of those arrays: "
+                                                   "evidence of work avoided, NOT a bandwidth figure"},
+                   event_pairs={"launches_timed": stage_ms[dom]["launches"], "region": "inside the timed steps, on the launch stream"})
+        cl = hot.coarse
+        kbar = stats["coarse"]["kbar"]
+        gathers = {"k_sweep": cl.ntheta * kbar * math.ceil(cl.nx * math.ceil(cl.nx / 4) / 64), "k_bound": cl.ntheta * kbar,
+                   "k_exact": stats["coarse"].get("kept_per_particle", 0.0) * math.ceil(kbar / 16)}
+        if dom in gathers:
+            ta_us = gathers[dom] * P * TA_CLK_PER_WAVE_LOAD / N_CU / (GPU_CLOCK_GHZ * 1e3)
+            out["gather"] = dict(wave_loads_per_launch=gathers[dom] * P, clk_per_wave_load=TA_CLK_PER_WAVE_LOAD, texture_path_bound_us=ta_us,
+                                 frac_of_texture_path_bound=ta_us / t_us)
+    # the whole step: processed bytes, whole-array bytes and -- when every kernel of the step has a PMC entry -- measured HBM bytes
+    step_proc = step_processed_bytes(pb)
+    ab = hot.algorithmic_bytes(scen)
+    lev = {k: v for k, v in ab.items() if k != "update"}
+    step_whole = sum(v["scatter"] + v["blur"] + (v["bound"] + v["exact"] if v["bnb"] else v["sweep"]) for v in lev.values()) + ab["update"]["per_particle"]
+    t = ms_per_step * 1e-3
+    meas = None
+    if traffic_all:
+        meas = sum(v.get("hbm_bytes_corrected", 0.0) * v.get("launches_per_step", 1.0) for k, v in traffic_all.items() if v.get("in_step"))
+    out["whole_step"] = {"processed_bytes_per_particle_scan": step_proc, "achieved": step_proc * P / t / 1e9,
+                         "frac": step_proc * P / t / 1e9 / HBM_PEAK_GBS,
+                         "measured_hbm_bytes_per_step": meas, "measured_hbm_frac": (meas / t / 1e9 / HBM_PEAK_GBS) if meas else None,
+                         "whole_array_bytes_per_particle_scan": step_whole, "whole_array_frac": step_whole * P / t / 1e9 / HBM_PEAK_GBS}
+    out["processed_bytes_per_particle_scan"] = {k: ({a: (round(b, 1) if not isinstance(b, bool) else b) for a, b in v.items()}) for k, v in pb.items()}
+    out["tile_stats"] = {k: {a: round(b, 3) for a, b in v.items()} for k, v in stats.items()}
+    return out
 
 
 def side_workload(name, P, K, W, device, rank):
@@ -344,19 +536,21 @@ def side_workload(name, P, K, W, device, rank):
     cfg = WORKLOADS[name]
     scen = Scenario(cfg, P, K + W, seed=0, rank=rank)
     hot = HotPath(cfg, P, scen, device)
-    E = hot.E
     for s in range(W):
         hot.step(s)
     hot.eng.take_flags()
-    el = timed_run(hot, hot.L, E, W, K)
-    hot.eng.take_flags()
+    blocks = []
+    for _ in range(3):
+        blocks.append(timed_run(hot, W, K)[0])
+        hot.eng.take_flags()
+    el = statistics.median(blocks)
     world = dist.get_world_size() if dist.is_initialized() else 1
-    return dict(value=P * world * K / el, unit="particle-scans/s", ms_per_step=1e3 * el / K, steps=K, particles_per_gpu=P,
+    rf = roofline_of(hot, scen, P, 1e3 * el / K, {}, {}, name)
+    return dict(value=P * world * K / el, unit="particle-scans/s", ms_per_step=1e3 * el / K, steps=K, repeats=3, particles_per_gpu=P,
                 workload=cfg["note"], pose_hypotheses_per_particle_scan=hot.coarse.ntheta * hot.coarse.nx ** 2 +
                 (hot.fine.ntheta * hot.fine.nx ** 2 if hot.fine else 0),
                 branch_and_bound={k: bool(lv.bnb) for k, lv in (("coarse", hot.coarse), ("fine", hot.fine)) if lv is not None},
-                tile_stats={k: {a: round(float(b), 4) for a, b in lv.bnb_stats().items()}
-                            for k, lv in (("coarse", hot.coarse), ("fine", hot.fine)) if lv is not None})
+                whole_step=rf["whole_step"], tile_stats=rf["tile_stats"])
 
 
 def config3_closed_loop(P, device):
@@ -389,29 +583,65 @@ def config3_closed_loop(P, device):
                      "D2H per scan; scan s is enqueued before scan s-1's results are read")
 
 
+def spawn_check(args, world, rank):
+    """Launch plumbing only (CPU): every rank joins a gloo group and adds 1; rank 0 prints what it saw."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.ones(1, dtype=torch.float64)
+        dist.all_reduce(t)
+        seen = int(t.item())
+        dist.destroy_process_group()
+    else:
+        seen = 1
+    if rank == 0:
+        print(json.dumps({"spawn_check": True, "n_gpus": world, "ranks_seen": seen, "gpus_requested": args.gpus}))
+    return 0 if seen == max(1, args.gpus) else 3
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))                 # no launcher around us: become one (one rank per GPU)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher must start exactly one rank per GPU "
+                         "(python bench.py --gpus N starts them itself)")
+    if args.spawn_check:
+        sys.exit(spawn_check(args, world, rank))
     force_dist = os.environ.get("SLAM2D_FORCE_DIST") == "1"     # exercise the sharded code path on one GPU
     cfg = WORKLOADS[args.workload]
-    P, K, W = args.particles or WORKLOAD_PARTICLES.get(args.workload, 64), args.steps, args.warmup
-    scen = Scenario(cfg, P, K + W, seed=0, rank=rank)
+    P, K, W, R = args.particles or WORKLOAD_PARTICLES.get(args.workload, 64), args.steps, args.warmup, max(1, args.repeats)
+    nprobe = min(8, K)
+    scen = Scenario(cfg, P, W + max(K, nprobe), seed=0, rank=rank)
     cpu = None
     if not args.no_cpu_baseline and world == 1 and rank == 0:
         cpu = cpu_baseline(cfg, scen, args.cpu_seconds, args.cpu_workers)      # before HIP is initialised: the pool forks
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
+    ngpu = torch.cuda.device_count()
+    if world > ngpu and not args.share_gpu:
+        raise SystemExit(f"bench.py: {world} ranks but {ngpu} visible GPU(s); --share-gpu is the dry mode that lets ranks share one")
+    dev_index = local_rank % ngpu
+    device = torch.device("cuda", dev_index)
+    torch.cuda.set_device(device)
+    ranks_seen = 1
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    assert world == max(1, args.gpus) or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        census = _ctl([1.0], device)
+        dist.all_reduce(census)                       # every rank adds one over the backend the bench will use
+        ranks_seen = int(census.item())
+        if ranks_seen != world or dist.get_world_size() != world:
+            raise SystemExit(f"bench.py: the {args.backend} group holds {ranks_seen} ranks, expected {world}")
     E = importlib.import_module("slam-2d-lidar-scan_amd.engine")
     lib = E._lib.lib()
     hot = HotPath(cfg, P, scen, device)
@@ -434,26 +664,59 @@ def main():
     flags = hot.eng.take_flags()        # synchronises; raises on any fault
     # a few bracketed steps (outside the timed region: an event pair costs ~5 us of stream time) find the dominant kernel
     E._lib.check(lib.slam2d_prof_enable(sum(1 << st for st in stages), 4 * 8 + 8), "prof_enable")
-    for s in range(W, W + min(8, K)):
+    for s in range(W, W + nprobe):
         hot.step(s)
     hot.eng.take_flags()
     probe_ms = collect()
     dom_stage = max(stages, key=lambda st: probe_ms.get(E._lib.STAGE_NAMES[st], {}).get("total_ms", 0.0))
-    # timed region: only the dominant kernel keeps its event pair
-    # ... sampled: an event pair holds the stream for ~6 us on each side of the kernel (visible as gaps in the kernel
-    # trace), so only every PROF_EVERY-th launch of the stage is bracketed (odd: a stage with one launch per level
-    # alternates between the levels)
-    nprobe = min(8, K)
     launches_per_step_of = {k: v["launches"] / nprobe for k, v in probe_ms.items()}
-    E._lib.check(lib.slam2d_prof_every(PROF_EVERY), "prof_every")
-    E._lib.check(lib.slam2d_prof_enable(1 << dom_stage, 4 * K // PROF_EVERY + 8), "prof_enable")
-    elapsed = timed_run(hot, lib, E, W, K)
-    flags = hot.eng.take_flags()
+    # what an event pair adds to a bracketed launch: the same pair with nothing in between, recorded while the stream is busy
+    timer = lib.slam2d_timer_create()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    pair = []
+    for i in range(12):
+        hot.step(W + i % nprobe)
+        lib.slam2d_timer_start(timer, stream)
+        lib.slam2d_timer_stop(timer, stream)
+        ms = C.c_float(0)
+        E._lib.check(lib.slam2d_timer_elapsed_ms(timer, C.byref(ms)), "timer")
+        pair.append(1e3 * ms.value)
+    lib.slam2d_timer_destroy(timer)
+    hot.eng.take_flags()
+    overhead_us = statistics.median(pair)
+    # timed region: R blocks of K steps, each bracketed by barrier + synchronize; only the dominant kernel keeps an event pair,
+    # and only around every n-th of its launches (an event pair holds the stream for ~6 us on each side of the kernel; odd n: a
+    # stage with one launch per level alternates between the levels)
+    dom_lps = launches_per_step_of.get(E._lib.STAGE_NAMES[dom_stage], 1.0)
+    every = int(max(1, min(PROF_EVERY_MAX, (R * K * dom_lps) // 24)))
+    if every > 1 and every % 2 == 0:
+        every -= 1
+    E._lib.check(lib.slam2d_prof_every(every), "prof_every")
+    E._lib.check(lib.slam2d_prof_enable(1 << dom_stage, int(R * K * dom_lps) // every + 16), "prof_enable")
+    blocks, mine = [], []
+    for _ in range(R):
+        el, own = timed_run(hot, W, K)
+        flags = flags | hot.eng.take_flags()
+        blocks.append(el)
+        mine.append(own)
     lib.slam2d_prof_disable()
     E._lib.check(lib.slam2d_prof_every(1), "prof_every")
     stage_ms = collect()
-    tile_stats = {k: {a: round(float(b), 4) for a, b in lv.bnb_stats().items()}
-                  for k, lv in (("coarse", hot.coarse), ("fine", hot.fine)) if lv is not None}
+    elapsed = statistics.median(blocks)
+    # N > 1: what the sharded normaliser (24-byte all-gather + merge launch) adds to a step on this rank
+    per_rank, normaliser_added_us = None, None
+    if dist.is_initialized():
+        own_ms = 1e3 * statistics.median(mine) / K
+        saved = hot.sharded
+        hot.sharded = False
+        local = statistics.median([timed_run(hot, W, K)[1] for _ in range(3)])
+        hot.sharded = saved
+        hot.eng.take_flags()
+        rec = _ctl([own_ms, 1e3 * (statistics.median(mine) - local) / K], device)
+        got = [torch.zeros_like(rec) for _ in range(world)]
+        dist.all_gather(got, rec)
+        per_rank = [float(g[0]) for g in got]
+        normaliser_added_us = [float(g[1]) for g in got]
 
     variants = {}
     if not args.no_variants and world == 1:          # (multi-GPU scaling runs: the headline only)
@@ -466,12 +729,13 @@ def main():
             for s in range(W):
                 hot.step(s)
             hot.eng.take_flags()
-            el = timed_run(hot, lib, E, W, K)
+            el = statistics.median([timed_run(hot, W, K)[0] for _ in range(3)])
             hot.eng.take_flags()
             for lv, v in saved:
                 lv.c.bnb = v
             hot.prune = False
-            return dict(value=P * world * K / el, unit="particle-scans/s", ms_per_step=1e3 * el / K, note=note)
+            return dict(value=P * world * K / el, unit="particle-scans/s", ms_per_step=1e3 * el / K, repeats=3, note=note)
+        rf_main = roofline_of(hot, scen, P, 1e3 * elapsed / K, stage_ms, launches_per_step_of, args.workload, overhead_us)
         if any(lv is not None and lv.bnb for lv in (hot.coarse, hot.fine)):
             variants["brute_force_sweep"] = variant(False, False, "every pose of the cube scored (k_sweep), the whole cube materialised "
                                                     "in HBM: the round-1 headline path")
@@ -484,44 +748,12 @@ def main():
             c3 = config3_closed_loop(64, device)
             if c3 is not None:
                 variants["config3_closed_loop"] = c3
+    else:
+        rf_main = roofline_of(hot, scen, P, 1e3 * elapsed / K, stage_ms, launches_per_step_of, args.workload, overhead_us)
 
     if rank == 0:
         total_units = P * world * K
-        ab = hot.algorithmic_bytes(scen)
-        dom = max(stage_ms, key=lambda k: stage_ms[k]["total_ms"])
-        lev = {k: v for k, v in ab.items() if k != "update"}
-        per_unit = {"k_sweep": sum(v["sweep"] for v in lev.values() if not v["bnb"]),
-                    "k_blur_clamp": sum(v["blur"] for v in lev.values()),
-                    "k_occ_scatter": sum(v["scatter"] for v in lev.values()),
-                    "k_bound": sum(v["bound"] for v in lev.values() if v["bnb"]),
-                    "k_exact": sum(v["exact"] for v in lev.values() if v["bnb"]),
-                    "k_grid_update": ab["update"]["per_particle"]}
-        launches_per_step = launches_per_step_of[dom]
-        bytes_per_launch = per_unit.get(dom, 0) * P / launches_per_step
-        if dom == "k_grid_update":
-            bytes_per_launch += ab["update"]["shared_lut"]
-        achieved = bytes_per_launch / (stage_ms[dom]["avg_us"] * 1e-6) / 1e9
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            # measured offline for the same command (tools/gpu_pmc.sh): per-launch HBM bytes, 2*FETCH_SIZE + WRITE_SIZE
-            # as MI355X_MICROARCH.md prescribes for gfx950
-            traffic = (json.load(open(tpath)).get(f"{args.workload}:{dom}") or {}).get("hbm_bytes_corrected")
-        # whole step against the memory roofline: SURVEY 8(d) bytes of every stage of one particle-scan, once per direction
-        step_bytes = sum(v["scatter"] + v["blur"] + (v["bound"] + v["exact"] if v["bnb"] else v["sweep"]) for v in lev.values()) \
-            + ab["update"]["per_particle"]
-        whole = step_bytes * P / (elapsed / K) / 1e9
-        # the gather kernels are bound by the texture path, not by bytes: wave-level load instructions x 16 clk per CU
-        cl = hot.coarse
-        kbar = float(hot.coarse.t["kcount"].double().mean().item())
-        gathers = {"k_sweep": cl.ntheta * kbar * math.ceil(cl.nx * math.ceil(cl.nx / 4) / 64),
-                   "k_bound": cl.ntheta * kbar,
-                   "k_exact": tile_stats["coarse"].get("kept_per_particle", 0.0) * math.ceil(kbar / 16)}
-        gather = None
-        if dom in gathers:
-            ta_us = gathers[dom] * P * TA_CLK_PER_WAVE_LOAD / N_CU / (GPU_CLOCK_GHZ * 1e3)
-            gather = dict(wave_loads_per_launch=gathers[dom] * P, clk_per_wave_load=TA_CLK_PER_WAVE_LOAD, texture_path_bound_us=ta_us,
-                          frac_of_texture_path_bound=ta_us / stage_ms[dom]["avg_us"])
+        rf_main.setdefault("event_pairs", {})["every"] = every
         out = {
             "metric": f"scans/sec ({cfg['beams']}-beam) x particles at fixed search volume",
             "value": total_units / elapsed, "unit": "particle-scans/s",
@@ -533,22 +765,18 @@ def main():
                        hot.coarse.ntheta * hot.coarse.nx ** 2 + (hot.fine.ntheta * hot.fine.nx ** 2 if hot.fine else 0),
                        "pose_scoring": "branch and bound over 4x4 pose tiles (exact arg-max / draw, confidence within 2e-8)"
                        if hot.coarse.bnb else "brute-force sweep",
-                       "parallelism": f"particles sharded x{world}, one 24-byte-per-rank RCCL all-gather of the weight normaliser per scan"
-                       if world > 1 else "single GPU"},
+                       "parallelism": f"particles sharded x{world}, one 24-byte-per-rank {'RCCL' if args.backend == 'nccl' else 'gloo (dry mode)'} "
+                                      "all-gather of the weight normaliser per scan" if world > 1 else "single GPU"},
             "scans_per_sec": K / elapsed,
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "avg_launch_us": stage_ms[dom]["avg_us"],
-                         "event_pairs": {"launches_timed": stage_ms[dom]["launches"], "every": PROF_EVERY,
-                                         "region": "inside the timed steps, on the launch stream"},
-                         "whole_step": {"algorithmic_bytes_per_particle_scan": step_bytes, "achieved": whole, "frac": whole / HBM_PEAK_GBS},
-                         "gather": gather},
+            "timed_blocks": {"repeats": R, "steps_each": K, "ms_per_step_of_each": [round(1e3 * b / K, 5) for b in blocks], "reported": "median"},
+            "roofline": rf_main,
             "stages_probe": {k: {"avg_us": round(v["avg_us"], 2), "launches": v["launches"]} for k, v in probe_ms.items()},
-            "algorithmic_bytes_per_particle_scan": ab,
-            "tile_stats": tile_stats,
+            "algorithmic_bytes_per_particle_scan": hot.algorithmic_bytes(scen),
             "fault_flags": int(np.bitwise_or.reduce(flags)) if len(flags) else 0,
         }
+        if dist.is_initialized():
+            out["ranks"] = {"backend": args.backend, "ranks_seen": ranks_seen, "gpus_visible": ngpu, "shared_gpu": bool(args.share_gpu and world > ngpu),
+                            "ms_per_step_per_rank": per_rank, "normaliser_added_us_per_rank": normaliser_added_us}
         if variants:
             out["variants"] = variants
         if cpu is not None:

@@ -1,0 +1,148 @@
+"""Parity of the configuration ``bench.py`` measures, AS it is measured: the bench's own ``Scenario`` and
+``HotPath`` objects (same launch sequence: lazy field build, merged endpoint / scatter launch, branch and bound,
+soft-max draw with given uniforms, map update with the normaliser in its launch) at the bench's particle counts --
+but with DISTINCT maps and estimates per particle, so that an indexing slip in the per-particle / per-XCD block
+maps (``p = (slot / bpp) * 8 + xcd``, one block per particle in the selection, the per-(particle, theta-group)
+needed-tile slices) cannot hide behind identical particles.  A spread of particles covering every ``p % 8`` class
+is compared with the CPU oracle: arg-max, drawn index, matched pose, log-confidence, the map after the update, and
+the normalised weights.  Reference contract: Utils/ScanMatcher_OGBased.py:91-151, Utils/OccupancyGrid.py:127-152,
+Algorithm/FastSlam.py:30-48.
+"""
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import slam_oracle as so
+
+pytestmark = pytest.mark.gpu
+E = importlib.import_module("slam-2d-lidar-scan_amd.engine")
+RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def bench():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import bench as b
+    return b
+
+
+def _world_variant(world, unit, w):
+    """World ``w`` of a family: the scenario's world with seeded extra box outlines and seeded erased patches, so the
+    shared scan fits every map to a different degree (variant 0 = the world the scan was cast in)."""
+    if w == 0:
+        return world
+    rs = np.random.RandomState(500 + w)
+    out = world.copy()
+    n = out.shape[0]
+    m = int(0.06 * n)
+    for _ in range(14):
+        h, ww = rs.randint(int(0.6 / unit), int(5.0 / unit)), rs.randint(int(0.6 / unit), int(5.0 / unit))
+        r0, c0 = rs.randint(m, n - m - h), rs.randint(m, n - m - ww)
+        t = 1 + w % 3
+        out[r0:r0 + t, c0:c0 + ww] = True
+        out[r0 + h - t:r0 + h, c0:c0 + ww] = True
+        out[r0:r0 + h, c0:c0 + t] = True
+        out[r0:r0 + h, c0 + ww - t:c0 + ww] = True
+    for _ in range(10):
+        h, ww = rs.randint(int(1.0 / unit), int(6.0 / unit)), rs.randint(int(1.0 / unit), int(6.0 / unit))
+        r0, c0 = rs.randint(m, n - m - h), rs.randint(m, n - m - ww)
+        out[r0:r0 + h, c0:c0 + ww] = False
+    c, k = n // 2, int(1.5 / unit)
+    out[c - k:c + k, c - k:c + k] = False
+    return out
+
+
+def _run_against_oracle(bench, workload, P, chosen, n_scans, n_worlds=8):
+    import torch
+    synth = importlib.import_module("slam-2d-lidar-scan_amd.synth")
+    cfg = bench.WORKLOADS[workload]
+    device = torch.device("cuda", 0)
+    scen = bench.Scenario(cfg, P, n_scans, seed=0)
+    hot = bench.HotPath(cfg, P, scen, device)
+    assert hot.lazy and not hot.sharded
+    u = cfg["unit"]
+    worlds = [_world_variant(scen.world, u, w) for w in range(n_worlds)]
+    world_of = [(p + p // 8) % n_worlds for p in range(P)]          # the world index is not the XCD class p % 8
+    counts = [synth.counts_from_world(w) for w in worlds]
+    for p, m in enumerate(hot.eng.maps):
+        m.upload(*counts[world_of[p]])
+    # oracle particles
+    lut = so.SpokeLUT(u, cfg["max_range"], cfg["fov"], cfg["beams"])
+    oracles = {}
+    for p in chosen:
+        og = so.GridOracle(cfg["map_m"], cfg["map_m"], {"x": 0.0, "y": 0.0}, u, cfg["fov"], cfg["beams"], cfg["max_range"],
+                           cfg["wall"], lut=lut)
+        og.visited[:], og.total[:] = counts[world_of[p]]
+        sm = so.MatcherOracle(og, cfg["search_radius"], cfg["half_rad"], cfg["sigma_cells"], cfg["move_sigma"], cfg["max_dev"],
+                              cfg["turn_sigma"], cfg["miss"], cfg["coarse_factor"])
+        oracles[p] = (og, sm)
+    logw_ref = np.zeros(P)
+    for s in range(n_scans):
+        hot.step(s)
+        flags = hot.eng.take_flags()
+        assert not (flags & E._lib.FATAL_FLAGS).any()
+        c = hot.eng.read_matches(hot.m_coarse).copy()
+        f = hot.eng.read_matches(hot.m_fine).copy() if hot.fine is not None else c
+        w_dev = hot.d_w.cpu().numpy().copy()
+        # every particle: the normaliser against NumPy on the device's own log-confidences (Algorithm/FastSlam.py:43-48)
+        logw_ref = logw_ref + c["log_confidence"]
+        logw_ref -= np.log(np.exp(logw_ref - logw_ref.max()).sum()) + logw_ref.max()
+        np.testing.assert_allclose(w_dev, np.exp(logw_ref), rtol=1e-9)
+        lc_oracle = {}
+        for p in chosen:
+            og, sm = oracles[p]
+            x, y, th = scen.est[s, p]
+            ranges, dist, psi, uni = scen.ranges[s], scen.dist[s], scen.psi[s], scen.uniform[s, p]
+            sm.trace = []
+            if cfg["levels"] == 2:
+                matched, conf = sm.matchScan({"x": x, "y": y, "theta": th, "range": ranges}, dist, psi, 2, matchMax=False, uniform=uni)
+                tr = [e for e in sm.trace if "cube" in e]
+                assert int(f["argmax"][p]) == int(tr[1]["cube"].argmax()), f"scan {s} particle {p}: fine arg-max"
+            else:
+                xr, yr, prob = sm.frameSearchSpace(x, y, u, cfg["sigma_cells"], cfg["miss"])
+                matched, _, conf = sm.searchToMatch(prob, x, y, th, ranges, xr, yr, cfg["search_radius"], cfg["half_rad"], u,
+                                                    dist, psi, fineSearch=False, matchMax=False, uniform=uni)
+                tr = [e for e in sm.trace if "cube" in e]
+            assert int(c["argmax"][p]) == int(tr[0]["cube"].argmax()), f"scan {s} particle {p}: coarse arg-max"
+            assert int(c["pick"][p]) == int(tr[0]["pick"]), f"scan {s} particle {p}: soft-max draw"
+            assert (f["x"][p], f["y"][p], f["theta"][p]) == (matched["x"], matched["y"], matched["theta"]), f"scan {s} particle {p}: pose"
+            np.testing.assert_allclose(c["log_confidence"][p], np.log(conf), rtol=1e-9, err_msg=f"scan {s} particle {p}")
+            if conf > 0:
+                np.testing.assert_allclose(c["confidence"][p], conf, rtol=RTOL)
+            lc_oracle[p] = np.log(conf)
+            og.updateOccupancyGrid(matched)
+            got_v, got_t = hot.eng.maps[p].download()
+            assert np.array_equal(got_v, og.visited) and np.array_equal(got_t, og.total), f"scan {s} particle {p}: map after the update"
+        # weight ratios of the oracle particles (the bar: 1e-5 relative)
+        p0 = chosen[0]
+        for p in chosen[1:]:
+            want = (lc_oracle[p] - lc_oracle[p0])
+            got = c["log_confidence"][p] - c["log_confidence"][p0]
+            assert abs(got - want) <= 1e-8 * max(1.0, abs(want))
+    return hot
+
+
+@pytest.mark.parametrize("variant", ["default", "two_level_bounds", "P13"])
+def test_benchmarked_config2_matches_oracle(bench, variant, monkeypatch):
+    """BASELINE config 2 as bench.py runs it (64 particles, 801^2 fields, 36 x 41 x 41 cubes, branch and bound, soft-max
+    draw), 8 distinct maps, 64 distinct estimates, two consecutive scans (first build, then the steady state with
+    persisted tile state on updated maps); 16 particles over all p % 8 classes against the oracle."""
+    P, chosen = 64, [0, 1, 2, 3, 4, 5, 6, 7, 9, 18, 27, 36, 45, 54, 62, 63]
+    if variant == "two_level_bounds":
+        monkeypatch.setenv("SLAM2D_BNB_LEVELS", "2")
+        chosen = [0, 9, 18, 27, 36, 45, 54, 63]
+    if variant == "P13":
+        P, chosen = 13, [0, 5, 7, 8, 11, 12]           # a particle count that is no multiple of 8
+    hot = _run_against_oracle(bench, "config2", P, chosen, n_scans=2)
+    assert hot.coarse.bnb and hot.coarse.bnb_levels == (2 if variant == "two_level_bounds" else 1)
+
+
+def test_benchmarked_config5_slice_matches_oracle(bench):
+    """The per-GPU slice of BASELINE config 5 as bench.py's `variants.config5` runs it: 128 particles, 2000^2 maps @ 0.05 m,
+    1081 beams, coarse 139 x 41 x 41 (two-level bounds) + fine 139 x 5 x 5; 4 distinct maps; three particles in
+    different XCD classes against the oracle (two-level matchScan, draw, update)."""
+    hot = _run_against_oracle(bench, "config5", 128, [3, 70, 125], n_scans=1, n_worlds=4)
+    assert hot.coarse.bnb and hot.coarse.bnb_levels == 2

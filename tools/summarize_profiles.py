@@ -1,70 +1,98 @@
 #!/usr/bin/env python3
-"""Turn the rocprofv3 outputs under gpurun_out/ into the small summaries committed under profiles/:
-per-kernel stats of the bench command and per-launch HBM traffic from the PMC passes
-(FETCH_SIZE / WRITE_SIZE in KB; per MI355X_MICROARCH.md FETCH_SIZE under-reports wide coalesced
-reads by 2x on gfx950, other widths uncalibrated -- both raw and corrected figures are kept)."""
+"""Turn the rocprofv3 outputs of tools/gpu_r3.sh (stages `kstat` and `pmc`) under gpurun_out/ into the small summaries
+committed under profiles/:
+
+  profiles/<round>_<workload>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of `python bench.py --workload <wl>`
+  profiles/<round>_pmc_<workload>.txt            per-launch HBM traffic of every kernel (FETCH_SIZE / WRITE_SIZE passes)
+  profiles/<round>_counters_<workload>.txt       SQ / TCP counters per launch
+  profiles/traffic.json                          what bench.py's roofline block reads: per-launch HBM bytes per kernel,
+                                                 keyed "<workload>:<kernel>", with the SHA-256 of the slam2d.hip they
+                                                 were measured on (bench.py refuses the file when the source has changed)
+
+FETCH_SIZE / WRITE_SIZE are KB counters; per MI355X_MICROARCH.md (HBM section) FETCH_SIZE reports half of the bytes of
+wide coalesced reads on gfx950, so HBM bytes = 2 * FETCH_SIZE + WRITE_SIZE (both raw figures are kept)."""
 import collections
 import csv
 import glob
+import hashlib
 import json
 import os
 import shutil
 
-ROUND = os.environ.get("ROUND", "r01")
+ROUND = os.environ.get("ROUND", "r03")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.chdir(ROOT)
 os.makedirs("profiles", exist_ok=True)
+SRC = os.path.join("slam-2d-lidar-scan_amd", "csrc", "slam2d.hip")
+sha = hashlib.sha256(open(SRC, "rb").read()).hexdigest()
+
+
+def short(name):
+    """`void k_blur_clamp<8>(Slam2dLevel)` -> ('k_blur_clamp', '<8>')."""
+    n = name.replace("void ", "").split("(")[0]
+    base = n.split("<")[0]
+    return base, n[len(base):]
+
+
 for wl in ("config2", "ref2level", "config5"):
-    src = f"gpurun_out/prof_{wl}/{wl}_kernel_stats.csv"
-    if os.path.exists(src):
-        shutil.copy(src, f"profiles/{ROUND}_{wl}_kernel_stats.csv")
-        print(f"== {src}")
-        for i, row in enumerate(csv.DictReader(open(src))):
-            if i < 12:
+    found = glob.glob(f"gpurun_out/kstat_{wl}/**/k_kernel_stats.csv", recursive=True)
+    if found:
+        shutil.copy(found[0], f"profiles/{ROUND}_{wl}_kernel_stats.csv")
+        print(f"== {found[0]}")
+        for i, row in enumerate(csv.DictReader(open(found[0]))):
+            if i < 14:
                 print(f"  {row['Name'][:60]:60s} calls {row['Calls']:>4s} avg {float(row['AverageNs']) / 1e3:9.2f} us  {row['Percentage']:>6s} %")
 
-agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob("gpurun_out/pmc_*/**/*counter_collection.csv", recursive=True):
-    for row in csv.DictReader(open(f)):
-        agg[row["Kernel_Name"].split("(")[0].replace("void ", "")][row["Counter_Name"]].append(float(row["Counter_Value"]))
-traffic, lines = {}, []
-for k, d in sorted(agg.items()):
-    if not k.startswith("k_"):
+entries = {}
+for wl in ("config2", "ref2level", "config5"):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(f"gpurun_out/pmc3/{wl}/*/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            base, targs = short(row["Kernel_Name"])
+            if base.startswith("k_"):
+                agg[(base, targs)][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    if not agg:
         continue
-    # steady state: skip the warm-up launches (first 5 steps)
-    mean = {c: sum(v[len(v) // 6:]) / max(1, len(v[len(v) // 6:])) for c, v in d.items()}
-    fetch, write = mean.get("FETCH_SIZE", 0.0) * 1024, mean.get("WRITE_SIZE", 0.0) * 1024
-    hit, miss = mean.get("TCC_HIT_sum", 0.0), mean.get("TCC_MISS_sum", 0.0)
-    name = k.split("<")[0]
-    targs = k[k.index("<") + 1:k.rindex(">")].replace(" ", "").split(",") if "<" in k else []
-    mode = (targs[1] if name == "k_sweep" and len(targs) > 1 else targs[0] if name == "k_select" and targs else "0")
-    if mode != "0":
-        name += {"1": "_ring", "2": "_rest"}.get(mode, "_" + mode)             # passes of the prior-pruned variant
-    traffic[f"config2:{name}"] = {"fetch_bytes_raw": fetch, "write_bytes_raw": write,
-                                  "hbm_bytes_corrected": 2 * fetch + write,
-                                  "l2_hit_rate": hit / (hit + miss) if hit + miss else None,
-                                  "launches_sampled": max(len(v) for v in d.values())}
-    lines.append(f"{k:24s} FETCH {fetch / 1e6:9.2f} MB  WRITE {write / 1e6:9.2f} MB  2*FETCH+WRITE {(2 * fetch + write) / 1e6:9.2f} MB"
-                 f"  L2 hit {100 * hit / (hit + miss) if hit + miss else float('nan'):5.1f} %")
-if traffic:
-    json.dump(traffic, open("profiles/traffic.json", "w"), indent=1, sort_keys=True)
-    open(f"profiles/{ROUND}_pmc_config2.txt", "w").write(
-        "rocprofv3 --pmc {FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum} --kernel-trace -- python bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-variants\n"
-        "per-launch means over the timed launches; FETCH/WRITE_SIZE are KB counters (x1024 here)\n" + "\n".join(lines) + "\n")
-    print("\n".join(lines))
+    # launches per step: relative to the map update (exactly one per step)
+    n_steps = max(len(v) for v in agg.get(("k_grid_update", ""), {"x": [0]}).values()) or 1
+    lines, extra = [], []
+    per_kernel = collections.defaultdict(lambda: dict(fetch=0.0, write=0.0, hit=0.0, miss=0.0, launches=0))
+    for (base, targs), d in sorted(agg.items()):
+        skip = {c: len(v) // 3 for c, v in d.items()}                       # steady state: drop the warm-up launches
+        mean = {c: sum(v[skip[c]:]) / max(1, len(v[skip[c]:])) for c, v in d.items()}
+        n = max(len(v) for v in d.values())
+        fetch, write = mean.get("FETCH_SIZE", 0.0) * 1024, mean.get("WRITE_SIZE", 0.0) * 1024
+        hit, miss = mean.get("TCC_HIT_sum", 0.0), mean.get("TCC_MISS_sum", 0.0)
+        lps = n / n_steps
+        k = per_kernel[base]
+        k["fetch"] += fetch * lps; k["write"] += write * lps; k["hit"] += hit * lps; k["miss"] += miss * lps; k["launches"] += n
+        lines.append(f"{base + targs:34s} launches/step {lps:5.2f}  FETCH {fetch / 1e6:9.2f} MB  WRITE {write / 1e6:9.2f} MB  2*FETCH+WRITE {(2 * fetch + write) / 1e6:9.2f} MB"
+                     f"  L2 hit {100 * hit / (hit + miss) if hit + miss else float('nan'):5.1f} %")
+        keys = [c for c in ("SQ_WAVES", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CU_CYCLES",
+                            "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCP_TOTAL_ACCESSES_sum") if c in mean]
+        if keys:
+            rd = mean.get("SQ_INSTS_VMEM_RD")
+            tail = f"  L1 lines per wave-load {mean['TCP_TOTAL_CACHE_ACCESSES_sum'] / rd:6.1f}" if rd and "TCP_TOTAL_CACHE_ACCESSES_sum" in mean else ""
+            extra.append(f"{(base + targs)[:40]:40s} " + "  ".join(f"{c} {mean[c]:.4g}" for c in keys) + tail)
+    for base, k in per_kernel.items():
+        lps = k["launches"] / n_steps
+        in_step = lps >= 0.5
+        per_launch = 1.0 / lps if lps else 0.0
+        entries[f"{wl}:{base}"] = {"fetch_bytes_raw": k["fetch"] * per_launch, "write_bytes_raw": k["write"] * per_launch,
+                                   "hbm_bytes_corrected": (2 * k["fetch"] + k["write"]) * per_launch,
+                                   "l2_hit_rate": k["hit"] / (k["hit"] + k["miss"]) if k["hit"] + k["miss"] else None,
+                                   "launches_per_step": lps, "in_step": in_step, "launches_sampled": k["launches"]}
+    step_total = sum(v["hbm_bytes_corrected"] * v["launches_per_step"] for kk, v in entries.items() if kk.startswith(wl + ":") and v["in_step"])
+    head = (f"rocprofv3 --pmc {{FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum}} --kernel-trace -- python bench.py --workload {wl} --steps 12 --warmup 6 "
+            "--repeats 1 --no-cpu-baseline --no-variants\nper-launch means after the warm-up launches; FETCH/WRITE_SIZE are KB counters (x1024 here); "
+            f"slam2d.hip sha256 {sha[:16]}\nHBM bytes of one step (all kernels of the step): {step_total / 1e6:.1f} MB\n")
+    open(f"profiles/{ROUND}_pmc_{wl}.txt", "w").write(head + "\n".join(lines) + "\n")
+    print(head + "\n".join(lines))
+    if extra:
+        open(f"profiles/{ROUND}_counters_{wl}.txt", "w").write(
+            f"rocprofv3 --pmc <SQ_* | TCP_*> --kernel-trace -- python bench.py --workload {wl} --steps 12 --warmup 6 --repeats 1 --no-cpu-baseline --no-variants\n"
+            "per-launch means after the warm-up launches (raw counter values)\n" + "\n".join(extra) + "\n")
+        print("\n".join(extra))
 
-# SQ / TCP counters of every kernel (raw per-launch means; pmc_sq and pmc_tcp passes)
-extra = []
-for k, d in sorted(agg.items()):
-    if not k.startswith("k_"):
-        continue
-    mean = {c: sum(v[len(v) // 4:]) / max(1, len(v[len(v) // 4:])) for c, v in d.items()}
-    keys = [c for c in ("SQ_WAVES", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CU_CYCLES",
-                        "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCP_TOTAL_ACCESSES_sum") if c in mean]
-    if keys:
-        rd = mean.get("SQ_INSTS_VMEM_RD")
-        tail = f"  L1 lines per wave-load {mean['TCP_TOTAL_CACHE_ACCESSES_sum'] / rd:6.1f}" if rd and "TCP_TOTAL_CACHE_ACCESSES_sum" in mean else ""
-        extra.append(f"{k[:40]:40s} " + "  ".join(f"{c} {mean[c]:.4g}" for c in keys) + tail)
-if extra:
-    open(f"profiles/{ROUND}_counters_config2.txt", "w").write(
-        "rocprofv3 --pmc <SQ_* | TCP_*> --kernel-trace -- python bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-variants\n"
-        "per-launch means after the warm-up launches (raw counter values)\n" + "\n".join(extra) + "\n")
-    print("\n".join(extra))
+if entries:
+    json.dump({"source_sha256": sha, "round": ROUND, "entries": entries}, open("profiles/traffic.json", "w"), indent=1, sort_keys=True)
