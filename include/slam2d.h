@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define SLAM2D_ABI_VERSION 9
+#define SLAM2D_ABI_VERSION 10
 #define SLAM2D_SPOKE_BAND 16         /* radial band width of the beam-major spoke table, in cells */
 
 /* library error codes (negative; positive values are hipError_t) */
@@ -67,6 +67,7 @@ extern "C" {
 #define SLAM2D_INIT_CELL 0x00010002u       /* visited = 1, total = 2 */
 #define SLAM2D_MAX_BLUR_RADIUS 16
 #define SLAM2D_MAX_BEAMS 2048
+#define SLAM2D_SYNC_WORDS 4            /* arrival counters per particle in Slam2dLevel.sync */
 
 /* One particle's map (device-resident).  X[cols] / Y[rows] are the stored cell-centre
  * coordinates (reference OccupancyGridX[0, :] / OccupancyGridY[:, 0]; rank-1 by
@@ -207,6 +208,10 @@ typedef struct {
     unsigned long long* seed_key; /* [P] best finite 8 x 8-tile bound of the particle, packed with its (theta, tile): the seed */
     double*  beam_xy;        /* [P][beams][2] scratch of slam2d_match (may be NULL): beam endpoints of the pose estimate
                                 (covertMeasureToXY, Utils/ScanMatcher_OGBased.py:81-89), evaluated once per particle */
+    uint32_t* sync;          /* [P][SLAM2D_SYNC_WORDS] arrival counters of the launches whose last-arriving block of a particle
+                                finishes the particle's work (k_exact_select split over several blocks; the tile triage as the tail of the
+                                scatter).  ZERO them once after allocation; every launch leaves them zero again.  NULL: those
+                                launches fall back to one block per particle / separate launches */
     int32_t bnb;             /* 1: slam2d_match scores this level by branch and bound; 2: with two-level bounds */
     int32_t ep_group;        /* angles per k_endpoints block (>= 1; 0 = 1): tileneed holds ceil(ntheta / ep_group) slices per particle */
     int32_t occ_gen;         /* 0: occ + tilemask are cleared at every build.  1..255: generation stamp -- an

@@ -37,6 +37,8 @@ INIT_CELL = 0x00010002
 MAX_BLUR_RADIUS = 16
 MAX_BEAMS = 2048
 SPOKE_BAND = 16
+SYNC_WORDS = 4
+ABI_VERSION = 10
 MATCH_PRUNE_BY_PRIOR = 1
 PRUNE_MARGIN = 40.0
 BNB_MARGIN = 30.0
@@ -92,7 +94,7 @@ class Slam2dLevel(C.Structure):
                 ("ring", _vp), ("prune_state", _vp), ("ring_cap", C.c_int32),
                 ("gmin", _vp), ("gmin2", _vp), ("pcells", _vp), ("bounds", _vp), ("tile_pmax", _vp), ("bnb_best", _vp),
                 ("gmin3d", _vp), ("p3cells", _vp), ("bounds1", _vp), ("seed_key", _vp),
-                ("beam_xy", _vp), ("bnb", C.c_int32), ("ep_group", C.c_int32), ("occ_gen", C.c_int32)]
+                ("beam_xy", _vp), ("sync", _vp), ("bnb", C.c_int32), ("ep_group", C.c_int32), ("occ_gen", C.c_int32)]
 
 
 class Slam2dMatch(C.Structure):
@@ -183,6 +185,8 @@ def lib():
         fn = getattr(L, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    if L.slam2d_abi_version() != ABI_VERSION:
+        raise Slam2dError(f"{LIB_PATH} has ABI version {L.slam2d_abi_version()}, the binding expects {ABI_VERSION}: rebuild it")
     for name, st in STRUCTS.items():
         n = L.slam2d_sizeof(name.encode())
         if n != C.sizeof(st):

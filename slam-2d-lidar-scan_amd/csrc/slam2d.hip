@@ -2242,9 +2242,29 @@ __global__ __launch_bounds__(64) void k_bound2(Slam2dLevel lv, int P) {
 #define XS_TILES 256
 #define XS_MAX_PER 32
 #define XS_CELLS 8192                // cell-list entries staged in LDS (ntheta * kmax: config 2 6480, reference 5400)
+#define XS_SPLIT_MAX 8
 #define SLAM2D_BNB_MAX_THETA 256
+// SPLIT: nsplit blocks per particle (all of them on the particle's XCD, for the field's sake).  Every block scans the
+// particle's bounds (the same list comes out everywhere) and scores its share of the surviving tiles -- with one block
+// per particle 64 of the 256 CUs worked and the particle with the most tiles (93 against a median of 27 at config 2) set
+// the kernel's time.  The scores go to level->cube with write-through (sc1) stores; every wave drains its stores, the
+// block takes a ticket from the particle's arrival counter (lv.sync: zero before the launch, put back to zero by the
+// last arriver), and the block that draws the last ticket runs the rest -- maximum, exp, per-theta sums, selection -- over
+// ALL the particle's tiles, reading the scores back with sc1 loads (MI355X_MICROARCH.md, "Inter-workgroup visibility":
+// sc1 stores + a vmcnt(0) drain per storing wave + a relaxed agent-scope counter on the producer side, sc1 loads on the
+// consumer side; nothing depends on where the blocks run).  The arithmetic of those stages and its order are the same
+// as with one block, so the results are bit-identical whatever nsplit is.
+__device__ __forceinline__ void store_score(double* dst, const double v, const bool through) {
+    if (through) __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *dst = v;
+}
+__device__ __forceinline__ double load_score(const double* src, const bool through) {
+    if (through) return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    return *src;
+}
+template <bool SPLIT>
 __global__ __launch_bounds__(XS_THREADS) void k_exact_select(Slam2dLevel lv, const double* __restrict__ est, int estride,
-                                                             const double* __restrict__ uniform, Slam2dMatch* out) {
+                                                             const double* __restrict__ uniform, Slam2dMatch* out, int P, int nsplit) {
     __shared__ int list_s[XS_TILES];                   // theta << 8 | tile, ascending
     __shared__ double sc_s[XS_TILES][16];              // a tile's scores (row-major 4 x 4, -inf = no pose), then exp(score - M)
     __shared__ double tsum_s[XS_TILES], tmax_s[XS_TILES];
@@ -2257,7 +2277,14 @@ __global__ __launch_bounds__(XS_THREADS) void k_exact_select(Slam2dLevel lv, con
     __shared__ int wbi_s[XS_THREADS / WAVE], wbn_s[XS_THREADS / WAVE];
     __shared__ double M_s[2];                          // [0] running maximum, [1] the one before this pass
     __shared__ int Mi_s[2];                            // its flat index, nan flag
-    const int p = blockIdx.x, tid = threadIdx.x;
+    __shared__ int last_s;
+    const int tid = threadIdx.x;
+    int p = blockIdx.x, part = 0;
+    if constexpr (SPLIT) {                             // block b runs on XCD b % 8: a particle's blocks share that XCD's L2
+        const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+        p = (slot / nsplit) * 8 + xcd; part = slot % nsplit;
+        if (p >= P) return;
+    }
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int nx = 2 * lv.ncell + 1, npose = nx * nx;
     const int nbt = (nx + 3) >> 2, nbq4 = ((nbt + 3) >> 2) << 2, nt = nbt * nbq4;
@@ -2273,7 +2300,8 @@ __global__ __launch_bounds__(XS_THREADS) void k_exact_select(Slam2dLevel lv, con
         const int g = g0 + i;
         if (g < ntot && bnd[g] >= thr) keepbits |= 1u << i;        // (padding tiles hold -inf)
     }
-    const bool cells_in_lds = lv.ntheta * lv.kmax <= XS_CELLS;
+    // (a block that scores a quarter of the tiles reads the few lists it needs from global memory instead of staging them all)
+    const bool cells_in_lds = !SPLIT && lv.ntheta * lv.kmax <= XS_CELLS;
     if (cells_in_lds) {
         const int* __restrict__ call = lv.cells + (size_t)p * lv.ntheta * lv.kmax;
         for (int i = tid; i < lv.ntheta * lv.kmax; i += XS_THREADS) cells_s[i] = call[i];
@@ -2297,22 +2325,19 @@ __global__ __launch_bounds__(XS_THREADS) void k_exact_select(Slam2dLevel lv, con
         (void*)(lv.field + (size_t)p * image), (short)0, (int)(image * sizeof(uint32_t)), 0x00020000);
     const double* __restrict__ pr = lv.prior + (size_t)p * 2 * npose;
     const double inv = 1.0 / lv.cost_scale;
-    int n = 0;
-    for (int base = 0; base < n_all; base += XS_TILES) {           // (block-uniform)
-        n = min(XS_TILES, n_all - base);
-        {
-            int o = off;
-            for (int i = 0; i < per; ++i)
-                if ((keepbits >> i) & 1u) {
-                    if (o >= base && o < base + XS_TILES) { const int g = g0 + i; list_s[o - base] = ((g / nt) << 8) | (g % nt); }
-                    ++o;
-                }
-        }
-        if (tid < lv.ntheta) jn_s[tid] = 0;
-        __syncthreads();
-        DBG_CLOCK(10, p == 0 && base == 0);
-        // ---- tiles ----
-        for (int j = wave; j < n; j += XS_THREADS / WAVE) {
+    // the pass's list: surviving tiles [base, base + XS_TILES) in ascending (theta, tile) order
+    auto build_list = [&](const int base) {
+        int o = off;
+        for (int i = 0; i < per; ++i)
+            if ((keepbits >> i) & 1u) {
+                if (o >= base && o < base + XS_TILES) { const int g = g0 + i; list_s[o - base] = ((g / nt) << 8) | (g % nt); }
+                ++o;
+            }
+    };
+    // exact scores of the pass's tiles j = first, first + stride, ... (one tile per wave at a time): lane = pose row x 1/16
+    // of the cell list, 16-byte field loads, DPP row sums; 16 lanes add the priors and store the scores
+    auto score_tiles = [&](const int n, const int first, const int stride) {
+        for (int j = first; j < n; j += stride) {
             const int ent = list_s[j];
             const int it = ent >> 8, t = ent & 255;
             const int by = t / nbq4, bx = t - by * nbq4;
@@ -2341,25 +2366,87 @@ __global__ __launch_bounds__(XS_THREADS) void k_exact_select(Slam2dLevel lv, con
                 const unsigned long long a = e == 0 ? acc[0] : e == 1 ? acc[1] : e == 2 ? acc[2] : acc[3];
                 if (scorer) {
                     sc = (-((double)a * inv) + prv) + ptw;                                    // :131, as k_sweep
-                    lv.cube[((size_t)p * lv.ntheta + it) * npose + qq] = sc;
+                    store_score(&lv.cube[((size_t)p * lv.ntheta + it) * npose + qq], sc, SPLIT);
                 }
-                sc_s[j][r * 4 + e] = sc;
+                if constexpr (!SPLIT) sc_s[j][r * 4 + e] = sc;
             }
-            // the tile's maximum in np.argmax order (first NaN, else largest, lowest index): the scoring lanes 16 r + e
-            // ascend with the flat pose index, so "lowest index" = lowest lane.  Quad butterflies, then the four rows.
-            double mq = scorer && !isnan(sc) ? sc : -INFINITY;
-            mq = fmax(mq, __longlong_as_double((long long)dpp_u64<0xB1>((unsigned long long)__double_as_longlong(mq))));
-            mq = fmax(mq, __longlong_as_double((long long)dpp_u64<0x4E>((unsigned long long)__double_as_longlong(mq))));
-            const double tmx = fmax(fmax(readlane_f64(mq, 0), readlane_f64(mq, 16)), fmax(readlane_f64(mq, 32), readlane_f64(mq, 48)));
-            const unsigned long long nanm = __ballot(scorer && isnan(sc));
-            const unsigned long long eqm = nanm ? nanm : __ballot(scorer && sc == tmx);
-            if (lane == 0) {
-                int arg = INT_MAX;
-                if (eqm) {
-                    const int l = __ffsll((long long)eqm) - 1;
-                    arg = it * npose + (4 * by + (l >> 4)) * nx + 4 * bx + (l & 15);
+            if constexpr (!SPLIT) {
+                // the tile's maximum in np.argmax order (first NaN, else largest, lowest index): the scoring lanes 16 r + e
+                // ascend with the flat pose index, so "lowest index" = lowest lane.  Quad butterflies, then the four rows.
+                double mq = scorer && !isnan(sc) ? sc : -INFINITY;
+                mq = fmax(mq, __longlong_as_double((long long)dpp_u64<0xB1>((unsigned long long)__double_as_longlong(mq))));
+                mq = fmax(mq, __longlong_as_double((long long)dpp_u64<0x4E>((unsigned long long)__double_as_longlong(mq))));
+                const double tmx = fmax(fmax(readlane_f64(mq, 0), readlane_f64(mq, 16)), fmax(readlane_f64(mq, 32), readlane_f64(mq, 48)));
+                const unsigned long long nanm = __ballot(scorer && isnan(sc));
+                const unsigned long long eqm = nanm ? nanm : __ballot(scorer && sc == tmx);
+                if (lane == 0) {
+                    int arg = INT_MAX;
+                    if (eqm) {
+                        const int l = __ffsll((long long)eqm) - 1;
+                        arg = it * npose + (4 * by + (l >> 4)) * nx + 4 * bx + (l & 15);
+                    }
+                    tmax_s[j] = nanm ? NAN : tmx; targ_s[j] = arg; tnan_s[j] = nanm ? 1 : 0;
                 }
-                tmax_s[j] = nanm ? NAN : tmx; targ_s[j] = arg; tnan_s[j] = nanm ? 1 : 0;
+            }
+        }
+    };
+    if constexpr (SPLIT) {
+        // ---- this block's share of the tiles, all passes; then the ticket ----
+        for (int base = 0; base < n_all; base += XS_TILES) {           // (block-uniform)
+            build_list(base);
+            __syncthreads();
+            score_tiles(min(XS_TILES, n_all - base), part + nsplit * wave, nsplit * (XS_THREADS / WAVE));
+            __syncthreads();                                           // list_s is rebuilt by the next pass / the tail
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // every storing wave drains its write-through stores
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned ticket = __hip_atomic_fetch_add(&lv.sync[p * SLAM2D_SYNC_WORDS], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = ticket == (unsigned)(nsplit - 1);
+            if (last) __hip_atomic_store(&lv.sync[p * SLAM2D_SYNC_WORDS], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            last_s = last;
+        }
+        __syncthreads();
+        if (!last_s) return;
+    }
+    int n = 0;
+    for (int base = 0; base < n_all; base += XS_TILES) {           // (block-uniform)
+        n = min(XS_TILES, n_all - base);
+        build_list(base);
+        if (tid < lv.ntheta) jn_s[tid] = 0;
+        __syncthreads();
+        DBG_CLOCK(10, p == 0 && base == 0);
+        // ---- tiles ----
+        if constexpr (!SPLIT) {
+            score_tiles(n, wave, XS_THREADS / WAVE);
+        } else {
+            // every tile of the pass back from the cube (sc1 loads: the stores were write-through), then the tiles' maxima
+            for (int i0 = 0; i0 < n * 16; i0 += XS_THREADS) {
+                const int idx = i0 + tid;
+                if (idx < n * 16) {
+                    const int ent = list_s[idx >> 4], it = ent >> 8, t = ent & 255;
+                    const int by = t / nbq4, bx = t - by * nbq4;
+                    const int dy = 4 * by + ((idx >> 2) & 3), dx = 4 * bx + (idx & 3);
+                    double sc = -INFINITY;
+                    if (dy < nx && dx < nx) sc = load_score(&lv.cube[((size_t)p * lv.ntheta + it) * npose + dy * nx + dx], true);
+                    sc_s[idx >> 4][idx & 15] = sc;
+                }
+            }
+            __syncthreads();
+            if (tid < n) {                                  // np.argmax order inside the tile: first NaN, else largest, lowest index
+                const int ent = list_s[tid], it = ent >> 8, t = ent & 255;
+                const int by = t / nbq4, bx = t - by * nbq4;
+                double tmx = -INFINITY;
+                int arg = INT_MAX, nan = 0;
+                for (int i = 0; i < 16; ++i) {
+                    const int dy = 4 * by + (i >> 2), dx = 4 * bx + (i & 3);
+                    if (dy >= nx || dx >= nx) continue;
+                    const double sc = sc_s[tid][i];
+                    const int q = it * npose + dy * nx + dx;
+                    if (isnan(sc)) { if (!nan) { nan = 1; arg = q; } }
+                    else if (!nan && (arg == INT_MAX || sc > tmx)) { tmx = sc; arg = q; }
+                }
+                tmax_s[tid] = nan ? NAN : tmx; targ_s[tid] = arg; tnan_s[tid] = nan;
             }
         }
         __syncthreads();
@@ -2466,7 +2553,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_exact_select(Slam2dLevel lv, con
                 for (int bx = 0; bx < nbt; ++bx)
                     if (bt[by * nbq4 + bx] >= thr) {
                         has = true;
-                        for (int e = 0; e < 4 && 4 * bx + e < nx; ++e) lsum += exp(c[lane * nx + 4 * bx + e] - M);
+                        for (int e = 0; e < 4 && 4 * bx + e < nx; ++e) lsum += exp(load_score(&c[lane * nx + 4 * bx + e], SPLIT) - M);
                     }
         }
         double linc = lsum;
@@ -2501,7 +2588,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_exact_select(Slam2dLevel lv, con
                         if (bt[by * nbq4 + bx] >= thr)
                             for (int e = 0; e < 4 && 4 * bx + e < nx; ++e) {
                                 last = it * npose + lane * nx + 4 * bx + e;
-                                r2 += exp(c[lane * nx + 4 * bx + e] - M);
+                                r2 += exp(load_score(&c[lane * nx + 4 * bx + e], SPLIT) - M);
                                 if (r2 > target) { found = last; break; }
                             }
                 }
@@ -3086,6 +3173,17 @@ static int ring_slot_bound(const Slam2dLevel& lv, double est_dist) {
     return n <= lv.ring_cap ? n : 0;
 }
 
+// Blocks per particle of k_exact_select: enough to put every CU to work (256 CUs / P particles), at most 4; needs the
+// arrival counters (Slam2dLevel.sync).  SLAM2D_XS_SPLIT overrides (1 = one block per particle).
+static int exact_split(const Slam2dLevel& lv, int P) {
+    static const int forced = [] { const char* e = getenv("SLAM2D_XS_SPLIT"); return e ? atoi(e) : 0; }();
+    if (!lv.sync) return 1;
+    int n = forced > 0 ? forced : 256 / (P > 0 ? P : 1);
+    if (forced <= 0 && n > 4) n = 4;
+    if (n > XS_SPLIT_MAX) n = XS_SPLIT_MAX;
+    return n < 1 ? 1 : n;
+}
+
 int slam2d_field_build(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2dMap* d_maps, int32_t P,
                        const double* d_centre, int32_t centre_stride, uint32_t* d_flags, void* stream) {
     int rc = check_level(lidar, level, P);
@@ -3158,7 +3256,9 @@ int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2
         }
         {
             StageScope prof(SLAM2D_STAGE_EXACT, s);
-            k_exact_select<<<P, XS_THREADS, 0, s>>>(lv, d_est, est_stride, d_uniform, d_out);
+            const int nsplit = exact_split(lv, P);
+            if (nsplit > 1) k_exact_select<true><<<(unsigned)cdiv(P, 8) * 8 * nsplit, XS_THREADS, 0, s>>>(lv, d_est, est_stride, d_uniform, d_out, P, nsplit);
+            else k_exact_select<false><<<P, XS_THREADS, 0, s>>>(lv, d_est, est_stride, d_uniform, d_out, P, 1);
         }
         return launch_status();
     }

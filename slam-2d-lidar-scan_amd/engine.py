@@ -503,6 +503,7 @@ class SearchLevel:
             ring=torch.zeros(1 + self.nx * ((self.nx + 3) // 4), dtype=i32, device=device),
             prune_state=torch.zeros(P, dtype=i32, device=device),
             beam_xy=torch.zeros((P, lidar.beams, 2), dtype=f64, device=device),
+            sync=torch.zeros((P, _lib.SYNC_WORDS), dtype=i32, device=device),       # arrival counters (zero between launches)
         )
         if self.bnb:        # branch and bound over 4x4 pose tiles (include/slam2d.h)
             t.update(
@@ -535,6 +536,7 @@ class SearchLevel:
             tilecount=t["tilecount"].data_ptr(),
             tileneed=t["tileneed"].data_ptr(), freerow=t["freerow"].data_ptr(), ring=t["ring"].data_ptr(), prune_state=t["prune_state"].data_ptr(),
             ring_cap=self.nx * ((self.nx + 3) // 4), bnb=self.bnb_levels, ep_group=self.ep_group, beam_xy=t["beam_xy"].data_ptr(),
+            sync=t["sync"].data_ptr(),
             **({k: t[k].data_ptr() for k in ("gmin3d", "p3cells", "bounds1", "seed_key")} if self.bnb_levels == 2 else {}),
             **({k: t[k].data_ptr() for k in ("gmin", "gmin2", "pcells", "bounds", "tile_pmax", "bnb_best")} if self.bnb else {}))
 

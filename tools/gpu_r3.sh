@@ -59,6 +59,23 @@ pmc)
     done
   done
   ROUND=r03 python tools/summarize_profiles.py > gpurun_out/profile_summary.txt 2>&1; tail -n 60 gpurun_out/profile_summary.txt | cut -c1-260 ;;
+bnbtests)
+  timeout 1200 python -m pytest tests -m gpu -q -x -p no:cacheprovider -k "branch_and_bound or benchmarked or config5 or synthetic_shapes or particle_counts" > gpurun_out/pytest_bnb.log 2>&1
+  echo "bnbtests rc=$?"; tail -n 15 gpurun_out/pytest_bnb.log | cut -c1-400 ;;
+ab)
+  # A/B of environment switches: AB="NAME=VAL,NAME2=VAL2;NAME=VAL3;-" (";"-separated settings, "-" = defaults), AB_WL = workloads
+  IFS=';' read -ra SETS <<< "${AB:--}"
+  for WL in ${AB_WL:-config2}; do
+    for SET in "${SETS[@]}"; do
+      ENVS=$(echo "$SET" | tr ',' ' '); [ "$SET" = "-" ] && ENVS=""
+      env $ENVS python bench.py --workload $WL --steps ${AB_STEPS:-60} --warmup 8 --repeats 3 --no-cpu-baseline --no-variants 2>/dev/null | python -c "
+import sys, json
+for line in sys.stdin:
+    if line.startswith('{'):
+        d = json.loads(line); print('$WL [$SET]', round(d['value']), 'ms/step', round(d['ms_per_step'], 4), d['timed_blocks']['ms_per_step_of_each'], {k: v['avg_us'] for k, v in d['stages_probe'].items()}, 'flags', d['fault_flags'])
+"
+    done
+  done ;;
 *) echo "unknown stage $ST" ;;
 esac
 done
