@@ -407,6 +407,15 @@ int slam2d_gather_maps(const Slam2dMap* d_src, const Slam2dMap* d_dst, const int
  * Needed after the caller wrote `cells` itself (upload, growth copy, resample copy). */
 int slam2d_map_refresh_bits(const Slam2dMap* d_maps, const int32_t* d_index, int32_t n, void* stream);
 
+/* The picture of particle p's map that the reference's driver draws per scan (Algorithm/FastSlam.py:172-177:
+ * `ogMap = visited / total; ogMap = ogMap[y0:y1, x0:x1]; np.flipud(1 - ogMap)`), straight from the device state:
+ *   d_out[i][j]    (float64, may be NULL) = 1 - visited / total of map cell (row, x0 + j), row = y0 + i, or -- flipud != 0 --
+ *                  y1 - 1 - i; the window [y0, y1) x [x0, x1) must lie inside the map (the caller resolves Python's slice
+ *                  clipping, as convertRealXYToMapIdx + slicing do there);
+ *   d_out_u8[i][j] (may be NULL) the same as 8-bit grey, rint(255 * value). */
+int slam2d_map_image(const Slam2dMap* d_maps, int32_t p, int32_t x0, int32_t x1, int32_t y0, int32_t y1, int32_t flipud,
+                     double* d_out, uint8_t* d_out_u8, void* stream);
+
 /* Fill a map with SLAM2D_INIT_CELL (np.ones / 2*np.ones, Utils/OccupancyGrid.py:13-14). */
 int slam2d_map_fill(uint32_t* d_cells, int64_t n, uint32_t value, void* stream);
 

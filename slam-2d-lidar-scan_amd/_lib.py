@@ -131,6 +131,7 @@ SIGNATURES = {
     "slam2d_weights_local": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _vp, _vp]),
     "slam2d_weights_merge": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, C.c_int64, _vp, _vp, _vp]),
     "slam2d_gather_maps": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int64, _vp]),
+    "slam2d_map_image": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     "slam2d_map_fill": (C.c_int, [_vp, C.c_int64, C.c_uint32, _vp]),
     "slam2d_map_refresh_bits": (C.c_int, [_vp, _vp, C.c_int32, _vp]),
     "slam2d_device_sincos": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp]),

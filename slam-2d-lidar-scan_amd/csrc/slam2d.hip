@@ -771,8 +771,11 @@ __global__ __launch_bounds__(TRIAGE_THREADS) void k_tile_triage(Slam2dLevel lv, 
 
 
 // Blur of the work list: gridDim.x one-wave blocks per particle walk that particle's active tiles.
+#ifndef BLUR_MIN_WAVES
+#define BLUR_MIN_WAVES 1
+#endif
 template <int RAD>
-__global__ __launch_bounds__(BLUR_THREADS) void k_blur_clamp(Slam2dLevel lv) {
+__global__ __launch_bounds__(BLUR_THREADS, BLUR_MIN_WAVES) void k_blur_clamp(Slam2dLevel lv) {
     __shared__ BlurLds<RAD> sm;
     const int p = blockIdx.y;
     const int n = lv.tilecount[2 * p];
@@ -2754,7 +2757,10 @@ __device__ __forceinline__ int rint_div(const double v, const double unit, const
 #ifndef UPDB_UNROLL
 #define UPDB_UNROLL 4
 #endif
-__global__ __launch_bounds__(256) void k_grid_update(Slam2dLidar lid, const Slam2dMap* __restrict__ maps, int P,
+#ifndef UPDB_MIN_WAVES
+#define UPDB_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(256, UPDB_MIN_WAVES) void k_grid_update(Slam2dLidar lid, const Slam2dMap* __restrict__ maps, int P,
                                                            const double* __restrict__ pose, int pstride,
                                                            const double* __restrict__ ranges,
                                                            const int32_t* __restrict__ beam_shift, uint32_t* flags,
@@ -2957,6 +2963,22 @@ __global__ void k_gather_maps(const Slam2dMap* __restrict__ src, const Slam2dMap
     const size_t n = (size_t)s.rows * s.pitch;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         d.cells[i] = s.cells[i];
+}
+
+// The picture of a map the reference draws (Algorithm/FastSlam.py:172-176): 1 - visited / total over a window, optionally
+// flipped upside down (np.flipud); float64 like the reference's arrays and / or 8-bit grey.
+__global__ void k_map_image(const Slam2dMap* __restrict__ maps, int p, int x0, int y0, int w, int h, int flipud,
+                            double* out, uint8_t* out_u8) {
+    const Slam2dMap m = maps[p];
+    const long long n = (long long)w * h;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / w), c = (int)(i - (long long)r * w);
+        const int my = flipud ? y0 + (h - 1 - r) : y0 + r;
+        const uint32_t v = m.cells[(size_t)my * m.pitch + x0 + c];
+        const double val = 1.0 - (double)(v >> 16) / (double)(v & 0xffffu);     // ogMap = visited / total; 1 - ogMap (:173,176)
+        if (out) out[i] = val;
+        if (out_u8) out_u8[i] = (uint8_t)rint(fmin(fmax(val, 0.0), 1.0) * 255.0);
+    }
 }
 
 __global__ void k_fill(uint32_t* cells, long long n, uint32_t value) {
@@ -3389,6 +3411,16 @@ int slam2d_gather_maps(const Slam2dMap* d_src, const Slam2dMap* d_dst, const int
 int slam2d_map_refresh_bits(const Slam2dMap* d_maps, const int32_t* d_index, int32_t n, void* stream) {
     if (!d_maps || n <= 0) return SLAM2D_E_BADARG;
     k_refresh_bits<<<dim3(1024, n), 256, 0, (hipStream_t)stream>>>(d_maps, d_index);
+    return launch_status();
+}
+
+int slam2d_map_image(const Slam2dMap* d_maps, int32_t p, int32_t x0, int32_t x1, int32_t y0, int32_t y1, int32_t flipud,
+                     double* d_out, uint8_t* d_out_u8, void* stream) {
+    if (!d_maps || p < 0 || x0 < 0 || y0 < 0 || x1 <= x0 || y1 <= y0 || (!d_out && !d_out_u8)) return SLAM2D_E_BADARG;
+    const long long n = (long long)(x1 - x0) * (y1 - y0);
+    long long blocks = (n + 256 * 4 - 1) / (256 * 4);
+    if (blocks > 65535) blocks = 65535;
+    k_map_image<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(d_maps, p, x0, y0, x1 - x0, y1 - y0, flipud, d_out, d_out_u8);
     return launch_status();
 }
 

@@ -42,9 +42,12 @@ def _parse_laser_line(tokens, stamp_offset):
 
 
 def read_text_log(path, record=None):
-    """Readings of a CARMEN (`FLASER`) or GMapping (`LASER_READING`) text log, in time-stamp order -- the order
-    the reference iterates its JSON in (sorted keys).  `record`: which tag to read; default: whichever the file
-    holds (LASER_READING wins if both occur, as in the reference's Intel pipeline).  Returns (readings, stamps)."""
+    """Readings of a CARMEN (`FLASER`) or GMapping (`LASER_READING`) text log in the order the reference's pipeline
+    processes them: its preprocessors key the records by the float time stamp in a dict (a repeated stamp: the last record
+    wins, DataPreprocess/preprocess_gfs.py:17), dump it as JSON (keys become ``repr(float)`` strings) and the drivers iterate
+    ``sorted(sensorData.keys())`` -- the STRING order of those keys (Utils/ScanMatcher_OGBased.py:232), which equals time
+    order only while all stamps have the same number of integer digits.  `record`: which tag to read; default: whichever
+    the file holds (LASER_READING wins if both occur, as in the reference's Intel pipeline).  Returns (readings, stamps)."""
     offsets = {"LASER_READING": 3, "FLASER": 6}
     found = {k: [] for k in offsets}
     with open(path, "r") as f:
@@ -55,8 +58,11 @@ def read_text_log(path, record=None):
     rows = found["LASER_READING"] or found["FLASER"]
     if not rows:
         raise ValueError(f"{path}: no FLASER / LASER_READING records")
-    rows.sort(key=lambda r: r[0])
-    return [r[1] for r in rows], np.array([r[0] for r in rows])
+    by_key = {}
+    for stamp, reading in rows:
+        by_key[repr(float(stamp))] = (stamp, reading)          # last record of a stamp wins, as in the reference's dict
+    order = sorted(by_key)                                     # string order of the JSON keys
+    return [by_key[k][1] for k in order], np.array([by_key[k][0] for k in order])
 
 
 def text_log_to_npz(src, dst, record=None):
@@ -64,3 +70,27 @@ def text_log_to_npz(src, dst, record=None):
     readings, _ = read_text_log(src, record)
     write_npz(dst, readings)
     return len(readings)
+
+
+def read_relations(path):
+    """A ``*.relations`` file (ground-truth relative poses between pairs of scans; DataSet/RawData/intel.relations and
+    friends) as the reference's DataPreprocess/preprocess_relation.py:1-22 reads it: per line
+    ``stamp1 stamp2 x y z roll pitch yaw`` -> x = token 2, y = token 3, theta = token 7, keyed once by the first and once by
+    the second time stamp (float keys; a repeated stamp: the last line wins).  Returns
+    ``{'relation_timeStamp1': {t1: {x, y, theta, timeStamp2}}, 'relation_timeStamp2': {t2: {x, y, theta, timeStamp1}}}``."""
+    by1, by2 = {}, {}
+    with open(path, "r") as f:
+        for line in f:
+            tok = line.split()
+            if not tok:
+                continue
+            x, y, theta, t1, t2 = float(tok[2]), float(tok[3]), float(tok[7]), float(tok[0]), float(tok[1])
+            by1[t1] = {"x": x, "y": y, "theta": theta, "timeStamp2": t2}
+            by2[t2] = {"x": x, "y": y, "theta": theta, "timeStamp1": t1}
+    return {"relation_timeStamp1": by1, "relation_timeStamp2": by2}
+
+
+def write_relations_json(path, relations):
+    """The processed-relations JSON exactly as the reference writes it (sorted keys, indent 4, :20-21)."""
+    with open(path, "w") as fp:
+        json.dump(relations, fp, sort_keys=True, indent=4)

@@ -244,13 +244,14 @@ class LidarModel:
         W, xs = self.width, self.xs
         rec = np.zeros((self.beams, 6), dtype=np.int32)
         grew = False
-        for i, c, _, occ in self.beam_cells(theta, rng):
-            if occ.any():
-                before = len(m.growth_log)
-                dc, dr = m.ensure_contains(x + xs[c[occ] % W], y + xs[c[occ] // W], self.unit)
-                rec[i, 0:2] = (dc, dr)
-                grew |= len(m.growth_log) != before
-            rec[i, 4:6] = (m.cols, m.rows)
+        with m.deferred_growth():          # the per-beam growth steps are planned on the host, the array follows once
+            for i, c, _, occ in self.beam_cells(theta, rng):
+                if occ.any():
+                    before = len(m.growth_log)
+                    dc, dr = m.ensure_contains(x + xs[c[occ] % W], y + xs[c[occ] // W], self.unit)
+                    rec[i, 0:2] = (dc, dr)
+                    grew |= len(m.growth_log) != before
+                rec[i, 4:6] = (m.cols, m.rows)
         if not grew:
             return None
         # low-side shifts of the beams after i
@@ -293,6 +294,7 @@ class MapState:
         if cells is None:
             cells = torch.full((self.rows, self.pitch), _lib.INIT_CELL, dtype=torch.int32, device=device)
         self.cells = cells
+        self._pending, self._defer = None, False
         self._alloc_bits()
         self._sync_coords()
         self.growth_log = []
@@ -323,6 +325,7 @@ class MapState:
         self.dY = _dev(self.Y, self.device)
 
     def desc(self):
+        self._materialise()
         return Slam2dMap(cells=self.cells.data_ptr(), X=self.dX.data_ptr(), Y=self.dY.data_ptr(),
                          rows=self.rows, cols=self.cols, pitch=self.pitch, bits_pitch=self.bits_pitch,
                          lim_x0=self.lim_x[0], lim_x1=self.lim_x[1], lim_y0=self.lim_y[0], lim_y1=self.lim_y[1],
@@ -341,51 +344,88 @@ class MapState:
             return 4
         return -1
 
-    def _grow(self, side, unit):
-        """One 20 % growth step on one side.  Returns (d_col, d_row): how far existing
-        content moved (non-zero only for low-side growth)."""
+    def _plan_grow(self, side, unit):
+        """One 20 % growth step on one side, host bookkeeping only: coordinate vectors, limits, shape, growth log.  The count
+        array follows in ONE re-allocation + block copy when the growth sequence is complete (``_materialise``): the first
+        update of a small map grows it seventeen times (CSAIL), and every step used to allocate and copy the whole map.
+        Returns (d_col, d_row): how far existing content moves (non-zero only for low-side growth)."""
+        if self._pending is None:
+            self._pending = [self.cells, self.rows, self.cols, 0, 0]       # the array as it was + accumulated low-side shift
         rows, cols = self.rows, self.cols
         if side in (1, 2):
             n = int(cols / 5)                                                 # :72
             if side == 1:      # low side: exact spacing (:75-76)
                 new = np.linspace(self.lim_x[0] - n * unit, self.lim_x[0], num=n, endpoint=False)
-                X = np.concatenate((new, self.X))
+                self.X = np.concatenate((new, self.X))
                 shift = (n, 0)
             else:              # high side: spacing unit*(n-1)/n, as the reference (:79-80)
                 new = np.linspace(self.lim_x[1] + unit, self.lim_x[1] + n * unit, num=n, endpoint=False)
-                X = np.concatenate((self.X, new))
+                self.X = np.concatenate((self.X, new))
                 shift = (0, 0)
-            Y = self.Y
         else:
             n = int(rows / 5)                                                 # :62
             if side == 3:
                 new = np.linspace(self.lim_y[0] - n * unit, self.lim_y[0], num=n, endpoint=False)
-                Y = np.concatenate((new, self.Y))
+                self.Y = np.concatenate((new, self.Y))
                 shift = (0, n)
             else:
                 new = np.linspace(self.lim_y[1] + unit, self.lim_y[1] + n * unit, num=n, endpoint=False)
-                Y = np.concatenate((self.Y, new))
+                self.Y = np.concatenate((self.Y, new))
                 shift = (0, 0)
-            X = self.X
-        nrows, ncols = len(Y), len(X)
-        pitch = -(-ncols // self.PITCH_ALIGN) * self.PITCH_ALIGN
-        cells = torch.full((nrows, pitch), _lib.INIT_CELL, dtype=torch.int32, device=self.device)
-        cells[shift[1]:shift[1] + rows, shift[0]:shift[0] + cols] = self.cells[:, :cols]
-        self.cells, self.X, self.Y = cells, X, Y
-        self.rows, self.cols, self.pitch = nrows, ncols, pitch
-        self._alloc_bits()
-        self._sync_coords()
+        self.rows, self.cols = len(self.Y), len(self.X)
+        self.lim_x = [self.X[0], self.X[-1]]           # mapXLim (:86-87)
+        self.lim_y = [self.Y[0], self.Y[-1]]           # mapYLim (:88-89)
+        self._pending[3] += shift[0]
+        self._pending[4] += shift[1]
         self.growth_log.append((side, n))
         return shift
+
+    def _materialise(self):
+        """The planned growth on the device: one fresh array of the final extent, the old content copied to its place."""
+        if self._pending is None:
+            return
+        old, rows, cols, dc, dr = self._pending
+        self._pending = None
+        self.pitch = -(-self.cols // self.PITCH_ALIGN) * self.PITCH_ALIGN
+        cells = torch.full((self.rows, self.pitch), _lib.INIT_CELL, dtype=torch.int32, device=self.device)
+        cells[dr:dr + rows, dc:dc + cols] = old[:, :cols]
+        self.cells = cells
+        self._alloc_bits()
+        self._sync_coords()
+
+    def _grow(self, side, unit):
+        """One growth step, on the device at once (expandOccupancyGrid)."""
+        shift = self._plan_grow(side, unit)
+        if not self._defer:
+            self._materialise()
+        return shift
+
+    def deferred_growth(self):
+        """Context manager: growth steps inside are planned on the host and materialised once at the end."""
+        m = self
+
+        class _Ctx:
+            def __enter__(self):
+                self.prev, m._defer = m._defer, True
+                return m
+
+            def __exit__(self, *exc):
+                m._defer = self.prev
+                if not m._defer:
+                    m._materialise()
+                return False
+        return _Ctx()
 
     def ensure_contains(self, x, y, unit):
         """checkAndExapndOG (:120-125).  Returns the total (d_col, d_row) content shift."""
         dc = dr = 0
         side = self._side_to_grow(x, y)
         while side != -1:
-            s = self._grow(side, unit)
+            s = self._plan_grow(side, unit)
             dc += s[0]; dr += s[1]
             side = self._side_to_grow(x, y)
+        if not self._defer:
+            self._materialise()
         return dc, dr
 
     def to_map_idx(self, x, y, unit):                                         # :102-106
@@ -393,12 +433,31 @@ class MapState:
         yi = np.rint((np.asarray(y) - self.lim_y[0]) / unit).astype(int)
         return xi, yi
 
+    def image(self, x0, x1, y0, y1, flipud=True, as_u8=False):
+        """``np.flipud(1 - (visited / total)[y0:y1, x0:x1])`` (Algorithm/FastSlam.py:173-176) computed on the device
+        (slam2d_map_image): a float64 (or uint8, rint(255 v)) tensor [y1 - y0, x1 - x0] on the map's device.  Python slice
+        semantics for the bounds (negative indices, clipping)."""
+        self._materialise()
+        xa, xb, _ = slice(int(x0), int(x1)).indices(self.cols)
+        ya, yb, _ = slice(int(y0), int(y1)).indices(self.rows)
+        h, w = max(0, yb - ya), max(0, xb - xa)
+        out = torch.empty((h, w), dtype=torch.uint8 if as_u8 else torch.float64, device=self.device)
+        if h == 0 or w == 0:
+            return out
+        d = upload_map_descs([self], self.device)
+        check(_lib.lib().slam2d_map_image(_ptr(d), 0, xa, xb, ya, yb, 1 if flipud else 0, None if as_u8 else _ptr(out),
+                                          _ptr(out) if as_u8 else None, _stream()), "slam2d_map_image")
+        torch.cuda.current_stream(self.device).synchronize()      # the descriptor upload must outlive the kernel
+        return out
+
     def download(self):
         """(visited, total) as float64 host arrays, like the reference's attributes."""
+        self._materialise()
         raw = self.cells[:, :self.cols].cpu().numpy().view(np.uint32)
         return (raw >> np.uint32(16)).astype(np.float64), (raw & np.uint32(0xFFFF)).astype(np.float64)
 
     def upload(self, visited, total):
+        self._materialise()
         v = np.asarray(visited)
         t = np.asarray(total)
         if v.shape != (self.rows, self.cols) or t.shape != v.shape:
@@ -415,7 +474,9 @@ class MapState:
         m.device = self.device
         m.X, m.Y = self.X.copy(), self.Y.copy()
         m.rows, m.cols, m.pitch = self.rows, self.cols, self.pitch
+        self._materialise()
         m.cells = self.cells.clone()
+        m._pending, m._defer = None, False
         m.bits_pitch, m.bits, m.bits_valid = self.bits_pitch, self.bits.clone(), self.bits_valid
         m._sync_coords()
         m.growth_log = list(self.growth_log)

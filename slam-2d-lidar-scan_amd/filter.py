@@ -68,6 +68,13 @@ class MapView:
     def convertRealXYToMapIdx(self, x, y):
         return self._m.to_map_idx(x, y, self._pf.lidar.unit)
 
+    def mapImage(self, xRange, yRange, as_u8=False):
+        """The frame the reference's driver saves per scan (Algorithm/FastSlam.py:171-177) without downloading the count
+        arrays: ``np.flipud(1 - (visited / total)[yIdx[0]:yIdx[1], xIdx[0]:xIdx[1]])`` as a host array, computed on the
+        device (slam2d_map_image); only the window crosses PCIe."""
+        xIdx, yIdx = self.convertRealXYToMapIdx(xRange, yRange)
+        return self._m.image(xIdx[0], xIdx[1], yIdx[0], yIdx[1], flipud=True, as_u8=as_u8).cpu().numpy()
+
 
 def _heading(dx, dy, dist):
     return math.acos(dx / dist) if dy > 0 else -math.acos(dx / dist)
@@ -163,6 +170,8 @@ class ParticleFilter:
         self.lazy_field = True
         self.prune_by_prior = True      # coarse level: poses the motion prior rules out are not scored
         self.step = 0
+        # run(): scans redone step by step (discarded speculative match); resample(): all / those that moved any state
+        self.stats = {"redo": 0, "resamples": 0, "state_moving_resamples": 0}
 
     # ---- odometry prior (Algorithm/FastSlam.py:77-106) ----
     def _raw_odometry(self, raw, prev_raw=None, prev_raw_heading="same"):
@@ -337,9 +346,12 @@ class ParticleFilter:
                 if finish(pending):
                     # the reference draws the resample indices BEFORE this scan's uniforms: rewind, resample, redo the scan
                     stream_rng.set_state(rng_state)
-                    resamples.append((prev_count, self.resample()))
+                    idx = self.resample()
+                    resamples.append((prev_count, idx))
                     rng_state = None
-                    redo = True
+                    # ... unless the draw moved nothing (always so with one particle, whose degeneracy test is always true,
+                    # Algorithm/FastSlam.py:37) and the speculative match consumed no uniform (match_max): it stands as it is
+                    redo = not (self.match_max and np.array_equal(np.asarray(idx), np.arange(self.total_particles)))
                 pending = None
             est_xy = self.prev_matched
             margin = (self.coarse.ncell + 1) * self.coarse.step
@@ -347,6 +359,7 @@ class ParticleFilter:
                 redo = True                                                         # a window may leave a map: grow, step by step
             if redo:
                 # discard the speculative match: its fault flags and its draw from the random stream
+                self.stats["redo"] += 1
                 torch.cuda.current_stream().synchronize()
                 eng.flags.zero_()
                 if rng_state is not None:
@@ -455,8 +468,9 @@ class ParticleFilter:
         n0 = len(m0.growth_log)
         shifts = self.lidar.grow_for_update(m0, x, y, reading['theta'], np.asarray(reading['range'], dtype=np.float64))
         for m in maps[1:]:
-            for side, _ in m0.growth_log[n0:]:
-                m._grow(side, self.lidar.unit)
+            with m.deferred_growth():                  # the whole sequence, one re-allocation per map
+                for side, _ in m0.growth_log[n0:]:
+                    m._grow(side, self.lidar.unit)
         if len(m0.growth_log) != n0:
             self.engine.refresh_maps()
         if shifts is None:
@@ -561,6 +575,7 @@ class ParticleFilter:
             m.device, m.X, m.Y = src.device, src.X.copy(), src.Y.copy()
             m.rows, m.cols, m.pitch = src.rows, src.cols, src.pitch
             m.cells = torch.empty_like(src.cells)
+            m._pending, m._defer = None, False
             m._alloc_bits()
             m._sync_coords()
             m.growth_log = list(src.growth_log)
@@ -576,7 +591,12 @@ class ParticleFilter:
     def apply_resample(self, idx):
         n, P, first = self.total_particles, self.numParticles, self.first_index
         maps = self.engine.maps
-        if not self.sharded:
+        moved = not np.array_equal(np.asarray(idx), np.arange(n))
+        self.stats["resamples"] += 1
+        self.stats["state_moving_resamples"] += int(moved)
+        if not moved:
+            pass        # every particle is replaced by a copy of itself: no map, pose or trajectory moves (only the weights reset)
+        elif not self.sharded:
             self.engine.maps = self._gather_maps(maps, idx)         # deepcopy of the chosen particles (:61)
             local = np.asarray(idx)
             tidx = torch.as_tensor(local.astype(np.int64), device=self.device)
@@ -606,7 +626,8 @@ class ParticleFilter:
             T = len(self.trajectory)
             tr = np.array(trajs).reshape(P, T, 2)
             self.trajectory = [tr[:, t].copy() for t in range(T)]
-        self.engine.refresh_maps()
+        if moved:
+            self.engine.refresh_maps()
         self.weights = np.full(P, 1 / n)                                                 # :62
         self.all_weights = np.full(n, 1 / n)
         self.d_logw.fill_(math.log(1 / n))

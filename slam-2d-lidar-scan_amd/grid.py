@@ -140,6 +140,12 @@ class OccupancyGrid:
             ox.extend(x + xs[c[occ] % W]); oy.extend(y + xs[c[occ] // W])
         return np.asarray(ex), np.asarray(ey), np.asarray(ox), np.asarray(oy)
 
+    def mapImage(self, xRange, yRange, as_u8=False):
+        """``np.flipud(1 - (visited / total)[yIdx[0]:yIdx[1], xIdx[0]:xIdx[1]])`` -- what plotOccupancyGrid (:168-170) and the
+        FastSLAM driver (Algorithm/FastSlam.py:171-177) draw -- computed on the device (slam2d_map_image)."""
+        xIdx, yIdx = self.convertRealXYToMapIdx(xRange, yRange)
+        return self.map.image(xIdx[0], xIdx[1], yIdx[0], yIdx[1], flipud=True, as_u8=as_u8).cpu().numpy()
+
     # ---- plotting (host Matplotlib, off the hot path; Utils/OccupancyGrid.py:161-175) ----
     def plotOccupancyGrid(self, xRange=None, yRange=None, plotThreshold=True):
         import matplotlib.pyplot as plt
@@ -147,9 +153,7 @@ class OccupancyGrid:
             xRange = self.mapXLim
         if yRange is None or yRange[0] < self.mapYLim[0] or yRange[1] > self.mapYLim[1]:
             yRange = self.mapYLim
-        visited, total = self.map.download()
-        xIdx, yIdx = self.convertRealXYToMapIdx(xRange, yRange)
-        img = np.flipud(1 - (visited / total)[yIdx[0]:yIdx[1], xIdx[0]:xIdx[1]])
+        img = self.mapImage(xRange, yRange)
         extent = [xRange[0], xRange[1], yRange[0], yRange[1]]
         plt.imshow(img, cmap='gray', extent=extent)
         plt.show()

@@ -1,0 +1,73 @@
+"""Export half of SURVEY 8(f)-4: the picture the reference's FastSLAM driver saves per scan
+(Algorithm/FastSlam.py:171-177: ``np.flipud(1 - (visited / total)[yIdx[0]:yIdx[1], xIdx[0]:xIdx[1]])``) computed on the
+device from a map that has GROWN (slam2d_map_image through the C ABI), against the same expression on the oracle's arrays;
+and the driver advice of round 2: the single-trajectory driver on the batched path never redoes a scan."""
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import slam_oracle as so
+
+pytestmark = pytest.mark.gpu
+REF_SM = (1.4, 0.25, 2, 0.1, 0.25, 0.3, 0.15, 5)
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return importlib.import_module("slam-2d-lidar-scan_amd")
+
+
+def _reference_picture(og, xRange, yRange):
+    """Algorithm/FastSlam.py:172-176 on an object with the OccupancyGrid surface (here: the oracle)."""
+    ogMap = og.occupancyGridVisited / og.occupancyGridTotal
+    xIdx, yIdx = og.convertRealXYToMapIdx(xRange, yRange)
+    ogMap = ogMap[yIdx[0]: yIdx[1], xIdx[0]: xIdx[1]]
+    return np.flipud(1 - ogMap)
+
+
+def test_map_image_of_a_grown_map_matches_the_oracle(pkg, intel_readings):
+    n = 14
+    r0 = intel_readings[0]
+    og = pkg.OccupancyGrid(10, 10, r0, 0.02, np.pi, 180, 10, 0.1)           # 501^2: the first update grows it
+    sm = pkg.ScanMatcher(og, *REF_SM)
+    so.run_scanmatch_flow(intel_readings, og, sm, max_scans=n)
+    ogo = so.GridOracle(10, 10, r0, 0.02, np.pi, 180, 10, 0.1)
+    smo = so.MatcherOracle(ogo, *REF_SM)
+    so.run_scanmatch_flow(intel_readings, ogo, smo, max_scans=n)
+    assert og.map.rows > 501 and (og.map.rows, og.map.cols) == ogo.visited.shape
+    for xRange, yRange in (([-13, 20], [-25, 7]),                           # the driver's window (clipped by the slice, as there)
+                           ([og.mapXLim[0] + 1.0, og.mapXLim[1] - 2.0], [og.mapYLim[0] + 0.5, og.mapYLim[1] - 0.25]),
+                           ([r0["x"] - 3.0, r0["x"] + 3.0], [r0["y"] - 2.0, r0["y"] + 4.0])):
+        want = _reference_picture(ogo, xRange, yRange)
+        got = og.mapImage(xRange, yRange)
+        assert got.dtype == np.float64 and got.shape == want.shape
+        assert np.array_equal(got, want)
+        u8 = og.mapImage(xRange, yRange, as_u8=True)
+        assert u8.dtype == np.uint8 and np.array_equal(u8, np.rint(want * 255).astype(np.uint8))
+    # unflipped, straight from the map object
+    img = og.map.image(10, 200, 40, 90, flipud=False).cpu().numpy()
+    assert np.array_equal(img, (1 - ogo.visited / ogo.total)[40:90, 10:200])
+
+
+def test_particle_view_image_and_single_particle_driver(pkg, intel_readings):
+    """ParticleFilter(1, match_max=True).run() is the single-trajectory driver (Utils/ScanMatcher_OGBased.py:226-256): its
+    degeneracy test is true after every scan (Algorithm/FastSlam.py:37 with N = 1), so every scan is followed by an identity
+    resample -- which must move no state and cost no redone scan; the best particle's picture equals the oracle's."""
+    n = 40
+    u = 0.02
+    r0 = intel_readings[0]
+    pf = pkg.ParticleFilter(1, [10, 10, r0, u, np.pi, 10, 180, 5 * u], list(REF_SM), rng=np.random.RandomState(0), match_max=True)
+    res = pf.run(intel_readings[:n])
+    assert len(res) == n and all(list(idx) == [0] for _, idx in res)        # the reference resamples after every scan
+    assert pf.stats["state_moving_resamples"] == 0 and pf.stats["redo"] <= 2, pf.stats     # (redo: only where a map had to grow)
+    ogo = so.GridOracle(10, 10, r0, u, np.pi, 180, 10, 5 * u)
+    smo = so.MatcherOracle(ogo, *REF_SM)
+    out, _ = so.run_scanmatch_flow(intel_readings, ogo, smo, max_scans=n)
+    assert np.array_equal(np.array([t[0] for t in pf.trajectory]), np.array([[m["x"], m["y"]] for m in out]))
+    view = pf.best_particle().og
+    want = _reference_picture(ogo, [-13, 20], [-25, 7])
+    assert np.array_equal(view.mapImage([-13, 20], [-25, 7]), want)
