@@ -205,10 +205,8 @@ class HotPath:
                                                              overlap=os.environ.get("SLAM2D_BENCH_OVERLAP", "0") == "1")
                 # (overlap: collective + merge on a side stream.  Bit-identical, but at one rank its events and stream
                 # switches cost the host more than the collective's latency: 0.207 vs 0.187 ms/step -- off by default)
-            if self.normalizer.overlap:
-                self.normalizer.wait()
             e.grid_update_weights_local(final, E.MATCH_DOUBLES, rng, self.d_logw, self.m_coarse.data_ptr() + 32, E.MATCH_DOUBLES,
-                                        self.normalizer.part)
+                                        self.normalizer.part, normalizer=self.normalizer)
         else:       # one launch: the normaliser rides beside the update (it reads only what the match wrote)
             e.grid_update_weights(final, E.MATCH_DOUBLES, rng, self.d_logw, self.m_coarse.data_ptr() + 32, E.MATCH_DOUBLES,
                                   self.d_w, self.d_stats)         # +32: log_confidence

@@ -733,10 +733,9 @@ __global__ __launch_bounds__(TRIAGE_THREADS) void k_tile_triage(Slam2dLevel lv, 
         const bool live = (liveb >> it) & 1u, any = (anyb >> it) & 1u;
         const bool wanted = live && (everything || ((need_s[t >> 5] >> (t & 31)) & 1u));
         bool to_fill = false;
-        if (live && !any) {
-            lv.tilemin[(size_t)p * ntile + t] = lv.floor_value;
-            if (wanted && state_s[t] != 0) { to_fill = true; state[t] = 0; }
-        }
+        // (a free tile's minimum is the floor -- not recorded: k_blur_check_redo reads the per-tile minima only when the frame
+        // has no free tile at all, and then every tile goes through the blur, which records its own)
+        if (live && !any && wanted && state_s[t] != 0) { to_fill = true; state[t] = 0; }
         const bool mine[2] = {wanted && any, to_fill};
 #pragma unroll
         for (int which = 0; which < 2; ++which) {
@@ -788,8 +787,24 @@ __global__ __launch_bounds__(BLUR_THREADS, BLUR_MIN_WAVES) void k_blur_clamp(Sla
     }
 }
 
-// gmin2 (branch and bound): element [Y][X] = min(gmin[Y..Y+1][X..X+1]) >> 12 over the frame's blocks; `part` of
-// `parts` thread groups of `nthreads` threads each.  Blocks beyond the buffer are clamped (duplicates only).
+// gmin2 (branch and bound): element [Y][X] = min(gmin[Y..Y+1][X..X+1]) >> 12.  Blocks beyond the buffer are clamped
+// (duplicates only).
+__device__ __forceinline__ void gmin2_entry(const Slam2dLevel& lv, const uint32_t* __restrict__ G, uint32_t* __restrict__ G2,
+                                            const int p, const int gp, const int Y, const int X) {
+    const int Y1 = min(Y + 1, gp - 1), X1 = min(X + 1, gp - 1);
+    const uint32_t v = min(min(G[(size_t)Y * gp + X], G[(size_t)Y * gp + X1]), min(G[(size_t)Y1 * gp + X], G[(size_t)Y1 * gp + X1]));
+    G2[(size_t)Y * gp + X] = v >> 12;
+    if (lv.bnb == 2) {
+        // two-level bounds: the 8x8 cell window of an 8x8-pose tile lies inside blocks Y..Y+2 x X..X+2; stored decimated by
+        // two in four phase planes, so that the tiles of one row (block stride 2) are contiguous
+        const int Y2 = min(Y + 2, gp - 1), X2 = min(X + 2, gp - 1);
+        uint32_t v3 = min(v, min(G[(size_t)Y * gp + X2], G[(size_t)Y1 * gp + X2]));
+        v3 = min(v3, min(min(G[(size_t)Y2 * gp + X], G[(size_t)Y2 * gp + X1]), G[(size_t)Y2 * gp + X2]));
+        const int hp = gp >> 1;
+        lv.gmin3d[(size_t)p * gp * gp + ((size_t)(((Y & 1) << 1) | (X & 1)) * hp + (Y >> 1)) * hp + (X >> 1)] = v3 >> 12;
+    }
+}
+// ... over the whole frame: `part` of `parts` thread groups of `nthreads` threads each
 __device__ __forceinline__ void gmin2_pass(const Slam2dLevel& lv, const int p, const Slam2dFrame& fr, const int tid,
                                            const int nthreads, const int part, const int parts) {
     const int gp = lv.tmax << 2;
@@ -798,18 +813,30 @@ __device__ __forceinline__ void gmin2_pass(const Slam2dLevel& lv, const int p, c
     uint32_t* __restrict__ G2 = lv.gmin2 + (size_t)p * gp * gp;
     for (int idx = part * nthreads + tid; idx < rows * cols; idx += parts * nthreads) {
         const int Y = idx / cols, X = idx - Y * cols;
-        const int Y1 = min(Y + 1, gp - 1), X1 = min(X + 1, gp - 1);
-        const uint32_t v = min(min(G[(size_t)Y * gp + X], G[(size_t)Y * gp + X1]), min(G[(size_t)Y1 * gp + X], G[(size_t)Y1 * gp + X1]));
-        G2[(size_t)Y * gp + X] = v >> 12;
-        if (lv.bnb == 2) {
-            // two-level bounds: the 8x8 cell window of an 8x8-pose tile lies inside blocks Y..Y+2 x X..X+2; stored decimated by
-            // two in four phase planes, so that the tiles of one row (block stride 2) are contiguous
-            const int Y2 = min(Y + 2, gp - 1), X2 = min(X + 2, gp - 1);
-            uint32_t v3 = min(v, min(G[(size_t)Y * gp + X2], G[(size_t)Y1 * gp + X2]));
-            v3 = min(v3, min(min(G[(size_t)Y2 * gp + X], G[(size_t)Y2 * gp + X1]), G[(size_t)Y2 * gp + X2]));
-            const int hp = gp >> 1;
-            lv.gmin3d[(size_t)p * gp * gp + ((size_t)(((Y & 1) << 1) | (X & 1)) * hp + (Y >> 1)) * hp + (X >> 1)] = v3 >> 12;
-        }
+        gmin2_entry(lv, G, G2, p, gp, Y, X);
+    }
+}
+// ... over the entries that can have changed: a tile written at this build (the blur list and the fill list of the triage)
+// changes the minima of its own 4 x 4 blocks, hence entries Y in [4 ty - 1, 4 ty + 3] (from 4 ty - 2 with gmin3d), likewise
+// X.  An entry the bounds read covers cells of tiles that are all needed, hence current: either rebuilt now (listed) or
+// holding the free-space constant since they were last written -- and every write of a tile has refreshed all the entries it
+// touches, so the entry equals what the whole-frame pass would store.  (That pass read and wrote 2 x 166 KB per particle
+// and scan for ~150 changed tiles: 21.7 MB of HBM traffic per launch at config 2.)
+__device__ __forceinline__ void gmin2_dirty(const Slam2dLevel& lv, const int p, const int tid, const int nthreads,
+                                            const int part, const int parts) {
+    const int gp = lv.tmax << 2, ntile = lv.tmax * lv.tmax;
+    const int nb = lv.tilecount[2 * p], nf = lv.tilecount[2 * p + 1];
+    const int* __restrict__ list = lv.tilelist + (size_t)p * 2 * ntile;
+    const int E = lv.bnb == 2 ? 6 : 5, per = E * E;
+    const uint32_t* __restrict__ G = lv.gmin + (size_t)p * gp * gp;
+    uint32_t* __restrict__ G2 = lv.gmin2 + (size_t)p * gp * gp;
+    for (int idx = part * nthreads + tid; idx < (nb + nf) * per; idx += parts * nthreads) {
+        const int k = idx / per, e = idx - k * per;
+        const int t = k < nb ? list[k] : list[ntile + (k - nb)];
+        const int ty = t / lv.tmax, tx = t - ty * lv.tmax;
+        const int Y = 4 * ty - (E - 4) + e / E, X = 4 * tx - (E - 4) + e % E;
+        if (Y < 0 || X < 0 || Y >= gp || X >= gp) continue;
+        gmin2_entry(lv, G, G2, p, gp, Y, X);
     }
 }
 
@@ -819,12 +846,15 @@ __device__ __forceinline__ void gmin2_pass(const Slam2dLevel& lv, const int p, c
 // at once when a free tile pins the minimum (frames[p].min_known, set by the triage: no redo can follow), block
 // (p, 0) alone after the check otherwise.
 template <int RAD>
-__global__ __launch_bounds__(256) void k_blur_check_redo(Slam2dLevel lv, uint32_t* flags) {
+__global__ __launch_bounds__(256) void k_blur_check_redo(Slam2dLevel lv, uint32_t* flags, int dirty_only) {
     __shared__ BlurLds<RAD> sm;
     __shared__ double red_s[4];
     const int p = blockIdx.x, tid = threadIdx.x;
     Slam2dFrame fr = lv.frames[p];
-    if (lv.bnb && fr.min_known) gmin2_pass(lv, p, fr, tid, 256, blockIdx.y, gridDim.y);
+    if (lv.bnb && fr.min_known) {
+        if (dirty_only) gmin2_dirty(lv, p, tid, 256, blockIdx.y, gridDim.y);
+        else gmin2_pass(lv, p, fr, tid, 256, blockIdx.y, gridDim.y);
+    }
     if (blockIdx.y != 0) return;
     {   // largest value any pose can read: free tiles hold the floor, the blurred ones recorded theirs
         const int n = lv.tilecount[2 * p];
@@ -3089,11 +3119,16 @@ static void launch_field(const Slam2dLevel& lv, const Slam2dMap* d_maps, int P, 
             default: k_blur_clamp<0><<<bgrid, BLUR_THREADS, 0, s>>>(lv); break;
         }
     }
+    // gmin2 only where a tile was written (SLAM2D_GMIN2_FULL=1: over the whole frame, as before round 3); 4 blocks per particle
+    // are plenty for ~150 tiles x 25 entries
+    static const bool full = [] { const char* e = getenv("SLAM2D_GMIN2_FULL"); return e && atoi(e) == 1; }();
+    const int dirty = lazy && !full ? 1 : 0;
+    const dim3 cgrid(P, lv.bnb ? (dirty ? 4 : 16) : 1);
     switch (lv.blur_radius) {
-        case 2: k_blur_check_redo<2><<<dim3(P, lv.bnb ? 16 : 1), 256, 0, s>>>(lv, d_flags); break;
-        case 4: k_blur_check_redo<4><<<dim3(P, lv.bnb ? 16 : 1), 256, 0, s>>>(lv, d_flags); break;
-        case 8: k_blur_check_redo<8><<<dim3(P, lv.bnb ? 16 : 1), 256, 0, s>>>(lv, d_flags); break;
-        default: k_blur_check_redo<0><<<dim3(P, lv.bnb ? 16 : 1), 256, 0, s>>>(lv, d_flags); break;
+        case 2: k_blur_check_redo<2><<<cgrid, 256, 0, s>>>(lv, d_flags, dirty); break;
+        case 4: k_blur_check_redo<4><<<cgrid, 256, 0, s>>>(lv, d_flags, dirty); break;
+        case 8: k_blur_check_redo<8><<<cgrid, 256, 0, s>>>(lv, d_flags, dirty); break;
+        default: k_blur_check_redo<0><<<cgrid, 256, 0, s>>>(lv, d_flags, dirty); break;
     }
 }
 

@@ -752,9 +752,13 @@ class ParticleEngine:
                                                 _ptr(d_ranges), _ptr(self.flags), _ptr(d_logw), C.c_void_p(logconf_ptr),
                                                 logconf_stride, _ptr(d_w), _ptr(d_stats), _stream()), "slam2d_grid_update_weights")
 
-    def grid_update_weights_local(self, d_pose, stride, d_ranges, d_logw, logconf_ptr, logconf_stride, d_part):
+    def grid_update_weights_local(self, d_pose, stride, d_ranges, d_logw, logconf_ptr, logconf_stride, d_part, normalizer=None):
         """Map update + the rank-local half of the sharded normaliser in one launch (slam2d_grid_update_weights_local);
-        the all-gather and slam2d_weights_merge follow (parallel.ShardedNormalizer(..., local_done=True))."""
+        the all-gather and slam2d_weights_merge follow (parallel.ShardedNormalizer(..., local_done=True)).  ``normalizer``:
+        that ShardedNormalizer (``d_part`` should be its ``part``): the launch is ordered behind its previous, possibly
+        still overlapped, merge first -- the launch writes the log-weights and the partials that merge works on."""
+        if normalizer is not None:
+            normalizer.pre_local()
         self.refresh_bits()
         check(self.L.slam2d_grid_update_weights_local(C.byref(self.lidar_c), _ptr(self.d_maps), self.P, _ptr(d_pose), stride,
                                                       _ptr(d_ranges), _ptr(self.flags), _ptr(d_logw), C.c_void_p(logconf_ptr),

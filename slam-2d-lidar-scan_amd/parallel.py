@@ -100,6 +100,14 @@ class ShardedNormalizer:
         """Order the current stream behind the last overlapped merge (no-op otherwise)."""
         if self.overlap and self.pending:
             torch.cuda.current_stream(self.part.device).wait_event(self.ev_merged)
+            self.pending = False
+
+    def pre_local(self):
+        """To be called BEFORE anything on the launch stream writes ``logw`` or ``self.part`` for the next scan -- i.e. before
+        the fused slam2d_grid_update_weights_local launch (``ParticleEngine.grid_update_weights_local`` does it when it is
+        handed the normaliser): with ``overlap`` the previous scan's all-gather (reads ``part``) and merge (reads and writes
+        ``logw``) may still be running on the side stream."""
+        self.wait()
 
     def __call__(self, logw, logconf_ptr, logconf_stride, w, stats, local_done=False):
         """In place on ``logw`` (this rank's log-weights); writes ``w`` and ``stats`` =
@@ -109,12 +117,19 @@ class ShardedNormalizer:
         stream = main.cuda_stream
         n = logw.numel()
         if self.overlap:
+            if local_done and self.pending:
+                # the rank-local half already ran on the launch stream: it must have been ordered behind the previous merge
+                # (pre_local) BEFORE it wrote logw / part -- too late to wait now
+                raise RuntimeError("ShardedNormalizer(overlap=True): call pre_local() (or pass the normaliser to "
+                                   "ParticleEngine.grid_update_weights_local) before the fused local launch")
             self.wait()                                       # logw, part: the previous scan's merge is done with them
         if not local_done:
             self.check(self.lib.slam2d_weights_local(logw.data_ptr(), logconf_ptr, logconf_stride, n,
                                                      self.part.data_ptr(), stream), "slam2d_weights_local")
         if self.overlap:
             self.ev_local.record(main)
+            for t in (logw, w, stats):                        # used on the side stream: keep the allocator from recycling them early
+                t.record_stream(self.side)
             with torch.cuda.stream(self.side):
                 self.side.wait_event(self.ev_local)
                 dist.all_gather_into_tensor(self.parts, self.part, group=self.group)

@@ -101,19 +101,34 @@ def _rccl_worker(port, out_path):
         rng = np.random.default_rng(5)
         conf = torch.from_numpy(rng.normal(-40.0, 6.0, size=(scans, n))).to(dev)
         res = {}
-        for mode in ("plain", "inorder", "overlap"):
+        for mode in ("plain", "inorder", "overlap", "overlap_local"):
             logw = torch.full((n,), -np.log(n), dtype=torch.float64, device=dev)
             w = torch.zeros(n, dtype=torch.float64, device=dev)
             stats = torch.zeros(2, dtype=torch.float64, device=dev)
-            norm = None if mode == "plain" else par.ShardedNormalizer(L, E._lib.check, dev, n, overlap=mode == "overlap")
-            assert norm is None or norm.overlap == (mode == "overlap")
+            norm = None if mode == "plain" else par.ShardedNormalizer(L, E._lib.check, dev, n, overlap=mode.startswith("overlap"))
+            assert norm is None or norm.overlap == mode.startswith("overlap")
             hist = []
             for s in range(scans):
                 if norm is None:
                     E._lib.check(L.slam2d_weights_normalize(E._ptr(logw), C.c_void_p(conf[s].data_ptr()), 1, n, E._ptr(w),
                                                             E._ptr(stats), E._stream()), "weights")
                 else:
-                    norm(logw, conf[s].data_ptr(), 1, w, stats)
+                    if mode == "overlap_local":
+                        # the rank-local half as its own launch on the main stream (what the fused update launch does): it
+                        # writes logw / part, so it has to be ordered behind the previous, still overlapped, merge first
+                        if s == 5:
+                            try:
+                                norm(logw, None, 1, w, stats, local_done=True)
+                                raised = False
+                            except RuntimeError:
+                                raised = True
+                            assert raised, "local_done without pre_local() while a merge is pending must raise"
+                        norm.pre_local()
+                        E._lib.check(L.slam2d_weights_local(E._ptr(logw), C.c_void_p(conf[s].data_ptr()), 1, n, E._ptr(norm.part),
+                                                            E._stream()), "weights_local")
+                        norm(logw, None, 1, w, stats, local_done=True)
+                    else:
+                        norm(logw, conf[s].data_ptr(), 1, w, stats)
                     if s % 7 == 3:                                   # a reader in the middle of the sequence
                         norm.wait()
                         hist.append(w.clone())
@@ -122,6 +137,7 @@ def _rccl_worker(port, out_path):
             torch.cuda.synchronize()
             res[mode] = (logw.cpu().numpy(), w.cpu().numpy(), stats.cpu().numpy(), [h.cpu().numpy() for h in hist])
         ok = all(np.array_equal(res["inorder"][i], res["overlap"][i]) for i in range(3))
+        ok &= all(np.array_equal(res["inorder"][i], res["overlap_local"][i]) for i in range(3))
         ok &= all(np.array_equal(a, b) for a, b in zip(res["inorder"][3], res["overlap"][3])) and len(res["overlap"][3]) == 4
         close = np.allclose(res["plain"][1], res["overlap"][1], rtol=1e-12, atol=0) and abs(res["overlap"][1].sum() - 1) < 1e-12
         open(out_path, "w").write(f"{int(ok)} {int(close)}")
