@@ -1081,8 +1081,6 @@ __global__ __launch_bounds__(NT) void k_endpoints(Slam2dLidar lid, Slam2dLevel l
     }
     const int B = lid.beams;
     DBG_CLOCK(40, grp == 0 && p == 0);
-    int n = 256;
-    while (n < B) n <<= 1;
     constexpr int NW = NT / 64;
     int hsize = 512;                                       // power of two >= 1.5 * beams (load factor <= 2/3)
     while (hsize < B + (B >> 1)) hsize <<= 1;
@@ -1110,7 +1108,9 @@ __global__ __launch_bounds__(NT) void k_endpoints(Slam2dLidar lid, Slam2dLevel l
     const int span = lv.bnb == 2 ? 8 * ((2 * lv.ncell + 8) >> 3) + 3 : lv.bnb ? 4 * ((2 * lv.ncell + 4) >> 2) + 3 : 2 * lv.ncell;
     const int ntl = (lead + span) >> BLUR_SHIFT;
     const int nc = lv.ncell;
-    const int per = NT == 256 ? n / 256 : 1;               // beams per thread, interleaved: beam = q * NT + tid, so that a
+    const int per = NT == 256 ? (B + 255) / 256 : 1;       // beams per thread (5 at 1081 beams -- rounding the beams up to a power of
+    //                                                        two first made it 8: three fully masked passes through every loop below,
+    //                                                        a third of the kernel's vector instructions), interleaved: beam = q * NT + tid, so that a
     //                                                        wave's loads and stores are contiguous (at 1081 beams the
     //                                                        thread-contiguous mapping cost 32 cache lines per wave-load)
     // np.linspace(theta - fov/2, theta + fov/2, num=B)  (:82-83)
@@ -2787,6 +2787,9 @@ __device__ __forceinline__ int rint_div(const double v, const double unit, const
 #ifndef UPDB_UNROLL
 #define UPDB_UNROLL 4
 #endif
+#ifndef UPDB_NO_LATTICE
+#define UPDB_NO_LATTICE 0            // 1: always the per-cell fp64 index path (A/B builds)
+#endif
 #ifndef UPDB_MIN_WAVES
 #define UPDB_MIN_WAVES 1
 #endif
@@ -2849,6 +2852,18 @@ __global__ __launch_bounds__(256, UPDB_MIN_WAVES) void k_grid_update(Slam2dLidar
             sx = bs[0]; sy = bs[1]; ax = bs[2]; ay = bs[3]; wc = bs[4]; wr = bs[5];
         }
         const uint32_t ncells = (uint32_t)m.rows * (uint32_t)m.pitch;
+        // The map index of a window cell is rint(((pose + xs[j]) - mapLim0) / unit) (:104-105,144-145), two fp64 chains per
+        // cell.  When the window step IS the map unit (lidarMaxRange a whole number of cells: every configuration in use)
+        // that is rint(A + j) with A = (pose - R - mapLim0) / unit: the fp64 evaluation differs from the real A + j by
+        // < 1e-11 cells (three roundings at magnitude <= 1e4), so it rounds to j + rint(A) whenever A is farther than
+        // 1e-6 from a half-integer -- decided once per particle; a particle that close to a rounding boundary takes the
+        // per-cell path with its exact-division fallback.  (Config 5: 138 k waves x ~25 fp64 instructions per cell saved;
+        // the kernel is instruction-bound there.)
+        const double Ax = ((px + -lid.max_range) - m.lim_x0) * inv_unit, Ay = ((py + -lid.max_range) - m.lim_y0) * inv_unit;
+        const double rAx = rint(Ax), rAy = rint(Ay);
+        const bool lattice = !beam_shift && lid.lut_xs_step == lid.unit && fabs(Ax) < 1e8 && fabs(Ay) < 1e8 &&
+                             fabs(fabs(Ax - rAx) - 0.5) > 1e-6 && fabs(fabs(Ay - rAy) - 0.5) > 1e-6 && !UPDB_NO_LATTICE;
+        const int bx = (int)rAx, by = (int)rAy;
         for (int k0 = kbeg + lane; k0 < kend; k0 += 64 * UPDB_UNROLL) {
             // straight-line phases, every load of a phase issued before its first use (no branches in between)
             double r[UPDB_UNROLL], xj[UPDB_UNROLL], yi[UPDB_UNROLL];
@@ -2860,6 +2875,14 @@ __global__ __launch_bounds__(256, UPDB_MIN_WAVES) void k_grid_update(Slam2dLidar
                 r[u] = sr[k];
                 cell[u] = sc[k];
             }
+            if (lattice) {
+                // the window's cells sit on the map's lattice: column index + the particle's offset, nothing else
+#pragma unroll
+                for (int u = 0; u < UPDB_UNROLL; ++u) {
+                    mxs[u] = (int)(cell[u] & 0xffffu) + bx;
+                    mys[u] = (int)(cell[u] >> 16) + by;
+                }
+            } else {
             // window coordinate of a column / row: np.linspace(-R, R, W)[j] = j * step + (-R), last element R
             // (lut_xs_step, checked against the table by the host), else the table itself
             if (lid.lut_xs_step != 0.0) {
@@ -2891,6 +2914,7 @@ __global__ __launch_bounds__(256, UPDB_MIN_WAVES) void k_grid_update(Slam2dLidar
                     mxs[u] = (int)rint(((px + xj[u]) - m.lim_x0) / lid.unit);
                     mys[u] = (int)rint(((py + yi[u]) - m.lim_y0) / lid.unit);
                 }
+            }
             }
 #pragma unroll
             for (int u = 0; u < UPDB_UNROLL; ++u) {

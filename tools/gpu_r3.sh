@@ -47,7 +47,7 @@ clock)
   timeout 600 python tools/dbg_clock.py config2 64 > gpurun_out/dbg_clock.log 2>&1
   echo "clock rc=$?"; tail -n 12 gpurun_out/dbg_clock.log ;;
 pmc)
-  for WL in config2 ref2level config5; do
+  for WL in ${PMC_WL:-config2 ref2level config5}; do
     for PASS in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "tcc:TCC_HIT_sum TCC_MISS_sum" \
                 "sq:SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES" \
                 "tcp:TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum"; do
