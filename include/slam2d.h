@@ -212,7 +212,8 @@ typedef struct {
                                 finishes the particle's work (k_exact_select split over several blocks; the tile triage as the tail of the
                                 scatter).  ZERO them once after allocation; every launch leaves them zero again.  NULL: those
                                 launches fall back to one block per particle / separate launches */
-    int32_t bnb;             /* 1: slam2d_match scores this level by branch and bound; 2: with two-level bounds */
+    int32_t bnb;             /* 1: slam2d_match scores this level by branch and bound; 2: with two-level bounds; 3: angle bounds
+                                (cubes of <= 5 x 5 poses per angle: needs gmin, gmin2, pcells, bounds [P][ntheta], bnb_best, seed_key) */
     int32_t ep_group;        /* angles per k_endpoints block (>= 1; 0 = 1): tileneed holds ceil(ntheta / ep_group) slices per particle */
     int32_t occ_gen;         /* 0: occ + tilemask are cleared at every build.  1..255: generation stamp -- an
                                 occ / tilemask byte means "occupied" only when it equals occ_gen, so nothing is
@@ -302,7 +303,14 @@ int slam2d_sweep(const Slam2dLidar* lidar, const Slam2dLevel* level, int32_t P,
  * best child of the tile with the best 8 x 8 bound, seed_key) gives a first threshold; the 4 x 4 children of the
  * 8 x 8 tiles that reach it get their gmin2 bounds (all other 4 x 4 tiles: -inf), and every theta whose best child
  * still reaches the running maximum is seeded exactly and raises it.  The maximum over all candidate seeds and the
- * tile set scored exactly do not depend on the order in which the waves run. */
+ * tile set scored exactly do not depend on the order in which the waves run.
+ * bnb == 3 (angle bounds; cubes of <= 5 x 5 poses per angle, e.g. the fine level behind a coarse factor of 2, with ~1000-cell
+ * lists): all poses of one angle read, at endpoint cell k, a window of <= 5 x 5 field cells starting at the patch corner, which
+ * lies inside the aligned 8 x 8 block gmin2 summarises there -- so U(theta) = -(sum_k gmin2[cell k] << 12) / cost_scale + the
+ * largest prior bounds the angle's whole plane from ONE 4-byte load per cell.  The plane of the particle's best-bound angle is
+ * scored exactly first (the seed, M0); planes with U < M0 - SLAM2D_BNB_MARGIN are not scored (level->cube keeps stale content
+ * there, their partial reads "nothing"): none of them can hold the arg-max, together they change the confidence by
+ * < ntheta * 25 * exp(-30) relative. */
 int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2dMap* d_maps, int32_t P,
                  const double* d_est, int32_t est_stride, const double* d_ranges,
                  double est_moving_dist, const double* d_psi_cs, const double* d_uniform,

@@ -127,6 +127,14 @@ __device__ __forceinline__ unsigned long long row16_sum_u64(unsigned long long t
     t += dpp_u64<0x140>(t);          // row_mirror
     return t;
 }
+// u32 sum over the 16 lanes of a DPP row, in every lane
+__device__ __forceinline__ unsigned row16_sum_u32(unsigned v) {
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);
+    return v;
+}
 // the same for a double (returned as its bits): used for the 16 exp(score - M) of a tile
 __device__ __forceinline__ unsigned long long row16_sum_f64(double v) {
     v += __longlong_as_double((long long)dpp_u64<0xB1>((unsigned long long)__double_as_longlong(v)));
@@ -216,7 +224,7 @@ __global__ void k_frame_axis(Slam2dLidar lid, Slam2dLevel lv, const Slam2dMap* _
         lv.frames[p] = fr;
         lv.tilecount[2 * p] = 0; lv.tilecount[2 * p + 1] = 0;
         if (lv.bnb) lv.bnb_best[p] = order_bits(-INFINITY);
-        if (lv.bnb == 2) lv.seed_key[p] = 0ull;
+        if (lv.bnb >= 2) lv.seed_key[p] = 0ull;
         if (f) atomicOr(&flags[p], f);
     }
     const int n = axis == 0 ? fr.mx1 - fr.mx0 : fr.my1 - fr.my0;
@@ -950,7 +958,7 @@ __device__ __forceinline__ void write_priors(const Slam2dLevel& lv, const int p,
         out[q] = rv;
         out[np_ + q] = tw;
     }
-    if (lv.bnb) {
+    if (lv.bnb && lv.bnb != 3) {
         // largest rv + thetaWeight of every 4x4 pose tile (+inf when one of them is NaN: np.argmax returns the first
         // NaN, so such a tile is always scored); padding tiles get -inf
         __syncthreads();                                   // the planes above were written by this block
@@ -1009,7 +1017,7 @@ __device__ __forceinline__ void frame_duties(const Slam2dLidar& lid, const Slam2
         lv.frames[p] = fr;
         lv.tilecount[2 * p] = 0; lv.tilecount[2 * p + 1] = 0;
         if (lv.bnb) lv.bnb_best[p] = order_bits(-INFINITY);
-        if (lv.bnb == 2) lv.seed_key[p] = 0ull;
+        if (lv.bnb >= 2) lv.seed_key[p] = 0ull;
         if (f) atomicOr(&flags[p], f);
     }
     bool bad = false;
@@ -1560,20 +1568,21 @@ __global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks
 // lane = (slot, cell slice) -- floor(64 / slots) slices share the cell list, which is staged in LDS once (no
 // vector-memory instruction per cell for the list), so a plane costs ~K / slices 16-byte gathers instead of K.
 // Same exact integer sums, same cube / partial layout as k_sweep with one chunk per theta.
-__global__ __launch_bounds__(64) void k_sweep_small(Slam2dLevel lv, int P) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long small_lds[];   // [64 * 4] partial sums, then [kmax] cells
-    const int b = blockIdx.x;
-    const int xcd = b & 7, slot = b >> 3;
-    const int p = (slot / lv.ntheta) * 8 + xcd, it = slot % lv.ntheta;
-    if (p >= P) return;
-    const int lane = threadIdx.x;
+// One (particle, theta) plane of a small cube by one wave; returns the plane's reduction (to every lane) and stores the scores
+// and, with `write`, the plane's Slam2dPartial.  small_lds: [64 * 4] partial sums, then [kmax] cells.
+// NWAVES waves (one block) split the cell list; the scores, the reduction and the return value are wave 0's.
+// small_lds: [NWAVES * 4 * 64] partial sums, then [kmax] cells.
+template <int NWAVES>
+__device__ __forceinline__ Best sweep_small_plane(const Slam2dLevel& lv, const int p, const int it, unsigned long long* small_lds,
+                                                  const bool write) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nx = 2 * lv.ncell + 1, npose = nx * nx;
     const int nq = (nx + 3) >> 2, nslot = nx * nq;             // <= 32 (checked by the host)
-    const int S = WAVE / nslot;                                 // cell slices
+    const int S = WAVE / nslot;                                 // cell slices per wave
     const int K = lv.kcount[p * lv.ntheta + it];
     const int* __restrict__ cl = lv.cells + ((size_t)p * lv.ntheta + it) * lv.kmax;
-    int* cells_s = reinterpret_cast<int*>(small_lds + WAVE * 4);
-    for (int k = lane; k < K; k += WAVE) cells_s[k] = cl[k];
+    int* cells_s = reinterpret_cast<int*>(small_lds + NWAVES * WAVE * 4);
+    for (int k = threadIdx.x; k < K; k += NWAVES * WAVE) cells_s[k] = cl[k];
     const size_t image = (size_t)lv.fmax * lv.fpitch;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(lv.field + (size_t)p * image), (short)0, (int)(image * sizeof(uint32_t)), 0x00020000);
@@ -1581,12 +1590,13 @@ __global__ __launch_bounds__(64) void k_sweep_small(Slam2dLevel lv, int P) {
     const int u = lane % nslot, sl = lane / nslot;
     const int iy = u / nq, dx = (u - iy * nq) * 4;
     const int off = (iy * lv.fpitch + dx) * 4;
+    const int ST = S * NWAVES;                                  // slices of the whole block
     unsigned lo[4] = {0u, 0u, 0u, 0u}, hi[4] = {0u, 0u, 0u, 0u};
     __syncthreads();
-    for (int k = sl; k < K; k += 8 * S) {                       // 8 gathers in flight
+    for (int k = sl + S * wave; k < K; k += 8 * ST) {           // 8 gathers in flight
         int o[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = (active && k + i * S < K) ? off + cells_s[k + i * S] * 4 : 0x7ffffff0;
+        for (int i = 0; i < 8; ++i) o[i] = (active && k + i * ST < K) ? off + cells_s[k + i * ST] * 4 : 0x7ffffff0;
         u32x4 v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o[i], 0, 0);
@@ -1600,28 +1610,31 @@ __global__ __launch_bounds__(64) void k_sweep_small(Slam2dLevel lv, int P) {
             }
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) small_lds[e * WAVE + lane] = ((unsigned long long)hi[e] << 32) | lo[e];
+    for (int e = 0; e < 4; ++e) small_lds[(wave * 4 + e) * WAVE + lane] = ((unsigned long long)hi[e] << 32) | lo[e];
     __syncthreads();
+    Best me{-INFINITY, INT_MAX, 0};
+    if (NWAVES > 1 && wave != 0) return me;
     const double* __restrict__ pr = lv.prior + (size_t)p * 2 * npose;
     double* __restrict__ out = lv.cube + ((size_t)p * lv.ntheta + it) * npose;
     const double inv = 1.0 / lv.cost_scale;
     const int nv = lane < nslot ? min(4, nx - dx) : 0, q0 = iy * nx + dx;
     double sc[4];
-    Best me{-INFINITY, INT_MAX, 0};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         sc[e] = -INFINITY;
         if (e < nv) {
             unsigned long long acc = 0ull;
-            for (int s2 = 0; s2 < S; ++s2) acc += small_lds[e * WAVE + lane + s2 * nslot];
+            for (int w2 = 0; w2 < NWAVES; ++w2)
+                for (int s2 = 0; s2 < S; ++s2) acc += small_lds[(w2 * 4 + e) * WAVE + lane + s2 * nslot];
             const int q = q0 + e;
             sc[e] = (-((double)acc * inv) + pr[q]) + pr[npose + q];                 // :131, as k_sweep
-            out[q] = sc[e];
+            if (write) out[q] = sc[e];
             Best cand{sc[e], it * npose + q, isnan(sc[e]) ? 1 : 0};
             if (better(cand, me)) me = cand;
         }
     }
     me = wave_best_ordered(me);
+    if (!write) return me;
     double ex = 0.0;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -1632,6 +1645,95 @@ __global__ __launch_bounds__(64) void k_sweep_small(Slam2dLevel lv, int P) {
         pt.max = me.v; pt.sumexp = ex; pt.argmax = me.i; pt.has_nan = me.nan;
         lv.partials[(size_t)p * lv.npartial + it] = pt;
     }
+    return me;
+}
+// pruned != 0 (Slam2dLevel.bnb == 3, "angle bounds"): a plane whose upper bound (k_abound) lies more than SLAM2D_BNB_MARGIN
+// below the particle's seed score (k_aseed) is not scored -- it cannot hold the arg-max and all such planes together change
+// the confidence by < ntheta * 25 * exp(-30) relative; its partial says "nothing here".
+__global__ __launch_bounds__(64) void k_sweep_small(Slam2dLevel lv, int P, int pruned) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long small_lds[];   // [64 * 4] partial sums, then [kmax] cells
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int p = (slot / lv.ntheta) * 8 + xcd, it = slot % lv.ntheta;
+    if (p >= P) return;
+    if (pruned && !(lv.bounds[(size_t)p * lv.ntheta + it] >= unorder_bits(lv.bnb_best[p]) - SLAM2D_BNB_MARGIN)) {
+        if (threadIdx.x == 0) {
+            Slam2dPartial pt;
+            pt.max = -INFINITY; pt.sumexp = 0.0; pt.argmax = INT_MAX; pt.has_nan = 0;
+            lv.partials[(size_t)p * lv.npartial + it] = pt;
+        }
+        return;
+    }
+    sweep_small_plane<1>(lv, p, it, small_lds, true);
+}
+
+// Angle bounds (Slam2dLevel.bnb == 3; cubes of <= 7 x 7 poses per angle behind long cell lists, e.g. the 5 x 5 fine level of a
+// 1081-beam scan).  All poses of one angle read, at endpoint cell k, a window of <= 7 x 7 field cells that starts at the patch
+// corner; for windows of <= 5 x 5 cells it lies inside the aligned 8 x 8 block gmin2 summarises at (corner >> 2), so
+//     U(theta) = -(sum_k gmin2[cell k] << 12) / cost_scale + max(rv + thetaWeight)
+// bounds every pose of the plane: ONE 4-byte load per cell and angle, 64 cells per load instruction -- against one 16-byte
+// gather per cell and 6 poses in the exact sweep, whose time is L1 tag lookups (30 sectors per load).  One wave per
+// (particle, theta); the particle's best bound (packed with its theta) goes to seed_key for k_aseed.
+#ifndef ABOUND_STRIDE
+#define ABOUND_STRIDE 1
+#endif
+__global__ __launch_bounds__(64) void k_abound(Slam2dLevel lv, int P) {
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int p = (slot / lv.ntheta) * 8 + xcd, it = slot % lv.ntheta;
+    if (p >= P) return;
+    const int lane = threadIdx.x;
+    const int nx = 2 * lv.ncell + 1, npose = nx * nx;
+    const int gp = lv.tmax << 2;
+    const int K = lv.kcount[p * lv.ntheta + it];
+    const int* __restrict__ pcl = lv.pcells + ((size_t)p * lv.ntheta + it) * lv.kmax;
+    const __amdgpu_buffer_rsrc_t rg2 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(lv.gmin2 + (size_t)p * gp * gp), (short)0, (int)((size_t)gp * gp * sizeof(uint32_t)), 0x00020000);
+    // (Every term of the bound is <= 0, so leaving cells out keeps it an upper bound -- but using every 4th cell of the list
+    // already made it too loose to prune anything at config 5: the exact sweep went from 32 back to 156 us.  Stride 1.)
+    unsigned sum = 0u;                                     // 20-bit values, <= 2048 cells: no carry
+    const int Ks = (K + ABOUND_STRIDE - 1) / ABOUND_STRIDE;
+    for (int k0 = 0; k0 < Ks; k0 += WAVE * 8) {
+        int off[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const int k = k0 + i * WAVE + lane; off[i] = k < Ks ? pcl[k * ABOUND_STRIDE] : 0x7ffffff0; }
+        unsigned v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b32(rg2, off[i], 0, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sum += v[i];
+    }
+    sum = row16_sum_u32(sum);
+    const unsigned tot = (unsigned)__builtin_amdgcn_readlane((int)sum, 0) + (unsigned)__builtin_amdgcn_readlane((int)sum, 16) +
+                         (unsigned)__builtin_amdgcn_readlane((int)sum, 32) + (unsigned)__builtin_amdgcn_readlane((int)sum, 48);
+    // largest prior of the plane (+inf when one is NaN: np.argmax returns the first NaN, such a plane is always scored)
+    double pmx = 0.0;
+    if (!lv.fine) {
+        const double* __restrict__ pr = lv.prior + (size_t)p * 2 * npose;
+        pmx = -INFINITY;
+        for (int q = lane; q < npose; q += WAVE) { const double v = pr[q] + pr[npose + q]; pmx = isnan(v) ? INFINITY : fmax(pmx, v); }
+        pmx = wave64_max(pmx);
+    }
+    const double U = (-(((double)tot * 4096.0) / lv.cost_scale) + pmx) + 1e-9;
+    if (lane == 0) {
+        lv.bounds[(size_t)p * lv.ntheta + it] = U;
+        if (U > -INFINITY && U < INFINITY) atomicMax(&lv.seed_key[p], (order_bits(U) & ~0x3FFFull) | (unsigned long long)it);
+        else if (U == INFINITY) atomicMax(&lv.seed_key[p], (order_bits(1e300) & ~0x3FFFull) | (unsigned long long)it);
+    }
+}
+// The seed: the plane of the particle's best-bound angle, exactly; its best score is a lower bound of the cube's maximum.  One
+// 1024-thread block per particle (16 waves share the cell list: a lone wave took ~30 us for 900 cells).
+#define ASEED_WAVES 16
+__global__ __launch_bounds__(64 * ASEED_WAVES) void k_aseed(Slam2dLevel lv, int P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long small_lds[];
+    const int p = blockIdx.x;
+    const unsigned long long key = lv.seed_key[p];
+    double best = -INFINITY;                               // no finite bound anywhere: no threshold, every plane is scored
+    if (key) {                                             // (block-uniform)
+        const Best me = sweep_small_plane<ASEED_WAVES>(lv, p, (int)(key & 0x3FFF), small_lds, false);
+        if (!me.nan && me.i != INT_MAX) best = me.v;
+    }
+    if (threadIdx.x == 0) lv.bnb_best[p] = order_bits(best);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1978,14 +2080,6 @@ __global__ __launch_bounds__(64 * BOUND_GROUP) void k_bound(Slam2dLevel lv, int 
 // so ONE load instruction serves 4-5 cells.  Level 2 (k_bound2): the four 4 x 4-pose children of the few level-1 tiles that
 // survive (0.3 per theta at config 5) get their gmin2 bound; every other 4 x 4 tile's bound is -inf.  k_exact_select is
 // unchanged.  The seed: best level-1 tile -> its best child by level-2 bound -> exact.
-// u32 sum over the 16 lanes of a DPP row, in every lane
-__device__ __forceinline__ unsigned row16_sum_u32(unsigned v) {
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);
-    return v;
-}
 // level-2 bounds of the four children of level-1 tile (R, Cx): lane = (child c = lane / 16, cell slice lane % 16); returns
 // the child's bound in every lane of its row (-inf for a child outside the cube)
 __device__ __forceinline__ double children_bounds(const Slam2dLevel& lv, const __amdgpu_buffer_rsrc_t rg2, const int* __restrict__ pcl,
@@ -3100,7 +3194,11 @@ static int check_field_args(const Slam2dLevel& lv, int P, bool lazy) {
         return SLAM2D_E_BADARG;
     if (lazy && !lv.tileneed) return SLAM2D_E_BADARG;
     if (lv.tmax * lv.tmax > 28000) return SLAM2D_E_TOOLARGE;        // k_tile_triage: 32 passes, 64 KB of LDS
-    if (lv.bnb) {
+    if (lv.bnb == 3) {                                 // angle bounds: small cubes only, windows of <= 5 x 5 cells
+        const int nx = 2 * lv.ncell + 1;
+        if (!lazy || !lv.gmin || !lv.gmin2 || !lv.pcells || !lv.bounds || !lv.bnb_best || !lv.seed_key) return SLAM2D_E_BADARG;
+        if (nx > 5 || nx * ((nx + 3) / 4) > 32 || lv.tmax * 16 != lv.fpitch || lv.ntheta >= (1 << 14)) return SLAM2D_E_BADARG;
+    } else if (lv.bnb) {
         const int nx = 2 * lv.ncell + 1;
         if (!lazy || !lv.gmin || !lv.gmin2 || !lv.pcells || !lv.bounds || !lv.tile_pmax || !lv.bnb_best || !lv.prune_state)
             return SLAM2D_E_BADARG;
@@ -3210,9 +3308,17 @@ static int launch_scores(const Slam2dLevel& lv, int P, const double* d_est, int 
     const int mode = ring_chunks > 0 ? 2 : 0;
     static const bool no_small = [] { const char* e = getenv("SLAM2D_SWEEP_NOSMALL"); return e && atoi(e) == 1; }();
     if (mode == 0 && nslot <= 32 && chunks == 1 && !no_small) {           // small cube: one wave per (particle, theta) plane
+        const unsigned grid = (unsigned)cdiv(P, 8) * 8 * lv.ntheta;
+        const size_t lds = (size_t)WAVE * 4 * sizeof(unsigned long long) + (size_t)lv.kmax * sizeof(int);
+        const int pruned = lv.bnb == 3 ? 1 : 0;
+        if (pruned) {                                                     // angle bounds first, then one exact seed per particle
+            StageScope prof(SLAM2D_STAGE_BOUND, s);
+            k_abound<<<grid, WAVE, 0, s>>>(lv, P);
+            k_aseed<<<P, WAVE * ASEED_WAVES, (size_t)ASEED_WAVES * WAVE * 4 * sizeof(unsigned long long) + (size_t)lv.kmax * sizeof(int), s>>>(lv, P);
+        }
         {
             StageScope prof(SLAM2D_STAGE_SWEEP, s);
-            k_sweep_small<<<(unsigned)cdiv(P, 8) * 8 * lv.ntheta, WAVE, (size_t)WAVE * 4 * sizeof(unsigned long long) + (size_t)lv.kmax * sizeof(int), s>>>(lv, P);
+            k_sweep_small<<<grid, WAVE, lds, s>>>(lv, P, pruned);
         }
         StageScope prof(SLAM2D_STAGE_SELECT, s);
         k_select<0><<<P, WAVE, 0, s>>>(lv, 1, 1, d_est, est_stride, d_uniform, d_out);
@@ -3320,7 +3426,7 @@ int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2
     static const bool merge_scatter = [] { const char* e = getenv("SLAM2D_MERGE_SCATTER"); return !e || atoi(e) != 0; }();
     const bool merged = own && merge_scatter;
     if (lv.occ_gen < 0 || lv.occ_gen > 255) return SLAM2D_E_BADARG;
-    if (lv.bnb) {
+    if (lv.bnb && lv.bnb != 3) {
         // branch and bound over 4x4 pose tiles: tile bounds + seed tiles, surviving tiles + selection
         if (framed && (rc = launch_frames(*lidar, lv, d_maps, P, d_est, est_stride, d_flags, true, s, d_ranges))) return rc;
         launch_endpoints(*lidar, lv, P, d_est, est_stride, d_ranges, est_moving_dist, d_psi_cs, d_flags, true, false, s, framed, own, merged);

@@ -531,6 +531,14 @@ class SearchLevel:
         self.bnb_levels = 0 if not self.bnb else (int(lv_env) if lv_env in ("1", "2") else (2 if lidar.beams >= 512 else 1))
         if self.bnb_levels == 2 and self.nx < 17:
             self.bnb_levels = 1
+        # angle bounds (Slam2dLevel.bnb == 3): a cube of <= 5 x 5 poses per angle is too small for pose tiles, but behind a long
+        # cell list one gmin2 entry per cell bounds the angle's whole plane -- most angles are then never scored.  Pays where
+        # the exact sweep of the plane is expensive, i.e. ~1000-cell lists; SLAM2D_ABOUND=0 / 1 forces it off / on
+        ab_env = os.environ.get("SLAM2D_ABOUND", "auto")
+        self.abound = (not self.bnb and self.nx <= 5 and self.ntheta < (1 << 14) and bnb is not False and ab_env != "0"
+                       and (ab_env == "1" or bnb is True or lidar.beams >= 512))
+        if self.abound:
+            self.bnb_levels = 3
         # angles per k_endpoints block (the block dilates and stores its tile marks once): SLAM2D_EP_GROUP overrides
         g_env = os.environ.get("SLAM2D_EP_GROUP", "")
         self.ep_group = int(g_env) if g_env.isdigit() and int(g_env) >= 1 else (4 if lidar.beams >= 512 else 2)      # measured: 1081 beams 189 / 173 / 163 / 165 us for 1 / 2 / 4 / 8, 180 beams 22.4 / 18.7 / 19.6 for 1 / 2 / 4
@@ -566,6 +574,15 @@ class SearchLevel:
             beam_xy=torch.zeros((P, lidar.beams, 2), dtype=f64, device=device),
             sync=torch.zeros((P, _lib.SYNC_WORDS), dtype=i32, device=device),       # arrival counters (zero between launches)
         )
+        if self.abound:     # angle bounds: block minima of the field, cell offsets into them, one bound per (particle, theta)
+            t.update(
+                gmin=torch.zeros((P, 4 * self.tmax, 4 * self.tmax), dtype=i32, device=device),
+                gmin2=torch.zeros((P, 4 * self.tmax, 4 * self.tmax), dtype=i32, device=device),
+                pcells=torch.zeros((P, self.ntheta, self.kmax), dtype=i32, device=device),
+                bounds=torch.zeros((P, self.ntheta), dtype=f64, device=device),
+                bnb_best=torch.zeros(P, dtype=torch.int64, device=device),
+                seed_key=torch.zeros(P, dtype=torch.int64, device=device),
+            )
         if self.bnb:        # branch and bound over 4x4 pose tiles (include/slam2d.h)
             t.update(
                 gmin=torch.zeros((P, 4 * self.tmax, 4 * self.tmax), dtype=i32, device=device),
@@ -599,6 +616,7 @@ class SearchLevel:
             ring_cap=self.nx * ((self.nx + 3) // 4), bnb=self.bnb_levels, ep_group=self.ep_group, beam_xy=t["beam_xy"].data_ptr(),
             sync=t["sync"].data_ptr(),
             **({k: t[k].data_ptr() for k in ("gmin3d", "p3cells", "bounds1", "seed_key")} if self.bnb_levels == 2 else {}),
+            **({k: t[k].data_ptr() for k in ("gmin", "gmin2", "pcells", "bounds", "bnb_best", "seed_key")} if self.abound else {}),
             **({k: t[k].data_ptr() for k in ("gmin", "gmin2", "pcells", "bounds", "tile_pmax", "bnb_best")} if self.bnb else {}))
 
     def next_generation(self):

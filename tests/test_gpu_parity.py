@@ -1135,6 +1135,7 @@ def test_branch_and_bound_equals_brute_force(pkg, case, variant, monkeypatch):
     for bnb in (False, True):
         pf, world = _synthetic_filter(pkg, cfg, P, bnb)
         assert pf.coarse.bnb == bnb and pf.fine.bnb == (bnb and pf.fine.nx >= 9)
+        assert pf.fine.abound == (bnb and pf.fine.nx <= 5)             # 5 x 5 fine cubes: angle bounds (Slam2dLevel.bnb == 3)
         if bnb and "SLAM2D_BNB_LEVELS" in BNB_VARIANTS[variant]:
             assert pf.coarse.bnb_levels == (int(BNB_VARIANTS[variant]["SLAM2D_BNB_LEVELS"]) if pf.coarse.nx >= 17 else 1)
         if "SLAM2D_EP_GROUP" in BNB_VARIANTS[variant]:
