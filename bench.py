@@ -88,6 +88,8 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of a multi-rank run "
                     "(nccl = RCCL over xGMI; gloo: dry mode, the 24-byte all-gather hops through host memory)")
     ap.add_argument("--share-gpu", action="store_true", help="dry mode: ranks beyond the visible GPUs share them (rank r -> GPU r %% count)")
+    ap.add_argument("--groups", type=int, default=None, help="particle groups per GPU, each on its own HIP stream (default: 2 from 32 "
+                    "particles per GPU up, SLAM2D_BENCH_GROUPS overrides; 1 = one stream)")
     ap.add_argument("--spawn-check", action="store_true", help="launch plumbing only (no GPU work): every rank joins a gloo group, "
                     "rank 0 prints the rank count it saw")
     return ap.parse_args()
@@ -181,8 +183,28 @@ class HotPath:
         self.lazy = os.environ.get("SLAM2D_BENCH_FULL_FIELD", "0") != "1"   # slam2d_match vs field_build + sweep
         self.prune = False      # SLAM2D_MATCH_PRUNE_BY_PRIOR: measured separately ("variants" in the JSON line)
 
-    def match_and_update(self, s):
-        """Both levels of the scan match and the map update of all particles for scan s."""
+    # -- what tests and the accounting read, the same on HotPathGroups --
+    @property
+    def groups(self):
+        return [self]
+
+    def levels(self):
+        return [lv for lv in (self.coarse, self.fine) if lv is not None]
+
+    def maps(self):
+        return list(self.eng.maps)
+
+    def matches(self, which):
+        return self.eng.read_matches(self.m_coarse if which == "coarse" else self.m_fine).copy()
+
+    def weights(self):
+        return self.d_w.cpu().numpy().copy()
+
+    def take_flags(self):
+        return self.eng.take_flags()
+
+    def match(self, s):
+        """Both levels of the scan match of this object's particles for scan s; returns the buffer that holds the matched poses."""
         e, E = self.eng, self.E
         est, rng = self.d_est[s], self.d_ranges[s]
         if not self.lazy:
@@ -199,6 +221,22 @@ class HotPath:
             (e.match if self.lazy else e.sweep)(self.fine, self.m_coarse, E.MATCH_DOUBLES, rng, float(self.dist[s]),
                                                 None, None, self.m_fine)
             final = self.m_fine
+        return final
+
+    def update_local(self, s, final, part_ptr):
+        """Map update at the matched poses + the local half of a split normaliser ([max, sum, sum of squares] of these
+        particles' log-weights -> the three doubles at part_ptr) in one launch."""
+        E = self.E
+        E._lib.check(self.L.slam2d_grid_update_weights_local(
+            C.byref(self.eng.lidar_c), E._ptr(self.eng.d_maps), self.P, E._ptr(final), E.MATCH_DOUBLES, E._ptr(self.d_ranges[s]),
+            E._ptr(self.eng.flags), E._ptr(self.d_logw), C.c_void_p(self.m_coarse.data_ptr() + 32), E.MATCH_DOUBLES,
+            C.c_void_p(part_ptr), E._stream()), "slam2d_grid_update_weights_local")
+
+    def match_and_update(self, s):
+        """Both levels of the scan match and the map update of all particles for scan s."""
+        e, E = self.eng, self.E
+        rng = self.d_ranges[s]
+        final = self.match(s)
         if self.sharded:   # the rank-local half of the normaliser rides in the update's launch; collective + merge follow
             if self.normalizer is None:
                 self.normalizer = self.par.ShardedNormalizer(self.L, E._lib.check, self.d_logw.device, self.total_particles,
@@ -252,6 +290,130 @@ class HotPath:
         out["update"] = dict(touched_cells=int(empty.sum() + occ.sum()),
                              per_particle=8 * int(empty.sum() + occ.sum()), shared_lut=12 * lid.width ** 2)    # RMW of 4-byte cells; spoke table (4 + 8 B per window cell)
         return out
+
+
+class ScenarioView:
+    """The inputs of particles [p0, p1) of a Scenario (scan data shared)."""
+
+    def __init__(self, scen, p0, p1):
+        self.__dict__.update(scen.__dict__)
+        self.P, self.est, self.uniform = p1 - p0, scen.est[:, p0:p1], scen.uniform[:, p0:p1]
+
+
+class HotPathGroups:
+    """The same step with the rank's particles in G groups, each on its own HIP stream.
+
+    Every kernel of the step is latency-bound at 64 particles: a launch ramps up, works at a fraction of the
+    machine and drains, and on ONE stream the next launch waits for the drain.  Particles are independent during a scan
+    (Algorithm/FastSlam.py:25-27), so two half-size launch sequences on two streams fill each other's ramps and drains --
+    measured 0.152 -> 0.137 ms per scan at 64 particles (tools/exp_streams.py; four groups are host-bound).  The one thing
+    the groups share is the weight normaliser (Algorithm/FastSlam.py:30-48): every group's update launch leaves its
+    [max, sum, sum of squares] (slam2d_grid_update_weights_local), a third stream waits for all groups' updates of the scan,
+    (all-gathers the partials across ranks when sharded,) and folds them in fixed order (slam2d_weights_merge) -- the
+    sharded normaliser with groups in the role of ranks.  A group's next update waits for that merge (it rewrites the
+    log-weights the merge works on), so the groups never drift more than a scan apart; nothing else synchronises them."""
+
+    def __init__(self, cfg, P, scen, device, G):
+        assert P % G == 0 and G >= 2
+        self.cfg, self.P, self.G = cfg, P, G
+        per = P // G
+        self.subs = [HotPath(cfg, per, ScenarioView(scen, g * per, (g + 1) * per), device) for g in range(G)]
+        h0 = self.subs[0]
+        self.E, self.L, self.lidar, self.coarse, self.fine, self.lazy = h0.E, h0.L, h0.lidar, h0.coarse, h0.fine, h0.lazy
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.sharded = dist.is_initialized() and (self.world > 1 or os.environ.get("SLAM2D_FORCE_DIST") == "1")
+        self.total_particles = P * self.world
+        self.d_logw = torch.zeros(P, dtype=torch.float64, device=device)
+        self.d_w = torch.zeros(P, dtype=torch.float64, device=device)
+        self.d_stats = torch.zeros(2, dtype=torch.float64, device=device)
+        for g, sub in enumerate(self.subs):
+            sub.d_logw, sub.d_w = self.d_logw[g * per:(g + 1) * per], self.d_w[g * per:(g + 1) * per]
+        self.parts_local = torch.zeros(3 * G, dtype=torch.float64, device=device)
+        self.parts_all = torch.zeros(3 * G * self.world, dtype=torch.float64, device=device) if self.sharded else self.parts_local
+        self.via_host = self.sharded and dist.get_backend() == "gloo"
+        self.streams = [torch.cuda.Stream(device) for _ in range(G)]
+        self.norm = torch.cuda.Stream(device)
+        self.handles = [C.c_void_p(st.cuda_stream) for st in self.streams]
+        self.norm_handle = C.c_void_p(self.norm.cuda_stream)
+        self.ev_done = [C.c_void_p(self.L.slam2d_event_create()) for _ in range(G)]       # events without timing, through the C ABI
+        self.ev_merged = C.c_void_p(self.L.slam2d_event_create())
+        self.merged_once = False
+        self.prune = False
+        torch.cuda.synchronize()
+
+    @property
+    def groups(self):
+        return self.subs
+
+    def levels(self):
+        return [lv for sub in self.subs for lv in sub.levels()]
+
+    def maps(self):
+        return [m for sub in self.subs for m in sub.eng.maps]
+
+    def matches(self, which):
+        torch.cuda.synchronize()
+        return np.concatenate([sub.matches(which) for sub in self.subs])
+
+    def weights(self):
+        torch.cuda.synchronize()
+        return self.d_w.cpu().numpy().copy()
+
+    def take_flags(self):
+        torch.cuda.synchronize()
+        f = np.concatenate([sub.eng.take_flags() for sub in self.subs])
+        torch.cuda.synchronize()                 # (the flags are cleared on torch's stream, the groups run on their own)
+        return f
+
+    def algorithmic_bytes(self, scen):
+        return self.subs[0].algorithmic_bytes(scen)
+
+    def step(self, s):
+        E, L = self.E, self.L
+        try:
+            for g, sub in enumerate(self.subs):
+                E._PINNED_STREAM = self.handles[g]           # every library call of this group goes to its stream (so does the
+                sub.prune = self.prune                       # little torch does on the launch path: engine._on_launch_stream)
+                final = sub.match(s)
+                if self.merged_once:
+                    L.slam2d_stream_wait_event(self.handles[g], self.ev_merged)   # the previous scan's merge is done with the log-weights
+                sub.update_local(s, final, self.parts_local.data_ptr() + 24 * g)
+                L.slam2d_event_record(self.ev_done[g], self.handles[g])
+            for g in range(self.G):
+                L.slam2d_stream_wait_event(self.norm_handle, self.ev_done[g])
+            if self.sharded:
+                with torch.cuda.stream(self.norm):
+                    if self.via_host:                            # gloo (dry mode): the partials hop through host memory
+                        mine = self.parts_local.cpu()
+                        got = [torch.empty_like(mine) for _ in range(self.world)]
+                        dist.all_gather(got, mine)
+                        self.parts_all.copy_(torch.cat(got))
+                    else:
+                        dist.all_gather_into_tensor(self.parts_all, self.parts_local)
+            # one merge launch for all groups: their log-weights are consecutive slices of one array
+            E._lib.check(L.slam2d_weights_merge(E._ptr(self.d_logw), self.P, E._ptr(self.parts_all), self.G * self.world,
+                                                self.total_particles, E._ptr(self.d_w), E._ptr(self.d_stats), self.norm_handle),
+                         "slam2d_weights_merge")
+            L.slam2d_event_record(self.ev_merged, self.norm_handle)
+            self.merged_once = True
+        finally:
+            E._PINNED_STREAM = None
+
+
+def bench_groups(arg, P):
+    """Particle groups per GPU: --groups, else SLAM2D_BENCH_GROUPS, else 2 from 32 particles up (four groups measured host-bound)."""
+    if arg is None:
+        env = os.environ.get("SLAM2D_BENCH_GROUPS", "")
+        arg = int(env) if env.isdigit() else (2 if P >= 32 and P % 2 == 0 else 1)
+    return max(1, int(arg))
+
+
+def make_hot_path(cfg, P, scen, device, groups):
+    """groups <= 1: everything on the current stream (HotPath); else HotPathGroups."""
+    if groups and groups > 1 and P % groups == 0 and P // groups >= 8:
+        return HotPathGroups(cfg, P, scen, device, groups)
+    return HotPath(cfg, P, scen, device)
 
 
 _CPU = {}
@@ -373,6 +535,7 @@ def timed_run(hot, first, K):
     t0 = time.perf_counter()
     for s in range(first, first + K):
         hot.step(s)
+    timed_run.host_enqueue_s = time.perf_counter() - t0      # how long the host took to enqueue the block (host-bound if ~ the block)
     torch.cuda.synchronize()
     mine = time.perf_counter() - t0
     if dist.is_initialized():
@@ -388,20 +551,28 @@ def timed_run(hot, first, K):
 def level_stats(hot):
     """What the last step really touched, per level (device state read back once, outside every timed region): tiles
     blurred / filled / needed per particle, pose tiles scored exactly, mean unique endpoint cells per angle, occupied
-    field cells."""
+    field cells -- averaged over the particles of all groups."""
+    torch.cuda.synchronize()
     out = {}
-    for name, lv in (("coarse", hot.coarse), ("fine", hot.fine)):
-        if lv is None:
-            continue
-        st = {a: float(b) for a, b in lv.bnb_stats().items()}
-        need = lv.t["tileneed"].cpu().numpy().view(np.uint32)              # [P, groups, words]
-        need = np.bitwise_or.reduce(need, axis=1)
-        st["needed_tiles"] = float(np.unpackbits(need.view(np.uint8), axis=1).sum(axis=1).mean())
-        st["kbar"] = float(lv.t["kcount"].double().mean().item())
-        P, f = lv.P, lv.fmax * lv.fpitch
-        occ = lv.t["occ"][:P * f].view(P, f)
-        st["occupied_field_cells"] = float((occ == lv.c.occ_gen).sum(dim=1).double().mean().item())
-        out[name] = st
+    for name in ("coarse", "fine"):
+        acc, wsum = {}, 0
+        for sub in hot.groups:
+            lv = getattr(sub, name)
+            if lv is None:
+                continue
+            st = {a: float(b) for a, b in lv.bnb_stats().items()}
+            need = lv.t["tileneed"].cpu().numpy().view(np.uint32)              # [P, groups of angles, words]
+            need = np.bitwise_or.reduce(need, axis=1)
+            st["needed_tiles"] = float(np.unpackbits(need.view(np.uint8), axis=1).sum(axis=1).mean())
+            st["kbar"] = float(lv.t["kcount"].double().mean().item())
+            P, f = lv.P, lv.fmax * lv.fpitch
+            occ = lv.t["occ"][:P * f].view(P, f)
+            st["occupied_field_cells"] = float((occ == lv.c.occ_gen).sum(dim=1).double().mean().item())
+            for a, v in st.items():
+                acc[a] = (max(acc.get(a, 0.0), v) if a == "kept_max_per_theta" else acc.get(a, 0.0) + v * lv.P)
+            wsum += lv.P
+        if wsum:
+            out[name] = {a: (v if a == "kept_max_per_theta" else v / wsum) for a, v in acc.items()}
     return out
 
 
@@ -533,14 +704,14 @@ def side_workload(name, P, K, W, device, rank):
     """A short run of another workload for the `variants` block (same launch sequence, its own scenario)."""
     cfg = WORKLOADS[name]
     scen = Scenario(cfg, P, K + W, seed=0, rank=rank)
-    hot = HotPath(cfg, P, scen, device)
+    hot = make_hot_path(cfg, P, scen, device, bench_groups(None, P))
     for s in range(W):
         hot.step(s)
-    hot.eng.take_flags()
+    hot.take_flags()
     blocks = []
     for _ in range(3):
         blocks.append(timed_run(hot, W, K)[0])
-        hot.eng.take_flags()
+        hot.take_flags()
     el = statistics.median(blocks)
     world = dist.get_world_size() if dist.is_initialized() else 1
     rf = roofline_of(hot, scen, P, 1e3 * el / K, {}, {}, name)
@@ -642,7 +813,8 @@ def main():
             raise SystemExit(f"bench.py: the {args.backend} group holds {ranks_seen} ranks, expected {world}")
     E = importlib.import_module("slam-2d-lidar-scan_amd.engine")
     lib = E._lib.lib()
-    hot = HotPath(cfg, P, scen, device)
+    G = bench_groups(args.groups, P)
+    hot = make_hot_path(cfg, P, scen, device, G)
 
     stages = [E._lib.STAGE_SWEEP, E._lib.STAGE_BLUR, E._lib.STAGE_SCATTER, E._lib.STAGE_UPDATE,
               E._lib.STAGE_SELECT, E._lib.STAGE_ENDPOINTS, E._lib.STAGE_BOUND, E._lib.STAGE_EXACT]
@@ -659,12 +831,12 @@ def main():
     # warm-up: the first steps build every field tile (nothing is known to hold the free-space constant yet)
     for s in range(W):
         hot.step(s)
-    flags = hot.eng.take_flags()        # synchronises; raises on any fault
+    flags = hot.take_flags()        # synchronises; raises on any fault
     # a few bracketed steps (outside the timed region: an event pair costs ~5 us of stream time) find the dominant kernel
     E._lib.check(lib.slam2d_prof_enable(sum(1 << st for st in stages), 4 * 8 + 8), "prof_enable")
     for s in range(W, W + nprobe):
         hot.step(s)
-    hot.eng.take_flags()
+    hot.take_flags()
     probe_ms = collect()
     dom_stage = max(stages, key=lambda st: probe_ms.get(E._lib.STAGE_NAMES[st], {}).get("total_ms", 0.0))
     launches_per_step_of = {k: v["launches"] / nprobe for k, v in probe_ms.items()}
@@ -680,7 +852,7 @@ def main():
         E._lib.check(lib.slam2d_timer_elapsed_ms(timer, C.byref(ms)), "timer")
         pair.append(1e3 * ms.value)
     lib.slam2d_timer_destroy(timer)
-    hot.eng.take_flags()
+    hot.take_flags()
     overhead_us = statistics.median(pair)
     # timed region: R blocks of K steps, each bracketed by barrier + synchronize; only the dominant kernel keeps an event pair,
     # and only around every n-th of its launches (an event pair holds the stream for ~6 us on each side of the kernel; odd n: a
@@ -691,10 +863,11 @@ def main():
         every -= 1
     E._lib.check(lib.slam2d_prof_every(every), "prof_every")
     E._lib.check(lib.slam2d_prof_enable(1 << dom_stage, int(R * K * dom_lps) // every + 16), "prof_enable")
-    blocks, mine = [], []
+    blocks, mine, enq = [], [], []
     for _ in range(R):
         el, own = timed_run(hot, W, K)
-        flags = flags | hot.eng.take_flags()
+        enq.append(timed_run.host_enqueue_s)
+        flags = flags | hot.take_flags()
         blocks.append(el)
         mine.append(own)
     lib.slam2d_prof_disable()
@@ -706,10 +879,16 @@ def main():
     if dist.is_initialized():
         own_ms = 1e3 * statistics.median(mine) / K
         saved = hot.sharded
-        hot.sharded = False
+        hot.sharded = False                          # the same steps with every rank normalising on its own: no collective
+        if isinstance(hot, HotPathGroups):
+            hot.parts_all = hot.parts_local
+            hot.world, total_saved, hot.total_particles = 1, hot.total_particles, hot.P
         local = statistics.median([timed_run(hot, W, K)[1] for _ in range(3)])
         hot.sharded = saved
-        hot.eng.take_flags()
+        if isinstance(hot, HotPathGroups):
+            hot.world, hot.total_particles = world, total_saved
+            hot.parts_all = torch.zeros(3 * hot.G * world, dtype=torch.float64, device=device) if saved else hot.parts_local
+        hot.take_flags()
         rec = _ctl([own_ms, 1e3 * (statistics.median(mine) - local) / K], device)
         got = [torch.zeros_like(rec) for _ in range(world)]
         dist.all_gather(got, rec)
@@ -719,16 +898,16 @@ def main():
     variants = {}
     if not args.no_variants and world == 1:          # (multi-GPU scaling runs: the headline only)
         def variant(bnb, prune, note):
-            saved = [(lv, lv.c.bnb) for lv in (hot.coarse, hot.fine) if lv is not None]
+            saved = [(lv, lv.c.bnb) for lv in hot.levels()]
             for lv, _ in saved:
                 if not bnb:
                     lv.c.bnb = 0
             hot.prune = prune
             for s in range(W):
                 hot.step(s)
-            hot.eng.take_flags()
+            hot.take_flags()
             el = statistics.median([timed_run(hot, W, K)[0] for _ in range(3)])
-            hot.eng.take_flags()
+            hot.take_flags()
             for lv, v in saved:
                 lv.c.bnb = v
             hot.prune = False
@@ -763,10 +942,13 @@ def main():
                        hot.coarse.ntheta * hot.coarse.nx ** 2 + (hot.fine.ntheta * hot.fine.nx ** 2 if hot.fine else 0),
                        "pose_scoring": "branch and bound over 4x4 pose tiles (exact arg-max / draw, confidence within 2e-8)"
                        if hot.coarse.bnb else "brute-force sweep",
+                       "particle_groups_per_gpu": G if isinstance(hot, HotPathGroups) else 1,
                        "parallelism": f"particles sharded x{world}, one 24-byte-per-rank {'RCCL' if args.backend == 'nccl' else 'gloo (dry mode)'} "
-                                      "all-gather of the weight normaliser per scan" if world > 1 else "single GPU"},
+                                      "all-gather of the weight normaliser per scan" if world > 1 else
+                                      ("single GPU, two particle groups on two HIP streams + one for the normaliser's merge" if isinstance(hot, HotPathGroups) else "single GPU")},
             "scans_per_sec": K / elapsed,
-            "timed_blocks": {"repeats": R, "steps_each": K, "ms_per_step_of_each": [round(1e3 * b / K, 5) for b in blocks], "reported": "median"},
+            "timed_blocks": {"repeats": R, "steps_each": K, "ms_per_step_of_each": [round(1e3 * b / K, 5) for b in blocks], "reported": "median",
+                             "host_enqueue_ms_per_step": round(1e3 * statistics.median(enq) / K, 5)},
             "roofline": rf_main,
             "stages_probe": {k: {"avg_us": round(v["avg_us"], 2), "launches": v["launches"]} for k, v in probe_ms.items()},
             "algorithmic_bytes_per_particle_scan": hot.algorithmic_bytes(scen),

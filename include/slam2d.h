@@ -451,6 +451,14 @@ int  slam2d_prof_collect(int32_t stage, double* total_ms, int32_t* launches);
 int  slam2d_prof_every(int32_t every);
 void slam2d_prof_disable(void);
 
+/* Ordering between streams for a host driver that runs groups of particles on several HIP streams (particles are
+ * independent during a scan, Algorithm/FastSlam.py:25-27; only the weight normaliser, :30-48, joins them): events without
+ * timing.  slam2d_event_record marks a point of `stream`; slam2d_stream_wait_event makes later work of `stream` wait for it. */
+void* slam2d_event_create(void);
+void  slam2d_event_destroy(void* event);
+int   slam2d_event_record(void* event, void* stream);
+int   slam2d_stream_wait_event(void* stream, void* event);
+
 /* Timing helper for bench.py: HIP events on the caller's stream.
  * slam2d_timer_create -> opaque handle; _start/_stop record events on `stream`;
  * _elapsed_ms synchronises on the stop event and returns milliseconds. */

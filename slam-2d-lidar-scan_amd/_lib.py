@@ -139,6 +139,10 @@ SIGNATURES = {
     "slam2d_prof_collect": (C.c_int, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "slam2d_prof_every": (C.c_int, [C.c_int32]),
     "slam2d_prof_disable": (None, []),
+    "slam2d_event_create": (_vp, []),
+    "slam2d_event_destroy": (None, [_vp]),
+    "slam2d_event_record": (C.c_int, [_vp, _vp]),
+    "slam2d_stream_wait_event": (C.c_int, [_vp, _vp]),
     "slam2d_timer_create": (_vp, []),
     "slam2d_timer_destroy": (None, [_vp]),
     "slam2d_timer_start": (C.c_int, [_vp, _vp]),

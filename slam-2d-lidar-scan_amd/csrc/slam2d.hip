@@ -3665,6 +3665,16 @@ int slam2d_debug_clock(long long* out64) {
 }
 #endif
 
+// ---- ordering between streams (no timing): events a host driver uses to chain particle groups on several streams ----
+void* slam2d_event_create(void) {
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    return (void*)e;
+}
+void slam2d_event_destroy(void* event) { if (event) (void)hipEventDestroy((hipEvent_t)event); }
+int slam2d_event_record(void* event, void* stream) { return event ? (int)hipEventRecord((hipEvent_t)event, (hipStream_t)stream) : SLAM2D_E_BADARG; }
+int slam2d_stream_wait_event(void* stream, void* event) { return event ? (int)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0) : SLAM2D_E_BADARG; }
+
 // ---- plain event timer ----
 struct Timer { hipEvent_t a, b; };
 void* slam2d_timer_create(void) {

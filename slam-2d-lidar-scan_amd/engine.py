@@ -62,6 +62,24 @@ class pinned_stream:
         return False
 
 
+class _on_launch_stream:
+    """Context for the few torch operations of the launch path (occupancy-stamp reset, index upload of the bit refresh): when
+    the library calls are pinned to a stream other than torch's current one, torch must enqueue there too."""
+
+    def __enter__(self):
+        self._ctx = None
+        pinned = None if _PINNED_STREAM is None else (_PINNED_STREAM.value or 0)          # (c_void_p(0).value is None)
+        if pinned is not None and pinned != (torch.cuda.current_stream().cuda_stream or 0):
+            self._ctx = torch.cuda.stream(torch.cuda.ExternalStream(pinned))
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self._ctx is not None:
+            self._ctx.__exit__(*exc)
+        return False
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -624,7 +642,8 @@ class SearchLevel:
         image is zeroed once per 254 builds instead of at every build."""
         g = self.c.occ_gen + 1
         if g > 254:
-            self.t["occ"].zero_()
+            with _on_launch_stream():
+                self.t["occ"].zero_()
             g = 1
         self.c.occ_gen = g
 
@@ -715,9 +734,10 @@ class ParticleEngine:
         stale = [i for i, m in enumerate(self.maps) if not m.bits_valid]
         if not stale:
             return
-        idx = _dev(np.asarray(stale, dtype=np.int32), self.device)
-        check(self.L.slam2d_map_refresh_bits(_ptr(self.d_maps), _ptr(idx), len(stale), _stream()),
-              "slam2d_map_refresh_bits")
+        with _on_launch_stream():
+            idx = _dev(np.asarray(stale, dtype=np.int32), self.device)
+            check(self.L.slam2d_map_refresh_bits(_ptr(self.d_maps), _ptr(idx), len(stale), _stream()),
+                  "slam2d_map_refresh_bits")
         for i in stale:
             self.maps[i].bits_valid = True
 

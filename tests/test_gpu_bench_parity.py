@@ -55,20 +55,21 @@ def _world_variant(world, unit, w):
     return out
 
 
-def _run_against_oracle(bench, workload, P, chosen, n_scans, n_worlds=8):
+def _run_against_oracle(bench, workload, P, chosen, n_scans, n_worlds=8, groups=1):
     import torch
     synth = importlib.import_module("slam-2d-lidar-scan_amd.synth")
     cfg = bench.WORKLOADS[workload]
     device = torch.device("cuda", 0)
     scen = bench.Scenario(cfg, P, n_scans, seed=0)
-    hot = bench.HotPath(cfg, P, scen, device)
-    assert hot.lazy and not hot.sharded
+    hot = bench.make_hot_path(cfg, P, scen, device, groups)
+    assert hot.lazy and not hot.sharded and len(hot.groups) == groups
     u = cfg["unit"]
     worlds = [_world_variant(scen.world, u, w) for w in range(n_worlds)]
     world_of = [(p + p // 8) % n_worlds for p in range(P)]          # the world index is not the XCD class p % 8
     counts = [synth.counts_from_world(w) for w in worlds]
-    for p, m in enumerate(hot.eng.maps):
+    for p, m in enumerate(hot.maps()):
         m.upload(*counts[world_of[p]])
+    torch.cuda.synchronize()
     # oracle particles
     lut = so.SpokeLUT(u, cfg["max_range"], cfg["fov"], cfg["beams"])
     oracles = {}
@@ -82,11 +83,11 @@ def _run_against_oracle(bench, workload, P, chosen, n_scans, n_worlds=8):
     logw_ref = np.zeros(P)
     for s in range(n_scans):
         hot.step(s)
-        flags = hot.eng.take_flags()
+        flags = hot.take_flags()
         assert not (flags & E._lib.FATAL_FLAGS).any()
-        c = hot.eng.read_matches(hot.m_coarse).copy()
-        f = hot.eng.read_matches(hot.m_fine).copy() if hot.fine is not None else c
-        w_dev = hot.d_w.cpu().numpy().copy()
+        c = hot.matches("coarse")
+        f = hot.matches("fine") if hot.fine is not None else c
+        w_dev = hot.weights()
         # every particle: the normaliser against NumPy on the device's own log-confidences (Algorithm/FastSlam.py:43-48)
         logw_ref = logw_ref + c["log_confidence"]
         logw_ref -= np.log(np.exp(logw_ref - logw_ref.max()).sum()) + logw_ref.max()
@@ -114,7 +115,7 @@ def _run_against_oracle(bench, workload, P, chosen, n_scans, n_worlds=8):
                 np.testing.assert_allclose(c["confidence"][p], conf, rtol=RTOL)
             lc_oracle[p] = np.log(conf)
             og.updateOccupancyGrid(matched)
-            got_v, got_t = hot.eng.maps[p].download()
+            got_v, got_t = hot.maps()[p].download()
             assert np.array_equal(got_v, og.visited) and np.array_equal(got_t, og.total), f"scan {s} particle {p}: map after the update"
         # weight ratios of the oracle particles (the bar: 1e-5 relative)
         p0 = chosen[0]
@@ -125,7 +126,7 @@ def _run_against_oracle(bench, workload, P, chosen, n_scans, n_worlds=8):
     return hot
 
 
-@pytest.mark.parametrize("variant", ["default", "two_level_bounds", "P13"])
+@pytest.mark.parametrize("variant", ["default", "two_groups", "two_level_bounds", "P13"])
 def test_benchmarked_config2_matches_oracle(bench, variant, monkeypatch):
     """BASELINE config 2 as bench.py runs it (64 particles, 801^2 fields, 36 x 41 x 41 cubes, branch and bound, soft-max
     draw), 8 distinct maps, 64 distinct estimates, two consecutive scans (first build, then the steady state with
@@ -136,13 +137,17 @@ def test_benchmarked_config2_matches_oracle(bench, variant, monkeypatch):
         chosen = [0, 9, 18, 27, 36, 45, 54, 63]
     if variant == "P13":
         P, chosen = 13, [0, 5, 7, 8, 11, 12]           # a particle count that is no multiple of 8
-    hot = _run_against_oracle(bench, "config2", P, chosen, n_scans=2)
+    # "two_groups": what `python bench.py` runs by default -- the particles in two groups on two HIP streams, the normaliser's
+    # partials merged on a third (bench.HotPathGroups); three scans, so that the cross-stream ordering of the merges is exercised
+    groups = 2 if variant == "two_groups" else 1
+    hot = _run_against_oracle(bench, "config2", P, chosen, n_scans=3 if groups == 2 else 2, groups=groups)
     assert hot.coarse.bnb and hot.coarse.bnb_levels == (2 if variant == "two_level_bounds" else 1)
+    assert bench.bench_groups(None, 64) == 2
 
 
 def test_benchmarked_config5_slice_matches_oracle(bench):
     """The per-GPU slice of BASELINE config 5 as bench.py's `variants.config5` runs it: 128 particles, 2000^2 maps @ 0.05 m,
     1081 beams, coarse 139 x 41 x 41 (two-level bounds) + fine 139 x 5 x 5; 4 distinct maps; three particles in
     different XCD classes against the oracle (two-level matchScan, draw, update)."""
-    hot = _run_against_oracle(bench, "config5", 128, [3, 70, 125], n_scans=1, n_worlds=4)
+    hot = _run_against_oracle(bench, "config5", 128, [3, 70, 125], n_scans=1, n_worlds=4, groups=2)
     assert hot.coarse.bnb and hot.coarse.bnb_levels == 2
