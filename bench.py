@@ -690,7 +690,9 @@ def roofline_of(hot, scen, P, ms_per_step, stage_ms, launches_per_step_of, workl
     t = ms_per_step * 1e-3
     meas = None
     if traffic_all:
-        meas = sum(v.get("hbm_bytes_corrected", 0.0) * v.get("launches_per_step", 1.0) for k, v in traffic_all.items() if v.get("in_step"))
+        # (the PMC summary counts launches per k_grid_update launch, i.e. per scan of ONE particle group)
+        meas = sum(v.get("hbm_bytes_corrected", 0.0) * v.get("launches_per_step", 1.0) for k, v in traffic_all.items() if v.get("in_step")) \
+            * launches_per_step_of.get("k_grid_update", len(hot.groups))
     out["whole_step"] = {"processed_bytes_per_particle_scan": step_proc, "achieved": step_proc * P / t / 1e9,
                          "frac": step_proc * P / t / 1e9 / HBM_PEAK_GBS,
                          "measured_hbm_bytes_per_step": meas, "measured_hbm_frac": (meas / t / 1e9 / HBM_PEAK_GBS) if meas else None,
