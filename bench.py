@@ -223,14 +223,11 @@ class HotPath:
             final = self.m_fine
         return final
 
-    def update_local(self, s, final, part_ptr):
+    def update_local(self, s, final, part):
         """Map update at the matched poses + the local half of a split normaliser ([max, sum, sum of squares] of these
-        particles' log-weights -> the three doubles at part_ptr) in one launch."""
-        E = self.E
-        E._lib.check(self.L.slam2d_grid_update_weights_local(
-            C.byref(self.eng.lidar_c), E._ptr(self.eng.d_maps), self.P, E._ptr(final), E.MATCH_DOUBLES, E._ptr(self.d_ranges[s]),
-            E._ptr(self.eng.flags), E._ptr(self.d_logw), C.c_void_p(self.m_coarse.data_ptr() + 32), E.MATCH_DOUBLES,
-            C.c_void_p(part_ptr), E._stream()), "slam2d_grid_update_weights_local")
+        particles' log-weights -> the three doubles of `part`) in one launch."""
+        self.eng.grid_update_weights_local(final, self.E.MATCH_DOUBLES, self.d_ranges[s], self.d_logw, self.m_coarse.data_ptr() + 32,
+                                           self.E.MATCH_DOUBLES, part)
 
     def match_and_update(self, s):
         """Both levels of the scan match and the map update of all particles for scan s."""
@@ -330,6 +327,7 @@ class HotPathGroups:
         for g, sub in enumerate(self.subs):
             sub.d_logw, sub.d_w = self.d_logw[g * per:(g + 1) * per], self.d_w[g * per:(g + 1) * per]
         self.parts_local = torch.zeros(3 * G, dtype=torch.float64, device=device)
+        self.part_of = [self.parts_local[3 * g:3 * g + 3] for g in range(G)]
         self.parts_all = torch.zeros(3 * G * self.world, dtype=torch.float64, device=device) if self.sharded else self.parts_local
         self.via_host = self.sharded and dist.get_backend() == "gloo"
         self.streams = [torch.cuda.Stream(device) for _ in range(G)]
@@ -378,7 +376,7 @@ class HotPathGroups:
                 final = sub.match(s)
                 if self.merged_once:
                     L.slam2d_stream_wait_event(self.handles[g], self.ev_merged)   # the previous scan's merge is done with the log-weights
-                sub.update_local(s, final, self.parts_local.data_ptr() + 24 * g)
+                sub.update_local(s, final, self.part_of[g])
                 L.slam2d_event_record(self.ev_done[g], self.handles[g])
             for g in range(self.G):
                 L.slam2d_stream_wait_event(self.norm_handle, self.ev_done[g])

@@ -37,7 +37,8 @@
  *   (reference: two float64 arrays initialised to 1 and 2, Utils/OccupancyGrid.py:13-14;
  *    hit: visited += 2, total += 2; miss: total += 1, :148-152).  A cell is occupied
  *   iff 2*visited > total (== visited/total > 0.5, Utils/ScanMatcher_OGBased.py:29-31).
- *   Counts saturate the format after 32766 observations of one cell; the update
+ *   That format holds 32766 observations of one cell; a map that may exceed it is kept in 64-bit cells
+ *   (Slam2dMap.wide) -- the Python side promotes a map before that can happen; on a narrow map the update
  *   kernel raises SLAM2D_F_COUNT_OVERFLOW instead of wrapping.
  */
 #ifndef SLAM2D_H
@@ -82,6 +83,11 @@ typedef struct {
     uint32_t*     occ_bits;  /* [rows][bits_pitch] 1 bit per cell: occupied (2*visited > total).  Kept in
                                 step by slam2d_grid_update; after any other write to `cells` call
                                 slam2d_map_refresh_bits.  The field build reads only these bits. */
+    int32_t wide;            /* 0: cells are uint32 (visited << 16 | total).  1: cells are uint64 [rows][pitch] (visited << 32 | total),
+                                `cells` points at them: the format of a map whose counts no longer fit 16 bits (a cell observed
+                                more than ~32 000 times; the reference's float64 counts never saturate).  The host promotes a map
+                                BEFORE an update could overflow it (it knows an upper bound: every update adds at most 2) */
+    int32_t _pad;
 } Slam2dMap;
 
 /* Lidar + polar spoke lookup table shared by all particles

@@ -34,6 +34,8 @@ FLAG_NAMES = {
     F_FLOOR_REDO: "field minimum differed from the analytic floor (clamp redone)",
 }
 INIT_CELL = 0x00010002
+INIT_CELL_WIDE = (1 << 32) | 2        # the same in the 64-bit cell format (Slam2dMap.wide)
+COUNT_LIMIT = 65535                  # largest `total` a narrow cell holds
 MAX_BLUR_RADIUS = 16
 MAX_BEAMS = 2048
 SPOKE_BAND = 16
@@ -55,7 +57,7 @@ class Slam2dMap(C.Structure):
     _fields_ = [("cells", _vp), ("X", _vp), ("Y", _vp),
                 ("rows", C.c_int32), ("cols", C.c_int32), ("pitch", C.c_int32), ("bits_pitch", C.c_int32),
                 ("lim_x0", C.c_double), ("lim_x1", C.c_double), ("lim_y0", C.c_double), ("lim_y1", C.c_double),
-                ("occ_bits", _vp)]
+                ("occ_bits", _vp), ("wide", C.c_int32), ("_pad", C.c_int32)]
 
 
 class Slam2dLidar(C.Structure):

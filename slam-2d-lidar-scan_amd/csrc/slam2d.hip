@@ -412,8 +412,13 @@ __global__ __launch_bounds__(256) void k_refresh_bits(const Slam2dMap* __restric
         const int col = c0 + lane;
         bool occ = false;
         if (col < m.cols) {
-            const uint32_t v = m.cells[(size_t)row * m.pitch + col];
-            occ = 2u * (v >> 16) > (v & 0xffffu);                                  // :29-31
+            if (m.wide) {
+                const unsigned long long v = reinterpret_cast<const unsigned long long*>(m.cells)[(size_t)row * m.pitch + col];
+                occ = 2ull * (v >> 32) > (v & 0xffffffffull);
+            } else {
+                const uint32_t v = m.cells[(size_t)row * m.pitch + col];
+                occ = 2u * (v >> 16) > (v & 0xffffu);                              // :29-31
+            }
         }
         const unsigned long long mask = __ballot(occ);
         if (lane < 2 && (c0 >> 5) + lane < m.bits_pitch)
@@ -3028,6 +3033,28 @@ __global__ __launch_bounds__(256, UPDB_MIN_WAVES) void k_grid_update(Slam2dLidar
                 mxs[u] = mx; mys[u] = my;
                 at[u] = inc[u] ? (uint32_t)my * (uint32_t)m.pitch + (uint32_t)mx : 0u;     // cell 0: a harmless read
             }
+            if (m.wide) {
+                // 64-bit cells (visited << 32 | total): a map whose counts have outgrown 16 bits (the host promotes it before
+                // that can happen; the reference's float64 counts never saturate, Utils/OccupancyGrid.py:148-152)
+                unsigned long long* cells64 = reinterpret_cast<unsigned long long*>(m.cells);
+                unsigned long long c64[UPDB_UNROLL];
+#pragma unroll
+                for (int u = 0; u < UPDB_UNROLL; ++u) c64[u] = cells64[min(at[u], ncells - 1u)];
+#pragma unroll
+                for (int u = 0; u < UPDB_UNROLL; ++u) {
+                    if (!inc[u]) continue;
+                    const unsigned long long add = inc[u] == 1u ? 1ull : 0x0000000200000002ull;
+                    if (beam_shift) { atomicAdd(&cells64[at[u]], add); continue; }
+                    const unsigned long long nc = c64[u] + add;
+                    cells64[at[u]] = nc;
+                    const bool was = 2ull * (c64[u] >> 32) > (c64[u] & 0xffffffffull), is = 2ull * (nc >> 32) > (nc & 0xffffffffull);
+                    if (was != is) {
+                        uint32_t* word = m.occ_bits + (size_t)mys[u] * m.bits_pitch + (mxs[u] >> 5);
+                        if (is) atomicOr(word, 1u << (mxs[u] & 31)); else atomicAnd(word, ~(1u << (mxs[u] & 31)));
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int u = 0; u < UPDB_UNROLL; ++u) c[u] = m.cells[min(at[u], ncells - 1u)];
 #pragma unroll
@@ -3108,7 +3135,7 @@ __global__ void k_gather_maps(const Slam2dMap* __restrict__ src, const Slam2dMap
                               const int32_t* __restrict__ index) {
     const int p = blockIdx.y;
     const Slam2dMap s = src[index[p]], d = dst[p];
-    const size_t n = (size_t)s.rows * s.pitch;
+    const size_t n = (size_t)s.rows * s.pitch * (s.wide ? 2 : 1);          // 32-bit words (a wide map: two per cell)
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         d.cells[i] = s.cells[i];
 }
@@ -3122,8 +3149,15 @@ __global__ void k_map_image(const Slam2dMap* __restrict__ maps, int p, int x0, i
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int r = (int)(i / w), c = (int)(i - (long long)r * w);
         const int my = flipud ? y0 + (h - 1 - r) : y0 + r;
-        const uint32_t v = m.cells[(size_t)my * m.pitch + x0 + c];
-        const double val = 1.0 - (double)(v >> 16) / (double)(v & 0xffffu);     // ogMap = visited / total; 1 - ogMap (:173,176)
+        double vis, tot;
+        if (m.wide) {
+            const unsigned long long v = reinterpret_cast<const unsigned long long*>(m.cells)[(size_t)my * m.pitch + x0 + c];
+            vis = (double)(v >> 32); tot = (double)(v & 0xffffffffull);
+        } else {
+            const uint32_t v = m.cells[(size_t)my * m.pitch + x0 + c];
+            vis = (double)(v >> 16); tot = (double)(v & 0xffffu);
+        }
+        const double val = 1.0 - vis / tot;                                     // ogMap = visited / total; 1 - ogMap (:173,176)
         if (out) out[i] = val;
         if (out_u8) out_u8[i] = (uint8_t)rint(fmin(fmax(val, 0.0), 1.0) * 255.0);
     }

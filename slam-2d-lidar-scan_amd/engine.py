@@ -309,9 +309,14 @@ class MapState:
         self.Y = np.ascontiguousarray(Y, dtype=np.float64)
         self.rows, self.cols = len(self.Y), len(self.X)
         self.pitch = -(-self.cols // self.PITCH_ALIGN) * self.PITCH_ALIGN
-        if cells is None:
+        fresh = cells is None
+        if fresh:
             cells = torch.full((self.rows, self.pitch), _lib.INIT_CELL, dtype=torch.int32, device=device)
         self.cells = cells
+        self.wide = cells.dtype == torch.int64          # 64-bit cells (visited << 32 | total): counts beyond 16 bits
+        # upper bound of any cell's `total` (2 initially, every update adds at most 2): the engine promotes a map to wide
+        # cells before an update could overflow a narrow one.  Cells handed in from elsewhere: unknown, assume the worst
+        self.count_bound = 2 if fresh else (2 ** 31 if self.wide else _lib.COUNT_LIMIT)
         self._pending, self._defer = None, False
         self._alloc_bits()
         self._sync_coords()
@@ -347,7 +352,18 @@ class MapState:
         return Slam2dMap(cells=self.cells.data_ptr(), X=self.dX.data_ptr(), Y=self.dY.data_ptr(),
                          rows=self.rows, cols=self.cols, pitch=self.pitch, bits_pitch=self.bits_pitch,
                          lim_x0=self.lim_x[0], lim_x1=self.lim_x[1], lim_y0=self.lim_y[0], lim_y1=self.lim_y[1],
-                         occ_bits=self.bits.data_ptr())
+                         occ_bits=self.bits.data_ptr(), wide=1 if self.wide else 0)
+
+    def promote(self):
+        """To 64-bit cells (visited << 32 | total), the format of a map whose counts may exceed 16 bits (Slam2dMap.wide).
+        The reference's float64 counts never saturate (Utils/OccupancyGrid.py:148-152); this is how a long stationary log
+        keeps running.  The occupancy bits are unaffected."""
+        if self.wide:
+            return
+        self._materialise()
+        c = self.cells.to(torch.int64)
+        self.cells = (((c >> 16) & 0xFFFF) << 32) | (c & 0xFFFF)
+        self.wide = True
 
     # -- growth: expandOccupancyGridHelper (:59-89) --
     def _side_to_grow(self, x, y):                                            # :108-118
@@ -405,7 +421,7 @@ class MapState:
         old, rows, cols, dc, dr = self._pending
         self._pending = None
         self.pitch = -(-self.cols // self.PITCH_ALIGN) * self.PITCH_ALIGN
-        cells = torch.full((self.rows, self.pitch), _lib.INIT_CELL, dtype=torch.int32, device=self.device)
+        cells = torch.full((self.rows, self.pitch), _lib.INIT_CELL_WIDE if self.wide else _lib.INIT_CELL, dtype=old.dtype, device=self.device)
         cells[dr:dr + rows, dc:dc + cols] = old[:, :cols]
         self.cells = cells
         self._alloc_bits()
@@ -471,6 +487,9 @@ class MapState:
     def download(self):
         """(visited, total) as float64 host arrays, like the reference's attributes."""
         self._materialise()
+        if self.wide:
+            raw = self.cells[:, :self.cols].cpu().numpy().view(np.uint64)
+            return (raw >> np.uint64(32)).astype(np.float64), (raw & np.uint64(0xFFFFFFFF)).astype(np.float64)
         raw = self.cells[:, :self.cols].cpu().numpy().view(np.uint32)
         return (raw >> np.uint32(16)).astype(np.float64), (raw & np.uint32(0xFFFF)).astype(np.float64)
 
@@ -480,11 +499,18 @@ class MapState:
         t = np.asarray(total)
         if v.shape != (self.rows, self.cols) or t.shape != v.shape:
             raise ValueError("count arrays do not match the map shape")
-        if (v < 0).any() or (t < 0).any() or v.max() > 65535 or t.max() > 65535 or \
+        if (v < 0).any() or (t < 0).any() or max(v.max(), t.max()) >= 2 ** 31 or \
                 not (np.array_equal(v, np.rint(v)) and np.array_equal(t, np.rint(t))):
-            raise ValueError("counts must be integers in [0, 65535]")
-        packed = (v.astype(np.uint32) << np.uint32(16)) | t.astype(np.uint32)
-        self.cells[:, :self.cols] = torch.from_numpy(packed.view(np.int32)).to(self.device)
+            raise ValueError("counts must be integers in [0, 2^31)")
+        if max(v.max(), t.max()) > _lib.COUNT_LIMIT:
+            self.promote()
+        if self.wide:
+            packed = (v.astype(np.uint64) << np.uint64(32)) | t.astype(np.uint64)
+            self.cells[:, :self.cols] = torch.from_numpy(packed.view(np.int64)).to(self.device)
+        else:
+            packed = (v.astype(np.uint32) << np.uint32(16)) | t.astype(np.uint32)
+            self.cells[:, :self.cols] = torch.from_numpy(packed.view(np.int32)).to(self.device)
+        self.count_bound = max(int(t.max()), 2)
         self.bits_valid = False
 
     def clone(self):
@@ -495,6 +521,7 @@ class MapState:
         self._materialise()
         m.cells = self.cells.clone()
         m._pending, m._defer = None, False
+        m.wide, m.count_bound = self.wide, self.count_bound
         m.bits_pitch, m.bits, m.bits_valid = self.bits_pitch, self.bits.clone(), self.bits_valid
         m._sync_coords()
         m.growth_log = list(self.growth_log)
@@ -724,7 +751,34 @@ class ParticleEngine:
         self.match_buf = {}
         self.refresh_maps()
 
+    def sync_bounds(self):
+        """Credit the updates launched since the last call to the maps that received them (every update adds at most 2 to a
+        cell's `total`): to be called before maps are copied, replaced or handed to somebody else."""
+        n = getattr(self, "_pending_updates", 0)
+        if n:
+            for m in self._bound_maps:
+                m.count_bound += 2 * n
+            self._pending_updates = 0
+
+    def _rebound(self):
+        self._bound_maps = list(self.maps)
+        self._max_bound = max(m.count_bound for m in self.maps)
+
+    def _before_update(self):
+        """Move every map that the coming update could overflow (16-bit counts) to 64-bit cells first (MapState.promote) --
+        the reference's float64 counts never saturate.  O(1) per scan until then."""
+        self._pending_updates += 1
+        if self._max_bound + 2 * self._pending_updates > _lib.COUNT_LIMIT and not all(m.wide for m in self.maps):
+            self.sync_bounds()
+            for m in self.maps:
+                if m.count_bound > _lib.COUNT_LIMIT:
+                    m.promote()
+            self.refresh_maps()
+
     def refresh_maps(self):
+        self.sync_bounds()
+        self._pending_updates = 0
+        self._rebound()
         self.d_maps = upload_map_descs(self.maps, self.device)
         self.maps_version = getattr(self, "maps_version", 0) + 1      # limits / descriptors changed (growth, resample)
         self.refresh_bits()
@@ -734,6 +788,8 @@ class ParticleEngine:
         stale = [i for i, m in enumerate(self.maps) if not m.bits_valid]
         if not stale:
             return
+        self.sync_bounds()                 # the host wrote these maps (upload, growth, copy): their count bounds may have changed
+        self._rebound()
         with _on_launch_stream():
             idx = _dev(np.asarray(stale, dtype=np.int32), self.device)
             check(self.L.slam2d_map_refresh_bits(_ptr(self.d_maps), _ptr(idx), len(stale), _stream()),
@@ -775,6 +831,7 @@ class ParticleEngine:
               "slam2d_match")
 
     def grid_update(self, d_pose, stride, d_ranges, d_beam_shift=None):
+        self._before_update()
         self.refresh_bits()
         check(self.L.slam2d_grid_update(C.byref(self.lidar_c), _ptr(self.d_maps), self.P, _ptr(d_pose), stride,
                                         _ptr(d_ranges), _ptr(d_beam_shift),
@@ -785,6 +842,7 @@ class ParticleEngine:
 
     def grid_update_weights(self, d_pose, stride, d_ranges, d_logw, logconf_ptr, logconf_stride, d_w, d_stats):
         """Map update + (weight *= confidence, normalise) of all particles in one launch (slam2d_grid_update_weights)."""
+        self._before_update()
         self.refresh_bits()
         check(self.L.slam2d_grid_update_weights(C.byref(self.lidar_c), _ptr(self.d_maps), self.P, _ptr(d_pose), stride,
                                                 _ptr(d_ranges), _ptr(self.flags), _ptr(d_logw), C.c_void_p(logconf_ptr),
@@ -797,6 +855,7 @@ class ParticleEngine:
         still overlapped, merge first -- the launch writes the log-weights and the partials that merge works on."""
         if normalizer is not None:
             normalizer.pre_local()
+        self._before_update()
         self.refresh_bits()
         check(self.L.slam2d_grid_update_weights_local(C.byref(self.lidar_c), _ptr(self.d_maps), self.P, _ptr(d_pose), stride,
                                                       _ptr(d_ranges), _ptr(self.flags), _ptr(d_logw), C.c_void_p(logconf_ptr),

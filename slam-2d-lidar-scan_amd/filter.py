@@ -394,6 +394,7 @@ class ParticleFilter:
         """Bookkeeping, map update, normaliser and the (asynchronous) download of everything the host reads."""
         eng, P = self.engine, self.numParticles
         own_norm = not self.sharded
+        eng._before_update()
         _lib.check(_lib.lib().slam2d_scan_commit(
             C.byref(eng.lidar_c), _ptr(eng.d_maps), P, _ptr(self.m_fine), _ptr(self.m_coarse), _ptr(self.d_pose),
             _ptr(self.d_head), _ptr(self.d_logw), _ptr(self.d_report), _ptr(self.d_ranges), _ptr(eng.flags),
@@ -565,7 +566,7 @@ class ParticleFilter:
         """new[i] = copy of maps[idx[i]].  Maps of one extent are copied by a single gather kernel
         (slam2d_gather_maps); ragged extents fall back to per-map device copies."""
         ref = maps[0]
-        same = all((m.rows, m.cols, m.pitch) == (ref.rows, ref.cols, ref.pitch) for m in maps)
+        same = all((m.rows, m.cols, m.pitch, m.wide) == (ref.rows, ref.cols, ref.pitch, ref.wide) for m in maps)
         if not same:
             return [maps[j].clone() for j in idx]
         new = []
@@ -576,6 +577,7 @@ class ParticleFilter:
             m.rows, m.cols, m.pitch = src.rows, src.cols, src.pitch
             m.cells = torch.empty_like(src.cells)
             m._pending, m._defer = None, False
+            m.wide, m.count_bound = src.wide, src.count_bound
             m._alloc_bits()
             m._sync_coords()
             m.growth_log = list(src.growth_log)
@@ -584,7 +586,7 @@ class ParticleFilter:
         d_src, d_dst = upload_map_descs(maps, self.device), upload_map_descs(new, self.device)
         d_idx = torch.as_tensor(np.asarray(idx, dtype=np.int32), device=self.device)
         _lib.check(_lib.lib().slam2d_gather_maps(_ptr(d_src), _ptr(d_dst), _ptr(d_idx), len(new),
-                                                 ref.rows * ref.pitch, _stream()), "slam2d_gather_maps")
+                                                 ref.rows * ref.pitch * (2 if ref.wide else 1), _stream()), "slam2d_gather_maps")
         torch.cuda.current_stream().synchronize()      # the descriptor uploads must outlive the kernel
         return new
 
@@ -592,6 +594,7 @@ class ParticleFilter:
         n, P, first = self.total_particles, self.numParticles, self.first_index
         maps = self.engine.maps
         moved = not np.array_equal(np.asarray(idx), np.arange(n))
+        self.engine.sync_bounds()                     # the maps are about to be copied: their count bounds go with them
         self.stats["resamples"] += 1
         self.stats["state_moving_resamples"] += int(moved)
         if not moved:
@@ -609,14 +612,14 @@ class ParticleFilter:
             # trajectory), whatever extent its map has grown to (parallel.migrate_ragged)
             head = self.d_head.cpu().numpy()
             traj = np.stack(self.trajectory, axis=1) if self.trajectory else np.zeros((P, 0, 2))
-            aux = [parallel.pack_particle(m.X, m.Y, m.growth_log, self.prev_matched[i], head[i], traj[i]).to(self.device)
+            aux = [parallel.pack_particle(m.X, m.Y, m.growth_log, self.prev_matched[i], head[i], traj[i], m.count_bound).to(self.device)
                    for i, m in enumerate(maps)]
             cells, aux = parallel.migrate_ragged([m.cells for m in maps], aux, idx, n, self.world, self.rank, self.group)
             new_maps, poses, heads, trajs = [], [], [], []
             for c, a in zip(cells, aux):
                 o = parallel.unpack_particle(a)
                 m = MapState(o["X"], o["Y"], self.device, cells=c.contiguous())
-                m.growth_log = o["growth_log"]
+                m.growth_log, m.count_bound = o["growth_log"], o["count_bound"]
                 new_maps.append(m)
                 poses.append(o["pose"]); heads.append(o["heading"]); trajs.append(o["trajectory"])
             self.engine.maps = new_maps

@@ -170,6 +170,8 @@ class OccupancyGrid:
                 continue
             setattr(new, k, copy.deepcopy(v, memo))
         new.device, new.lidar = self.device, self.lidar
+        if self._engine is not None:
+            self._engine.sync_bounds()
         new.map = self.map.clone()
         new._engine = None
         new.version = 0

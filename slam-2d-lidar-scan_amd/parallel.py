@@ -240,7 +240,8 @@ def migrate_ragged(cells, aux, indices, total, world, rank, group=None):
     by tag).  Returns (new_cells, new_aux) for this rank's slots."""
     first, count = shard_range(total, world, rank)
     assert len(cells) == count and len(aux) == count
-    sizes = torch.tensor([[c.shape[0], c.shape[1], a.numel()] for c, a in zip(cells, aux)], dtype=torch.int64).reshape(count, 3)
+    # (the element width travels too: a map promoted to 64-bit cells, MapState.promote, keeps them on its new rank)
+    sizes = torch.tensor([[c.shape[0], c.shape[1], a.numel(), c.element_size()] for c, a in zip(cells, aux)], dtype=torch.int64).reshape(count, 4)
     table = _gather_sizes(sizes, total, world, rank, group)
     local, sends, recvs = resample_plan(indices, total, world, rank)
     new_cells, new_aux = [None] * count, [None] * count
@@ -252,9 +253,10 @@ def migrate_ragged(cells, aux, indices, total, world, rank, group=None):
         ops.append(dist.P2POp(dist.isend, _stage(cells[s].contiguous(), group), dst_rank, group=group, tag=2 * tag))
         ops.append(dist.P2POp(dist.isend, _stage(aux[s].contiguous(), group), dst_rank, group=group, tag=2 * tag + 1))
     for src_rank, d, tag in recvs:
-        rows, pitch, naux = (int(v) for v in table[int(indices[tag])])
+        rows, pitch, naux, esize = (int(v) for v in table[int(indices[tag])])
         like = cells[0] if count else None
-        cbuf = _stage(torch.empty((rows, pitch), dtype=like.dtype, device=like.device), group)
+        cbuf = _stage(torch.empty((rows, pitch), dtype=torch.int64 if esize == 8 else like.dtype if like.element_size() == esize else torch.int32,
+                                  device=like.device), group)
         abuf = _stage(torch.empty(naux, dtype=torch.float64, device=like.device), group)
         landing.append((d, cbuf, abuf))
         ops.append(dist.P2POp(dist.irecv, cbuf, src_rank, group=group, tag=2 * tag))
@@ -268,15 +270,15 @@ def migrate_ragged(cells, aux, indices, total, world, rank, group=None):
     return new_cells, new_aux
 
 
-def pack_particle(X, Y, growth_log, pose, heading, trajectory):
+def pack_particle(X, Y, growth_log, pose, heading, trajectory, count_bound=2):
     """Everything of one particle except its count map, as one float64 vector (the ``aux`` of
-    ``migrate_ragged``): [cols, rows, len(growth_log), T, pose(3), heading, trajectory (T x 2), X (cols),
+    ``migrate_ragged``): [cols, rows, len(growth_log), T, count bound, pose(3), heading, trajectory (T x 2), X (cols),
     Y (rows), growth log (n x 2)].  Small integers are exact in float64."""
     import numpy as np
     X, Y = np.asarray(X, dtype=np.float64), np.asarray(Y, dtype=np.float64)
     log = np.asarray(growth_log, dtype=np.float64).reshape(-1, 2)
     traj = np.asarray(trajectory, dtype=np.float64).reshape(-1, 2)
-    head = np.array([len(X), len(Y), len(log), len(traj)], dtype=np.float64)
+    head = np.array([len(X), len(Y), len(log), len(traj), float(count_bound)], dtype=np.float64)
     return torch.from_numpy(np.concatenate((head, np.asarray(pose, dtype=np.float64).reshape(3),
                                             [float(heading)], traj.ravel(), X, Y, log.ravel())))
 
@@ -284,8 +286,8 @@ def pack_particle(X, Y, growth_log, pose, heading, trajectory):
 def unpack_particle(aux):
     """Inverse of ``pack_particle``: dict(X, Y, growth_log, pose, heading, trajectory) of NumPy values."""
     a = aux.detach().cpu().numpy()
-    cols, rows, nlog, T = (int(v) for v in a[:4])
-    o = 4
+    cols, rows, nlog, T, bound = (int(v) for v in a[:5])
+    o = 5
     pose = a[o:o + 3].copy(); o += 3
     heading = float(a[o]); o += 1
     traj = a[o:o + 2 * T].reshape(T, 2).copy(); o += 2 * T
@@ -293,4 +295,4 @@ def unpack_particle(aux):
     Y = a[o:o + rows].copy(); o += rows
     log = [(int(s), int(n)) for s, n in a[o:o + 2 * nlog].reshape(nlog, 2)]
     assert o + 2 * nlog == a.size
-    return dict(X=X, Y=Y, growth_log=log, pose=pose, heading=heading, trajectory=traj)
+    return dict(X=X, Y=Y, growth_log=log, pose=pose, heading=heading, trajectory=traj, count_bound=bound)

@@ -1,0 +1,93 @@
+"""Counts beyond 16 bits.  The reference's count arrays are float64 and never saturate (Utils/OccupancyGrid.py:13-14,148-152);
+the packed 32-bit cell (visited << 16 | total) holds ~32 000 observations of a cell.  Before an update could overflow it the
+map moves to 64-bit cells (Slam2dMap.wide, MapState.promote): a long stationary log keeps running, and the results stay the
+reference's."""
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import slam_oracle as so
+
+pytestmark = pytest.mark.gpu
+REF_SM = (1.4, 0.25, 2, 0.1, 0.25, 0.3, 0.15, 5)
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return importlib.import_module("slam-2d-lidar-scan_amd")
+
+
+def _seeded_counts(shape, seed, hi):
+    """Counts within 10 of `hi`: a handful of updates carries every touched cell past it."""
+    rs = np.random.RandomState(seed)
+    total = rs.randint(hi - 10, hi, size=shape).astype(np.float64)
+    visited = np.floor(total * rs.uniform(0.0, 1.0, size=shape)).astype(np.float64)
+    return np.maximum(visited, 1.0), total
+
+
+def test_update_past_the_16_bit_counts_matches_the_oracle(pkg, intel_readings):
+    """A map whose cells already hold up to 65 533 observations: the next updates (every hit adds 2) cross 65 535.  The
+    drop-in classes must promote the map and keep matching the oracle's float64 arrays exactly -- counts, the matcher's view
+    of them (occupied <=> 2 visited > total) and the exported picture."""
+    r0 = intel_readings[0]
+    og = pkg.OccupancyGrid(30, 30, r0, 0.02, np.pi, 180, 10, 0.1)
+    ogo = so.GridOracle(30, 30, r0, 0.02, np.pi, 180, 10, 0.1)
+    v, t = _seeded_counts(ogo.visited.shape, 7, 65534)
+    og.set_counts(v, t)
+    ogo.visited[:], ogo.total[:] = v, t
+    assert not og.map.wide and og.map.count_bound == int(t.max())
+    sm, smo = pkg.ScanMatcher(og, *REF_SM), so.MatcherOracle(ogo, *REF_SM)
+    for i, reading in enumerate(intel_readings[:4]):
+        og.updateOccupancyGrid(reading)
+        ogo.updateOccupancyGrid(reading)
+        assert og.map.wide == (int(t.max()) + 2 * (i + 1) > 65535)
+        assert np.array_equal(og.occupancyGridVisited, ogo.visited) and np.array_equal(og.occupancyGridTotal, ogo.total)
+    assert og.map.wide and ogo.total.max() > 65535
+    # the matcher reads the occupancy bits, which the wide update keeps in step
+    est = dict(intel_readings[4])
+    got, conf = sm.matchScan(est, 0.1, None, 5)
+    want, conf_o = smo.matchScan(est, 0.1, None, 5)
+    assert (got["x"], got["y"], got["theta"]) == (want["x"], want["y"], want["theta"])
+    np.testing.assert_allclose(conf, conf_o, rtol=1e-5)
+    img = og.mapImage([r0["x"] - 4, r0["x"] + 4], [r0["y"] - 4, r0["y"] + 4])
+    xi, yi = ogo.convertRealXYToMapIdx([r0["x"] - 4, r0["x"] + 4], [r0["y"] - 4, r0["y"] + 4])
+    assert np.array_equal(img, np.flipud(1 - (ogo.visited / ogo.total)[yi[0]:yi[1], xi[0]:xi[1]]))
+    # upload of counts that need the wide format, and a deep copy of a wide map
+    import copy
+    og2 = copy.deepcopy(og)
+    assert og2.map.wide and np.array_equal(og2.occupancyGridTotal, ogo.total)
+    og3 = pkg.OccupancyGrid(30, 30, r0, 0.02, np.pi, 180, 10, 0.1)
+    og3.set_counts(ogo.visited, ogo.total)
+    assert og3.map.wide and np.array_equal(og3.occupancyGridVisited, ogo.visited)
+
+
+def test_batched_filter_promotes_and_resamples_wide_maps(pkg, intel_readings):
+    """The batched filter with maps close to the 16-bit limit: promotion inside the per-scan update, then a forced resample
+    (the gather kernel copies 64-bit cells), against oracle particles run with the same draws."""
+    u = 0.02
+    r0 = intel_readings[0]
+    ogP = [30, 30, r0, u, np.pi, 10, 180, 5 * u]
+    pf = pkg.ParticleFilter(3, ogP, list(REF_SM), rng=np.random.RandomState(3), growable=False)
+    v, t = _seeded_counts((pf.engine.maps[0].rows, pf.engine.maps[0].cols), 11, 65530)
+    for m in pf.engine.maps:
+        m.upload(v, t)
+    pf.engine.refresh_maps()
+    oracle = so.ParticleFilterOracle(3, ogP, list(REF_SM), rng=np.random.RandomState(3))
+    for p in oracle.particles:
+        p.og.visited[:], p.og.total[:] = v, t
+    for count, reading in enumerate(intel_readings[:6], start=1):
+        pf.updateParticles(reading, count)
+        oracle.updateParticles(reading, count)
+        pf.weightUnbalanced(); oracle.weightUnbalanced()
+        if count == 4:
+            idx = pf.resample()
+            assert list(idx) == list(oracle.resample())
+    assert all(m.wide for m in pf.engine.maps)
+    for i, p in enumerate(oracle.particles):
+        gv, gt = pf.engine.maps[i].download()
+        assert np.array_equal(gv, p.og.visited) and np.array_equal(gt, p.og.total), f"particle {i}"
+        assert tuple(pf.prev_matched[i]) == (p.prevMatchedReading["x"], p.prevMatchedReading["y"], p.prevMatchedReading["theta"])

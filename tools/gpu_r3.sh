@@ -15,7 +15,7 @@ echo "== $(date) stages: $*"
 for ST in "$@"; do
 case $ST in
 newtests)
-  timeout 900 python -m pytest $(ls tests/test_gpu_bench_parity.py tests/test_gpu_bench_cli.py tests/test_gpu_export.py 2>/dev/null) -m gpu -q -x -p no:cacheprovider > gpurun_out/pytest_new.log 2>&1
+  timeout 900 python -m pytest $(ls tests/test_gpu_bench_parity.py tests/test_gpu_bench_cli.py tests/test_gpu_export.py tests/test_gpu_wide_counts.py 2>/dev/null) -m gpu -q -x -p no:cacheprovider > gpurun_out/pytest_new.log 2>&1
   echo "newtests rc=$?"; tail -n 25 gpurun_out/pytest_new.log | cut -c1-400 ;;
 tests)
   timeout 1800 python -m pytest tests -m gpu -q --maxfail=30 -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
