@@ -389,6 +389,12 @@ int slam2d_grid_update_weights_local(const Slam2dLidar* lidar, const Slam2dMap* 
  *                         d_flags into d_flag_snapshot[P] with an atomic exchange, so that one asynchronous download
  *                         returns everything the host reads; a bit the update raises after the exchange stays in d_flags
  *                         and is reported with the next call.
+ *                         abort_mask (d_w != NULL only; 0: none): SLAM2D_F_* bits that void the scan.  A driver that enqueues
+ *                         the commit before it has seen the match's fault bits (the pipelined closed loop) passes
+ *                         SLAM2D_F_WINDOW_OUTSIDE_MAP: if the match raised such a bit for ANY particle -- the reference would
+ *                         have grown that map first (checkAndExapndOG, Utils/ScanMatcher_OGBased.py:27) -- the whole launch is
+ *                         a no-op (no bookkeeping, no map update, no weights; d_flag_snapshot receives the bits, d_flags keeps
+ *                         them) and the host grows the maps and runs the scan again.
  * Arguments as in the calls they bundle. */
 int slam2d_scan_match(const Slam2dLidar* lidar, const Slam2dLevel* coarse, const Slam2dLevel* fine, const Slam2dMap* d_maps,
                       int32_t P, const double* d_prev_pose, double raw_theta, double prev_raw_theta, int32_t has_turn,
@@ -398,7 +404,7 @@ int slam2d_scan_match(const Slam2dLidar* lidar, const Slam2dLevel* coarse, const
 int slam2d_scan_commit(const Slam2dLidar* lidar, const Slam2dMap* d_maps, int32_t P, const Slam2dMatch* d_fine,
                        const Slam2dMatch* d_coarse, double* d_prev_pose, double* d_heading, double* d_logw, double* d_report,
                        const double* d_ranges, uint32_t* d_flags, double* d_w, double* d_stats, uint32_t* d_flag_snapshot,
-                       void* stream);
+                       uint32_t abort_mask, void* stream);
 
 /* The same normaliser for particles sharded over several processes (one per GPU).  Rank-local
  * half: d_logw[i] += d_logconf[i * logconf_stride], then d_part[3] = [max log w, sum exp(lw - max),

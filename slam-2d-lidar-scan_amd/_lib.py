@@ -129,7 +129,7 @@ SIGNATURES = {
                                     C.c_double, C.c_double, C.c_int32, C.c_double, _vp, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp,
                                     _vp, C.c_uint32, _vp]),
     "slam2d_scan_commit": (C.c_int, [C.POINTER(Slam2dLidar), _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                     _vp, _vp]),
+                                     _vp, C.c_uint32, _vp]),
     "slam2d_weights_local": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _vp, _vp]),
     "slam2d_weights_merge": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, C.c_int64, _vp, _vp, _vp]),
     "slam2d_gather_maps": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int64, _vp]),

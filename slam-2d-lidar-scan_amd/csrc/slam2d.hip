@@ -2758,6 +2758,7 @@ struct WeightsJob {
     // slam2d_scan_commit: the same block first does the scan's bookkeeping (k_post_match's work) for all particles
     const Slam2dMatch* fine; const Slam2dMatch* coarse; double* prev; double* heading; double* report;
     double* part;            // sharded filters: only the rank-local half (k_weights_local's work), the collective follows
+    uint32_t abort_mask;     // slam2d_scan_commit: fault bits of the match that make the WHOLE launch a no-op (see there)
 };
 // pose / heading / log-weight bookkeeping of one particle after its match (Algorithm/FastSlam.py:110-117,134-135)
 __device__ __forceinline__ void post_match_one(const Slam2dMatch* __restrict__ fine, const Slam2dMatch* __restrict__ coarse, const int p,
@@ -2897,6 +2898,19 @@ __global__ __launch_bounds__(256, UPDB_MIN_WAVES) void k_grid_update(Slam2dLidar
                                                            const double* __restrict__ ranges,
                                                            const int32_t* __restrict__ beam_shift, uint32_t* flags,
                                                            int groups, WeightsJob wj) {
+    if (wj.abort_mask) {
+        // scan-level abort (slam2d_scan_commit): if the match left one of these fault bits for ANY particle -- a search window
+        // outside its map: the host has to grow the map and run the scan again -- nothing of this launch may happen: no map
+        // update, no bookkeeping, no weights.  The bits were set by earlier launches and are not cleared here, so every
+        // block reads the same.
+        bool bad = false;
+        for (int i = threadIdx.x; i < wj.N; i += blockDim.x) bad |= (flags[i] & wj.abort_mask) != 0u;
+        if (__syncthreads_or(bad)) {
+            if (blockIdx.x == 0 && wj.flag_snapshot)
+                for (int i = threadIdx.x; i < wj.N; i += blockDim.x) wj.flag_snapshot[i] = flags[i];
+            return;
+        }
+    }
     if (wj.logw && blockIdx.x == 0) {                      // one extra block: the normaliser, beside the update (one launch less;
         //                                                    block 0, so that it starts with the launch and not as its tail)
         if (wj.fine) {                                     // ... after the scan's bookkeeping (the update blocks take their
@@ -3569,7 +3583,7 @@ int slam2d_scan_match(const Slam2dLidar* lidar, const Slam2dLevel* coarse, const
 int slam2d_scan_commit(const Slam2dLidar* lidar, const Slam2dMap* d_maps, int32_t P, const Slam2dMatch* d_fine,
                        const Slam2dMatch* d_coarse, double* d_prev_pose, double* d_heading, double* d_logw, double* d_report,
                        const double* d_ranges, uint32_t* d_flags, double* d_w, double* d_stats, uint32_t* d_flag_snapshot,
-                       void* stream) {
+                       uint32_t abort_mask, void* stream) {
     if (!d_w) {                                        // sharded filters run their own normaliser (a collective sits in it)
         const int rc = slam2d_post_match(d_fine, d_coarse, P, d_prev_pose, d_heading, d_logw, d_report, stream);
         if (rc) return rc;
@@ -3582,7 +3596,7 @@ int slam2d_scan_commit(const Slam2dLidar* lidar, const Slam2dMap* d_maps, int32_
     return launch_update(lidar, d_maps, P, reinterpret_cast<const double*>(d_fine), (int)(sizeof(Slam2dMatch) / sizeof(double)), d_ranges,
                          nullptr, d_flags,
                          WeightsJob{d_logw, nullptr, 1, P, d_w, d_stats, d_flags, d_flag_snapshot, d_fine, d_coarse, d_prev_pose, d_heading,
-                                    d_report, nullptr}, stream);
+                                    d_report, nullptr, abort_mask}, stream);
 }
 
 int slam2d_weights_local(double* d_logw, const double* d_logconf, int32_t logconf_stride, int32_t N, double* d_part,

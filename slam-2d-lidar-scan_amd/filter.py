@@ -139,22 +139,21 @@ class ParticleFilter:
         self.d_head = torch.full((P,), float("nan"), dtype=torch.float64, device=dev)   # prevMatchedMovingTheta
         self.d_est = torch.zeros((P, 3), dtype=torch.float64, device=dev)
         self.d_psi = torch.zeros((P, 2), dtype=torch.float64, device=dev)
-        self.d_uniform = torch.zeros(P, dtype=torch.float64, device=dev)
-        self.d_ranges = torch.zeros(beams, dtype=torch.float64, device=dev)
-        self._h_uniform = torch.zeros(P, dtype=torch.float64).pin_memory()
-        self._h_ranges = torch.zeros(beams, dtype=torch.float64).pin_memory()
-        # the pipelined driver (run()) stages scan s while scan s-1 may still be in flight: second set of pinned buffers
-        self._h_uniform2 = torch.zeros(P, dtype=torch.float64).pin_memory()
-        self._h_ranges2 = torch.zeros(beams, dtype=torch.float64).pin_memory()
-        self._d_flagsnap = torch.zeros(P, dtype=torch.int32, device=dev)
-        self._h_flagsnap = torch.zeros(P, dtype=torch.int32).pin_memory()
+        # the scan's inputs sit in ONE device buffer ([beams ranges | P uniforms]: one H2D copy per scan), staged through two
+        # pinned host buffers (the pipelined driver, run(), stages scan s while scan s-1 may still be in flight)
+        self._d_in = torch.zeros(beams + P, dtype=torch.float64, device=dev)
+        self.d_ranges, self.d_uniform = self._d_in[:beams], self._d_in[beams:]
+        self._h_in = [torch.zeros(beams + P, dtype=torch.float64).pin_memory() for _ in range(2)]
         # everything the host reads per scan sits in ONE device buffer (one D2H copy, one synchronisation):
-        # [P x 5 report: x, y, theta, confidence, log-confidence | P normalised weights | variance, log of the weight sum]
-        self._d_pack = torch.zeros(6 * P + 2, dtype=torch.float64, device=dev)
-        self._h_pack = torch.zeros(6 * P + 2, dtype=torch.float64).pin_memory()
+        # [P x 5 report: x, y, theta, confidence, log-confidence | P normalised weights | variance, log of the weight sum | P fault-bit words]
+        self._npack = 6 * P + 2
+        self._d_pack = torch.zeros(self._npack + (P + 1) // 2, dtype=torch.float64, device=dev)
+        self._h_pack = torch.zeros(self._npack + (P + 1) // 2, dtype=torch.float64).pin_memory()
+        self._d_flagsnap = self._d_pack[self._npack:].view(torch.int32)[:P]
+        self._h_flagsnap = self._h_pack[self._npack:].view(torch.int32)[:P]
         self.d_report = self._d_pack[:5 * P].view(P, 5)
         self.d_w = self._d_pack[5 * P:6 * P]
-        self.d_stats = self._d_pack[6 * P:]
+        self.d_stats = self._d_pack[6 * P:6 * P + 2]
         self.d_w.fill_(1.0)
         self.d_logw = torch.zeros(P, dtype=torch.float64, device=dev)     # log of weight = 1 (:75)
         self._normalized_step = -1
@@ -168,10 +167,16 @@ class ParticleFilter:
         self.last_variance = None
         self._normalizer = None
         self.lazy_field = True
-        self.prune_by_prior = True      # coarse level: poses the motion prior rules out are not scored
+        # coarse level: poses the motion prior rules out are not scored (SLAM2D_MATCH_PRUNE_BY_PRIOR) -- where the cube is large
+        # enough for the two extra launches (ring, then the rest for unsettled particles) to pay: at the reference's 30 x 27 x 27
+        # cube the pruned coarse level takes 51 us against 31 us for the plain sweep (closed loop over the Intel log, round 3)
+        import os
+        from .engine import BNB_MIN_WORK
+        env = os.environ.get("SLAM2D_PRUNE", "auto")
+        self.prune_by_prior = env == "1" or (env != "0" and self.coarse.ntheta * self.coarse.nx ** 2 * beams >= BNB_MIN_WORK)
         self.step = 0
         # run(): scans redone step by step (discarded speculative match); resample(): all / those that moved any state
-        self.stats = {"redo": 0, "resamples": 0, "state_moving_resamples": 0}
+        self.stats = {"redo": 0, "aborted": 0, "resamples": 0, "state_moving_resamples": 0}
 
     # ---- odometry prior (Algorithm/FastSlam.py:77-106) ----
     def _raw_odometry(self, raw, prev_raw=None, prev_raw_heading="same"):
@@ -208,9 +213,15 @@ class ParticleFilter:
         u = src.random_sample(self.total_particles)
         return u[self.first_index:self.first_index + self.numParticles]
 
-    def _stage(self, host_buf, dev_buf, values):
-        host_buf.numpy()[...] = values
-        dev_buf.copy_(host_buf, non_blocking=True)
+    def _stage_inputs(self, which, ranges, uniforms=None):
+        """The scan's ranges (and uniforms) to the device through pinned buffer `which`: one asynchronous copy."""
+        h, B = self._h_in[which], self.lidar.beams
+        h.numpy()[:B] = ranges
+        if uniforms is None:
+            self.d_ranges.copy_(h[:B], non_blocking=True)
+        else:
+            h.numpy()[B:] = uniforms
+            self._d_in.copy_(h, non_blocking=True)
 
     # ---- Particle.update for all particles (Algorithm/FastSlam.py:25-27,122-135) ----
     def updateParticles(self, reading, count):
@@ -218,7 +229,9 @@ class ParticleFilter:
         single download at the end (poses, confidences) runs on the device without a host round
         trip; the host only decides map growth from the poses it already has."""
         eng, P, L = self.engine, self.numParticles, _lib.lib()
-        self._stage(self._h_ranges, self.d_ranges, np.asarray(reading['range'], dtype=np.float64))
+        rng_in = np.asarray(reading['range'], dtype=np.float64)
+        if count == 1 or self.match_max:
+            self._stage_inputs(0, rng_in)
         if count == 1:
             self.prev_raw_heading = None
             self.d_pose.copy_(torch.tensor([[reading['x'], reading['y'], reading['theta']]] * P, dtype=torch.float64))
@@ -234,7 +247,7 @@ class ParticleFilter:
             if self.growable:
                 self._grow_for_windows(est_xy[:, 0], est_xy[:, 1], self.coarse.reach)
             if not self.match_max:
-                self._stage(self._h_uniform, self.d_uniform, self._draw_uniforms())
+                self._stage_inputs(0, rng_in, self._draw_uniforms())
             _lib.check(L.slam2d_prior(_ptr(self.d_pose), float(reading['theta']), float(self.prev_raw['theta']),
                                       has_turn, float(turn), _ptr(self.d_head), P, _ptr(self.d_est),
                                       _ptr(self.d_psi), _stream()), "slam2d_prior")
@@ -278,17 +291,32 @@ class ParticleFilter:
 
     def _run(self, readings, first_count, force_resample, on_scan):
         eng, P = self.engine, self.numParticles
-        resamples, pending = [], None          # pending = (count, reading, raw_heading, event) of the scan in flight
+        # pending = (count, reading, raw_heading, event, state of the random stream before the scan's uniforms) of the scan in flight
+        resamples, pending = [], None
         events = [torch.cuda.Event(), torch.cuda.Event()]
 
         stream_rng = self.rng if self.rng is not None else np.random
+        # A scan is speculated without knowing whether one of its search windows leaves a map (the reference would grow that map
+        # first, Utils/ScanMatcher_OGBased.py:27): the match raises SLAM2D_F_WINDOW_OUTSIDE_MAP for such a particle and the
+        # commit, told to treat that bit as fatal for the WHOLE scan (abort_mask), does nothing at all on the device.  The host
+        # finds the bit in the scan's report, grows the maps and runs the scan again, step by step.  (Round 2 did not speculate
+        # while any window was within 2.5 m of a map's edge: 39 % of the Intel log's scans.)  Sharded filters commit in three
+        # calls around a collective and keep the conservative rule.
+        abortable = self.growable and not self.sharded
+        abort_mask = _lib.F_WINDOW_OUTSIDE_MAP if abortable else 0
+
+        def was_aborted(p):
+            """Wait for scan p's report; True if its commit was a no-op on the device (a window had left a map)."""
+            p[3].synchronize()
+            if abortable and (self._h_flagsnap.numpy().view(np.uint32) & abort_mask).any():
+                return True
+            self._check_flag_snapshot()
+            return False
 
         def finish(p):
             """Scan p's results are on the host: bookkeeping + the reference's degeneracy test.  Returns whether the
             reference resamples after this scan (the caller does it: the random stream may have to be rewound first)."""
-            count, reading, raw_heading, ev = p
-            ev.synchronize()
-            self._check_flag_snapshot()
+            count, reading, raw_heading = p[0], p[1], p[2]
             rep = self._h_pack.numpy()[:5 * P].reshape(P, 5)
             matched, conf = rep[:, 0:3].copy(), rep[:, 3].copy()
             self.trajectory.append(matched[:, :2].copy())
@@ -310,39 +338,59 @@ class ParticleFilter:
             if unb or count in force_resample:
                 resamples.append((count, self.resample()))
 
+        def discard_speculation(rng_state):
+            """Throw away what is in flight: its fault flags and its draws from the random stream."""
+            torch.cuda.current_stream().synchronize()
+            eng.flags.zero_()
+            if rng_state is not None:
+                stream_rng.set_state(rng_state)
+
+        def redo_aborted(p):
+            """Scan p was voided on the device (and so is everything enqueued after it): back to the random stream's state
+            before its uniforms, then the scan again through the calls that grow the maps."""
+            self.stats["aborted"] = self.stats.get("aborted", 0) + 1
+            discard_speculation(p[4])
+            plain(p[0], p[1])
+
         for count, reading in enumerate(readings, start=first_count):
             if count == 1 or (pending is None and self.prev_raw is None) or not self.lazy_field:
                 assert pending is None
                 plain(count, reading)
                 continue
-            if self.growable and self.prev_matched is not None:
-                # no speculation while some particle's window hugs its map's edge (judged from the poses the host
-                # already has, one or two scans old, with 1 m of slack for the motion since): the scan would very likely
-                # have to be redone step by step, and a discarded match is 0.2 ms of device time
+            if self.growable and not abortable and self.prev_matched is not None:
+                # (no device-side abort: no speculation while some particle's window hugs its map's edge, judged from the poses
+                # the host already has, one or two scans old, with 1 m of slack for the motion since)
                 slack = (self.coarse.ncell + 1) * self.coarse.step + 1.0
                 if self._outside(self.prev_matched[:, 0], self.prev_matched[:, 1], self.coarse.reach + slack).size:
                     if pending is not None:
                         prev_count = pending[0]
+                        was_aborted(pending)
                         if finish(pending):
                             resamples.append((prev_count, self.resample()))
                         pending = None
                     plain(count, reading)
                     continue
             parity = count & 1
-            hr, hu = (self._h_ranges, self._h_uniform) if parity else (self._h_ranges2, self._h_uniform2)
             if pending is None:
                 prev_raw, prev_raw_heading = self.prev_raw, self.prev_raw_heading
             else:
                 prev_raw, prev_raw_heading = pending[1], pending[2]
             dist, raw_heading, has_turn, turn = self._raw_odometry(reading, prev_raw, prev_raw_heading)
             rng_state = stream_rng.get_state()
-            self._stage(hr, self.d_ranges, np.asarray(reading['range'], dtype=np.float64))
-            if not self.match_max:
-                self._stage(hu, self.d_uniform, self._draw_uniforms())
+            state_before = rng_state
+            self._stage_inputs(parity, np.asarray(reading['range'], dtype=np.float64), None if self.match_max else self._draw_uniforms())
             self._enqueue_match(reading, prev_raw, dist, has_turn, turn)          # speculative: scan count-1 not seen yet
             redo = False
             if pending is not None:
                 prev_count = pending[0]
+                if was_aborted(pending):
+                    # scan count-1 did not happen on the device: redo it (with the growth it needs), then this scan, whose
+                    # speculative match started from a state that never was
+                    redo_aborted(pending)
+                    pending = None
+                    self.stats["redo"] += 1
+                    plain(count, reading)
+                    continue
                 if finish(pending):
                     # the reference draws the resample indices BEFORE this scan's uniforms: rewind, resample, redo the scan
                     stream_rng.set_state(rng_state)
@@ -352,26 +400,27 @@ class ParticleFilter:
                     # ... unless the draw moved nothing (always so with one particle, whose degeneracy test is always true,
                     # Algorithm/FastSlam.py:37) and the speculative match consumed no uniform (match_max): it stands as it is
                     redo = not (self.match_max and np.array_equal(np.asarray(idx), np.arange(self.total_particles)))
+                    if not redo:
+                        state_before = stream_rng.get_state()
                 pending = None
-            est_xy = self.prev_matched
-            margin = (self.coarse.ncell + 1) * self.coarse.step
-            if not redo and self.growable and self._outside(est_xy[:, 0], est_xy[:, 1], self.coarse.reach + margin).size:
-                redo = True                                                         # a window may leave a map: grow, step by step
+            if not abortable:
+                est_xy = self.prev_matched
+                margin = (self.coarse.ncell + 1) * self.coarse.step
+                if not redo and self.growable and self._outside(est_xy[:, 0], est_xy[:, 1], self.coarse.reach + margin).size:
+                    redo = True                                                     # a window may leave a map: grow, step by step
             if redo:
-                # discard the speculative match: its fault flags and its draw from the random stream
                 self.stats["redo"] += 1
-                torch.cuda.current_stream().synchronize()
-                eng.flags.zero_()
-                if rng_state is not None:
-                    stream_rng.set_state(rng_state)
+                discard_speculation(rng_state)
                 plain(count, reading)
                 continue
-            self._enqueue_commit()
+            self._enqueue_commit(abort_mask)
             ev = events[parity]
             ev.record()
-            pending = (count, reading, raw_heading, ev)
+            pending = (count, reading, raw_heading, ev, state_before)
         if pending is not None:
-            if finish(pending):
+            if was_aborted(pending):
+                redo_aborted(pending)
+            elif finish(pending):
                 resamples.append((pending[0], self.resample()))
         eng.take_flags()        # a bit the last update raised after its launch's snapshot (slam2d_scan_commit) is still there
         return resamples
@@ -390,8 +439,9 @@ class ParticleFilter:
             _ptr(self.m_fine),
             _ptr(eng.flags), _lib.MATCH_PRUNE_BY_PRIOR if self.prune_by_prior else 0, _stream()), "slam2d_scan_match")
 
-    def _enqueue_commit(self):
-        """Bookkeeping, map update, normaliser and the (asynchronous) download of everything the host reads."""
+    def _enqueue_commit(self, abort_mask=0):
+        """Bookkeeping, map update, normaliser and the (asynchronous) download of everything the host reads.  abort_mask: fault
+        bits of the match that turn the whole commit into a device-side no-op (slam2d_scan_commit)."""
         eng, P = self.engine, self.numParticles
         own_norm = not self.sharded
         eng._before_update()
@@ -399,13 +449,12 @@ class ParticleFilter:
             C.byref(eng.lidar_c), _ptr(eng.d_maps), P, _ptr(self.m_fine), _ptr(self.m_coarse), _ptr(self.d_pose),
             _ptr(self.d_head), _ptr(self.d_logw), _ptr(self.d_report), _ptr(self.d_ranges), _ptr(eng.flags),
             _ptr(self.d_w) if own_norm else None, _ptr(self.d_stats) if own_norm else None,
-            _ptr(self._d_flagsnap) if own_norm else None, _stream()), "slam2d_scan_commit")
+            _ptr(self._d_flagsnap) if own_norm else None, abort_mask if own_norm else 0, _stream()), "slam2d_scan_commit")
         if not own_norm:
             self._normalize_on_device()                 # two launches around the one all-gather of the scan
             self._d_flagsnap.copy_(eng.flags)
             eng.flags.zero_()
-        self._h_pack.copy_(self._d_pack, non_blocking=True)
-        self._h_flagsnap.copy_(self._d_flagsnap, non_blocking=True)
+        self._h_pack.copy_(self._d_pack, non_blocking=True)           # report, weights, variance AND the fault-bit snapshot
 
     def _check_flag_snapshot(self):
         f = self._h_flagsnap.numpy().view(np.uint32)
