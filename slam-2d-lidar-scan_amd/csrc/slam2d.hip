@@ -3289,11 +3289,11 @@ static void launch_field(const Slam2dLevel& lv, const Slam2dMap* d_maps, int P, 
             default: k_blur_clamp<0><<<bgrid, BLUR_THREADS, 0, s>>>(lv); break;
         }
     }
-    // gmin2 only where a tile was written (SLAM2D_GMIN2_FULL=1: over the whole frame, as before round 3); 4 blocks per particle
-    // are plenty for ~150 tiles x 25 entries
+    // gmin2 only where a tile was written (SLAM2D_GMIN2_FULL=1: over the whole frame, as before round 3)
     static const bool full = [] { const char* e = getenv("SLAM2D_GMIN2_FULL"); return e && atoi(e) == 1; }();
     const int dirty = lazy && !full ? 1 : 0;
-    const dim3 cgrid(P, lv.bnb ? (dirty ? 4 : 16) : 1);
+    static const int dblocks = [] { const char* e = getenv("SLAM2D_GMIN2_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 16; }();
+    const dim3 cgrid(P, lv.bnb ? (dirty ? dblocks : 16) : 1);
     switch (lv.blur_radius) {
         case 2: k_blur_check_redo<2><<<cgrid, 256, 0, s>>>(lv, d_flags, dirty); break;
         case 4: k_blur_check_redo<4><<<cgrid, 256, 0, s>>>(lv, d_flags, dirty); break;

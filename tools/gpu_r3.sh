@@ -22,7 +22,7 @@ tests)
   echo "tests rc=$?"; tail -n 30 gpurun_out/pytest_gpu.log | cut -c1-400 ;;
 kstat)
   for WL in config2 ref2level config5; do
-    OUT=$ROOT/gpurun_out/kstat_$WL; rm -rf $OUT
+    OUT=$ROOT/gpurun_out/kstat_$WL${KSTAT_TAG:-}; rm -rf $OUT
     ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o k -- \
         python $ROOT/bench.py --workload $WL --steps 40 --warmup 5 --no-cpu-baseline --no-variants > $OUT.log 2>&1 )
     echo "kstat $WL rc=$?"
