@@ -662,10 +662,13 @@ def roofline_of(hot, scen, P, ms_per_step, stage_ms, launches_per_step_of, workl
                        "k_exact": sum(v["exact"] for v in lev.values() if v["bnb"]), "k_grid_update": ab["update"]["per_particle"]}.get(dom, 0) * P / lps
         name = {"k_exact": "k_exact_select"}.get(dom, dom)
         tr = (traffic_all.get(name) or {}).get("hbm_bytes_corrected")
+        proc_at = (traffic_all.get(name) or {}).get("processed_bytes_at_measurement")      # of the scans the counters saw
         achieved = proc / (t_us * 1e-6) / 1e9
         out.update(kernel=dom, achieved=achieved, frac=achieved / HBM_PEAK_GBS, traffic=tr,
                    measured_hbm_frac=(tr / (t_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if tr else None,
-                   wasted=(tr / proc) if tr and proc else None, traffic_note=traffic_note,
+                   wasted=(tr / (proc_at or proc)) if tr and (proc_at or proc) else None,
+                   wasted_note="HBM traffic / processed bytes, both of the scans the PMC run measured (tile counts move along the "
+                               "trajectory)" if proc_at else None, traffic_note=traffic_note,
                    processed_bytes_per_launch=proc, avg_launch_us=t_us, avg_launch_us_with_event_pair=raw_us,
                    event_pair_overhead_us=overhead_us,
                    whole_array_convention={"bytes_per_launch": whole_array, "frac": whole_array / (t_us * 1e-6) / 1e9 / HBM_PEAK_GBS,

@@ -82,6 +82,30 @@ for wl in ("config2", "ref2level", "config5"):
                                    "hbm_bytes_corrected": (2 * k["fetch"] + k["write"]) * per_launch,
                                    "l2_hit_rate": k["hit"] / (k["hit"] + k["miss"]) if k["hit"] + k["miss"] else None,
                                    "launches_per_step": lps, "in_step": in_step, "launches_sampled": k["launches"]}
+    # what the SAME run really processed (bench.py's own accounting, from the JSON line it printed under the profiler): the
+    # tile counts move along the trajectory, so `wasted` = traffic / processed must use the bytes of the scans measured
+    try:
+        import sys
+        sys.path.insert(0, ROOT)
+        import bench
+        line = [ln for ln in open(f"gpurun_out/pmc3/{wl}/fetch.log").read().splitlines() if ln.startswith("{")][-1]
+        doc = json.loads(line)
+        pb, P = doc["roofline"]["processed_bytes_per_particle_scan"], doc["config"]["particles_per_gpu"]
+        nprobe = min(8, doc["steps"])
+        lps_of = {k: v["launches"] / nprobe for k, v in doc["stages_probe"].items()}
+        extra_stage = {"k_tile_triage": "triage", "k_blur_check_redo": "check"}
+        for base in per_kernel:
+            stage = {"k_exact_select": "k_exact"}.get(base, base)
+            if stage in lps_of:
+                proc = bench.stage_bytes_per_launch(stage, pb, P, lps_of[stage])
+            elif base in extra_stage:
+                proc = sum(v.get(extra_stage[base], 0.0) for k, v in pb.items() if k != "update") * P / max(lps_of.get("k_blur_clamp", 1.0), 1e-9)
+            else:
+                continue
+            entries[f"{wl}:{base}"]["processed_bytes_at_measurement"] = proc
+            entries[f"{wl}:{base}"]["tile_stats_at_measurement"] = doc["roofline"]["tile_stats"]
+    except Exception as exc:                               # the summaries stand without it
+        print("no processed-bytes accounting for", wl, repr(exc))
     step_total = sum(v["hbm_bytes_corrected"] * v["launches_per_step"] for kk, v in entries.items() if kk.startswith(wl + ":") and v["in_step"])
     head = (f"rocprofv3 --pmc {{FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum}} --kernel-trace -- python bench.py --workload {wl} --steps 12 --warmup 6 "
             "--repeats 1 --no-cpu-baseline --no-variants\nper-launch means after the warm-up launches; FETCH/WRITE_SIZE are KB counters (x1024 here); "
