@@ -163,6 +163,38 @@ __device__ __forceinline__ double wave64_max(double v) {
     return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 
+// Inclusive prefix sums over the 64 lanes of a wave without LDS-crossbar round trips (a __shfl_up scan of a double is twelve
+// ds_bpermute): DPP row shifts inside the four rows of 16 lanes (lanes without a source add 0), then the row totals are carried
+// across with row_bcast:15 (rows 1 and 3 <- lane 15 of the row below) and row_bcast:31 (rows 2 and 3 <- lane 31).  Fixed order.
+__device__ __forceinline__ double wave_scan_incl_f64(double v) {
+    v += dpp_f64<0x111>(v);          // row_shr:1
+    v += dpp_f64<0x112>(v);          // row_shr:2
+    v += dpp_f64<0x114>(v);          // row_shr:4
+    v += dpp_f64<0x118>(v);          // row_shr:8
+    {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0x142, 0xA, 0xF, false);        // row_bcast:15
+        const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x142, 0xA, 0xF, false);
+        v += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    }
+    {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0x143, 0xC, 0xF, false);        // row_bcast:31
+        const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x143, 0xC, 0xF, false);
+        v += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_scan_incl_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
+    return v;
+}
+
 // ------------------------------------------------------------------------------------
 // K2a  frame geometry                      (Utils/ScanMatcher_OGBased.py:21-28)
 // ------------------------------------------------------------------------------------
@@ -874,7 +906,7 @@ __global__ __launch_bounds__(256) void k_blur_check_redo(Slam2dLevel lv, uint32_
         const int* list = lv.tilelist + (size_t)p * 2 * lv.tmax * lv.tmax;
         double mx = lv.floor_value > 0.5 * lv.floor_value ? 0.0 : lv.floor_value;
         for (int i = tid; i < n; i += 256) mx = fmax(mx, lv.tilemax[(size_t)p * lv.tmax * lv.tmax + list[i]]);
-        for (int o = 1; o < WAVE; o <<= 1) mx = fmax(mx, __shfl_xor(mx, o));
+        mx = wave64_max(mx);
         if ((tid & 63) == 0) red_s[tid >> 6] = mx;
         __syncthreads();
         if (tid == 0) lv.frames[p].field_max = fmax(fmax(red_s[0], red_s[1]), fmax(red_s[2], red_s[3]));
@@ -895,7 +927,7 @@ __global__ __launch_bounds__(256) void k_blur_check_redo(Slam2dLevel lv, uint32_
     const double* __restrict__ tm = lv.tilemin + (size_t)p * lv.tmax * lv.tmax;
     double m = INFINITY;
     for (int t = tid; t < nty * ntx; t += 256) m = fmin(m, tm[(t / ntx) * lv.tmax + (t % ntx)]);
-    for (int o = 1; o < WAVE; o <<= 1) m = fmin(m, __shfl_xor(m, o));
+    m = wave64_min(m);
     if ((tid & 63) == 0) red_s[tid >> 6] = m;
     __syncthreads();
     m = fmin(fmin(red_s[0], red_s[1]), fmin(red_s[2], red_s[3]));
@@ -1329,6 +1361,17 @@ __device__ __forceinline__ double wave_sum(double v) {
     // and no LDS-crossbar round trips (all 64 lanes must be active)
     v += dpp_f64<0xB1>(v); v += dpp_f64<0x4E>(v); v += dpp_f64<0x141>(v); v += dpp_f64<0x140>(v);
     return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+// wave_best without the 6-step butterfly of three values (24 ds_bpermute) in the common case: DPP maximum, one ballot; only
+// when several lanes tie for the maximum, or a NaN is present, the full comparison decides.  Same result as wave_best.  All 64
+// lanes must be active.
+__device__ __forceinline__ Best wave_best_fast(const Best me) {
+    if (__ballot(me.nan != 0)) return wave_best(me);
+    const double m = wave64_max(me.i != INT_MAX ? me.v : -INFINITY);
+    const unsigned long long eq = __ballot(me.v == m && me.i != INT_MAX);
+    if (!eq) return Best{-INFINITY, INT_MAX, 0};
+    if ((eq & (eq - 1)) == 0ull) return Best{m, __builtin_amdgcn_readlane(me.i, __ffsll((long long)eq) - 1), 0};
+    return wave_best(me);
 }
 // wave_best for candidates whose index ascends with the lane (so "lowest index" = lowest lane): ballots and readlanes
 // instead of a 6-step butterfly of three values.  np.argmax semantics as `better`.  All 64 lanes must be active.
@@ -1767,7 +1810,7 @@ __global__ __launch_bounds__(64) void k_select(Slam2dLevel lv, int chunks, int R
         Best cand{part(w).max, part(w).argmax, part(w).has_nan};
         if (better(cand, me)) me = cand;
     }
-    me = wave_best(me);
+    me = wave_best_fast(me);
     const double M = me.v;
     if (mode == 1) {
         // a pose outside the ring scores rv + (field sum) + thetaWeight <= -100 + K * (largest field value);
@@ -1786,12 +1829,7 @@ __global__ __launch_bounds__(64) void k_select(Slam2dLevel lv, int chunks, int R
     const int w0 = lane * per, w1 = min(nW, w0 + per);
     double mine = 0.0;
     for (int w = w0; w < w1; ++w) mine += part(w).sumexp * exp(part(w).max - M);
-    double incl = mine;                           // inclusive scan over lanes
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-        const double up = __shfl_up(incl, o);
-        if (lane >= o) incl += up;
-    }
+    const double incl = wave_scan_incl_f64(mine);     // inclusive scan over lanes
     const double total = readlane_f64(incl, WAVE - 1);
     int pick = me.i;
     if (uniform != nullptr && !isnan(total)) {
@@ -1818,12 +1856,7 @@ __global__ __launch_bounds__(64) void k_select(Slam2dLevel lv, int chunks, int R
             const int q0 = iy * nx + dx, nvl = u < nslot ? min(4, nx - dx) : 0;
             double lsum = 0.0;
             for (int e = 0; e < nvl; ++e) lsum += exp(c[(size_t)it * npose + q0 + e] - M);
-            double linc = lsum;
-#pragma unroll
-            for (int o = 1; o < WAVE; o <<= 1) {
-                const double up = __shfl_up(linc, o);
-                if (lane >= o) linc += up;
-            }
+            const double linc = wave_scan_incl_f64(lsum);
             const unsigned long long hit = __ballot(nvl > 0 && run + linc > target);
             const unsigned long long have = __ballot(nvl > 0);
             const int llast = 63 - __clzll((long long)have);                      // chunk's last slot (have != 0)
@@ -1848,12 +1881,7 @@ __global__ __launch_bounds__(64) void k_select(Slam2dLevel lv, int chunks, int R
         const int a0 = qlo + lane * per2, a1 = min(qhi, a0 + per2);
         double lsum = 0.0;
         for (int q = a0; q < a1; ++q) lsum += exp(c[(size_t)it * npose + q] - M);
-        double linc = lsum;
-#pragma unroll
-        for (int o = 1; o < WAVE; o <<= 1) {
-            const double up = __shfl_up(linc, o);
-            if (lane >= o) linc += up;
-        }
+        const double linc = wave_scan_incl_f64(lsum);
         const unsigned long long hit = __ballot(run + linc > target);
         pick = it * npose + max(qlo, qhi - 1);                    // rounding fallback: chunk's last pose
         if (hit) {
@@ -2439,12 +2467,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_exact_select(Slam2dLevel lv, con
         for (int i = tid; i < lv.ntheta * lv.kmax; i += XS_THREADS) cells_s[i] = call[i];
     }
     const int cnt = __popc(keepbits);
-    int incl = cnt;
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-        const int up = __shfl_up(incl, o);
-        if (lane >= o) incl += up;
-    }
+    const int incl = wave_scan_incl_i32(cnt);
     if (lane == WAVE - 1) wtot_s[wave] = incl;
     if (tid < lv.ntheta) { kc_s[tid] = lv.kcount[p * lv.ntheta + tid]; S_s[tid] = 0.0; }
     if (tid == 0) { M_s[0] = -INFINITY; Mi_s[0] = INT_MAX; Mi_s[1] = 0; }
@@ -2544,7 +2567,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_exact_select(Slam2dLevel lv, con
     int n = 0;
     for (int base = 0; base < n_all; base += XS_TILES) {           // (block-uniform)
         n = min(XS_TILES, n_all - base);
-        build_list(base);
+        if (!(SPLIT && n_all <= XS_TILES)) build_list(base);       // (a single pass: the list of the scoring phase is still there)
         if (tid < lv.ntheta) jn_s[tid] = 0;
         __syncthreads();
         DBG_CLOCK(10, p == 0 && base == 0);
@@ -2588,7 +2611,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_exact_select(Slam2dLevel lv, con
             if (wave < XS_TILES / WAVE) {                // thread = tile
                 Best bme{-INFINITY, INT_MAX, 0};
                 if (tid < n && targ_s[tid] != INT_MAX) bme = Best{tmax_s[tid], targ_s[tid], tnan_s[tid]};
-                bme = wave_best(bme);
+                bme = wave_best_fast(bme);
                 if (lane == 0) { wbv_s[wave] = bme.v; wbi_s[wave] = bme.i; wbn_s[wave] = bme.nan; }
             }
             __syncthreads();
@@ -2641,12 +2664,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_exact_select(Slam2dLevel lv, con
     const int w0 = lane * tper, w1 = min(nW, w0 + tper);
     double mine = 0.0;
     for (int w = w0; w < w1; ++w) mine += S_s[w];
-    double cinc = mine;
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-        const double up = __shfl_up(cinc, o);
-        if (lane >= o) cinc += up;
-    }
+    const double cinc = wave_scan_incl_f64(mine);
     const double total = readlane_f64(cinc, WAVE - 1);
     int pick = Mi_s[0];
     if (uniform != nullptr && !isnan(total)) {
@@ -2688,12 +2706,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_exact_select(Slam2dLevel lv, con
                         for (int e = 0; e < 4 && 4 * bx + e < nx; ++e) lsum += exp(load_score(&c[lane * nx + 4 * bx + e], SPLIT) - M);
                     }
         }
-        double linc = lsum;
-#pragma unroll
-        for (int o = 1; o < WAVE; o <<= 1) {
-            const double up = __shfl_up(linc, o);
-            if (lane >= o) linc += up;
-        }
+        const double linc = wave_scan_incl_f64(lsum);
         const unsigned long long hit = __ballot(has && run + linc > target);
         const unsigned long long have = __ballot(has);
         if (have) {
