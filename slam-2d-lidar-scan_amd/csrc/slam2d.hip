@@ -732,6 +732,14 @@ __global__ __launch_bounds__(TRIAGE_THREADS) void k_tile_triage(Slam2dLevel lv, 
     uint32_t* need_s = reinterpret_cast<uint32_t*>(tri_lds + 2 * ntile4);
     const uint8_t stamp = occ_stamp(lv);
     uint8_t* state = lv.tilestate + (size_t)p * ntile;
+    // every global load of the kernel's first half is issued before the first barrier -- flags, states AND the first words of
+    // the needed-tile slices: the kernel is a chain of round trips, this makes it one instead of two
+    constexpr int PRE = 4;
+    const uint32_t* __restrict__ sl = need_slice(lv, p, 0, nneed);
+    const int nsl = lazy ? nneed * need_slices(lv) : 0;
+    uint32_t pre[PRE];
+#pragma unroll
+    for (int u = 0; u < PRE; ++u) { const int i = tid + u * TRIAGE_THREADS; pre[u] = i < nsl ? sl[i] : 0u; }
     {
         const uint8_t* tiles = lv.tilemask + (size_t)p * ntile;
         for (int t = tid; t < ntile; t += TRIAGE_THREADS) { tiles_s[t] = tiles[t] == stamp; state_s[t] = state[t]; }
@@ -740,8 +748,10 @@ __global__ __launch_bounds__(TRIAGE_THREADS) void k_tile_triage(Slam2dLevel lv, 
     if (tid < 2) base[tid] = 0;
     __syncthreads();
     if (lazy) {                                            // the particle's needed tiles: OR over the theta slices
-        const uint32_t* __restrict__ sl = need_slice(lv, p, 0, nneed);
-        for (int i = tid; i < nneed * need_slices(lv); i += TRIAGE_THREADS) {
+#pragma unroll
+        for (int u = 0; u < PRE; ++u)
+            if (pre[u]) { const int w = (tid + u * TRIAGE_THREADS) % nneed; if ((need_s[w] & pre[u]) != pre[u]) atomicOr(&need_s[w], pre[u]); }
+        for (int i = tid + PRE * TRIAGE_THREADS; i < nsl; i += TRIAGE_THREADS) {
             const uint32_t v = sl[i];
             if (v) { const int w = i % nneed; if ((need_s[w] & v) != v) atomicOr(&need_s[w], v); }
         }
