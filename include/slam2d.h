@@ -167,7 +167,7 @@ typedef struct {
     Slam2dFrame* frames;     /* [P] */
     int32_t* axis_x;         /* [P][wmax] field column of every window map column */
     int32_t* axis_y;         /* [P][wmax] */
-    uint8_t* occ;            /* [P][fmax][fpitch] occupied field cells; then [P][tmax][tmax] tile flags (16x16 cells) */
+    uint8_t* occ;            /* [P][fmax][fpitch] occupied field cells; then [P][2 tmax][fp] block flags (8 x 8 cells), fp = (2 tmax + 17) & ~15 */
     uint32_t* field;         /* [P][fmax][fpitch]  fixed-point cost of probSP (see above) */
     int32_t* cells;          /* [P][ntheta][kmax] unique endpoint cells (patch-corner offsets) */
     int32_t* kcount;         /* [P][ntheta] */
@@ -176,8 +176,10 @@ typedef struct {
     Slam2dPartial* partials; /* [P][npartial] per-wave reductions of the cube (sweep -> select) */
     int32_t npartial;        /* capacity per particle: ntheta * ceil(ny*nx / 64) */
     int32_t tmax;            /* ceil(fmax / 16): 16x16-cell tiles per field edge */
-    uint8_t* tilemask;       /* [P][tmax][tmax] tile holds an occupied field cell (stamped like occ; must follow occ
-                                contiguously: one memset clears both when occ_gen == 0) */
+    uint8_t* tilemask;       /* [P][2 tmax][fp], fp = (2 tmax + 17) & ~15 (the bytes beyond 2 tmax of a row are never written): the 8 x 8-cell block holds an occupied field cell (stamped like occ; must follow
+                                occ contiguously: one memset clears both when occ_gen == 0).  Four flags per blur tile: at a blur
+                                radius of 8 a tile's halo is exactly its 4 x 4 blocks, so the triage lists exactly the tiles whose
+                                halo holds a wall */
     uint8_t* tilestate;      /* [P][tmax][tmax] PERSISTENT across calls: 0 = the field tile already holds
                                 the free-space constant (no rewrite needed), 1 = dirty/unknown.
                                 Initialise to 1; set to 1 whenever the field buffer is written by

@@ -21,6 +21,9 @@
 #define WAVE 64
 #define BLUR_TILE 16                 // field tile edge of the blur (power of two: BLUR_SHIFT)
 #define BLUR_SHIFT 4
+#define FLAG_SHIFT 3                 // occupancy flags are kept per 8 x 8-cell block (four per tile): with a blur radius of 8 the halo of
+//                                      a tile is exactly its 4 x 4 blocks, so "a wall nearby" is decided exactly (3 x 3 tile flags listed
+//                                      24-60 % of tiles whose halo then turned out empty)
 
 // ------------------------------------------------------------------------------------
 // stage profiling (bench.py): optional HIP-event pairs around selected kernels
@@ -79,6 +82,11 @@ __device__ __forceinline__ double unorder_bits(unsigned long long k) {
     unsigned long long b = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
     return __longlong_as_double((long long)b);
 }
+// Block flags of one particle: [2 tmax][flag_pitch] bytes, the pitch a multiple of 16 with at least two unused (never
+// written, hence never "set") bytes at the end of every row: the triage copies rows with 16-byte loads and reads the byte left
+// of a row's first flag from the padding of the row above.
+__host__ __device__ __forceinline__ int flag_pitch(const Slam2dLevel& lv) { return ((lv.tmax << 1) + 17) & ~15; }
+__host__ __device__ __forceinline__ size_t flag_bytes(const Slam2dLevel& lv) { return (size_t)(lv.tmax << 1) * flag_pitch(lv); }
 // The occupied-field image and the tile flags are not cleared between builds: a cell / tile is
 // occupied when its byte equals the build's generation stamp (Slam2dLevel.occ_gen, 1..255).
 __device__ __forceinline__ uint8_t occ_stamp(const Slam2dLevel& lv) { return (uint8_t)(lv.occ_gen ? lv.occ_gen : 1); }
@@ -315,7 +323,8 @@ __global__ __launch_bounds__(256) void k_occ_scatter(Slam2dLevel lv, const Slam2
     if (col_base < fr.mx0) edge &= ~0u << (fr.mx0 - col_base);                    // window edges
     if (col_base + 32 > fr.mx1) edge &= ~0u >> (col_base + 32 - fr.mx1);
     uint8_t* occ = lv.occ + (size_t)p * lv.fmax * lv.fpitch;
-    uint8_t* tiles = lv.tilemask + (size_t)p * lv.tmax * lv.tmax;
+    uint8_t* tiles = lv.tilemask + (size_t)p * flag_bytes(lv);                // flags of 8 x 8-cell blocks, [2 tmax][flag_pitch]
+    const int fpad = flag_pitch(lv);
     const uint8_t stamp = occ_stamp(lv);
     const int half = lane >> 5, bit = lane & 31;
 #pragma unroll
@@ -338,7 +347,7 @@ __global__ __launch_bounds__(256) void k_occ_scatter(Slam2dLevel lv, const Slam2
                 const int fx = ax_s[col - fr.mx0];
                 if (fx >= 0 && fy >= 0) {                                          // :36-37
                     occ[(size_t)fy * lv.fpitch + fx] = stamp;
-                    tiles[(fy >> BLUR_SHIFT) * lv.tmax + (fx >> BLUR_SHIFT)] = stamp;
+                    tiles[(fy >> FLAG_SHIFT) * fpad + (fx >> FLAG_SHIFT)] = stamp;
                 }
             }
         }
@@ -404,7 +413,8 @@ __device__ __forceinline__ void scatter_role(const Slam2dLidar& lid, const Slam2
     if (col_base < fr.mx0) edge &= ~0u << (fr.mx0 - col_base);                    // window edges
     if (col_base + 32 > fr.mx1) edge &= ~0u >> (col_base + 32 - fr.mx1);
     uint8_t* occ = lv.occ + (size_t)p * lv.fmax * lv.fpitch;
-    uint8_t* tiles = lv.tilemask + (size_t)p * lv.tmax * lv.tmax;
+    uint8_t* tiles = lv.tilemask + (size_t)p * flag_bytes(lv);                // flags of 8 x 8-cell blocks, [2 tmax][flag_pitch]
+    const int fpad = flag_pitch(lv);
     const uint8_t stamp = occ_stamp(lv);
     const int half = lane >> 5, bit = lane & 31;
 #pragma unroll
@@ -426,7 +436,7 @@ __device__ __forceinline__ void scatter_role(const Slam2dLidar& lid, const Slam2
                 const int fx = ax_s[col - fr.mx0];
                 if (fx >= 0 && fy >= 0) {                                          // :36-37
                     occ[(size_t)fy * lv.fpitch + fx] = stamp;
-                    tiles[(fy >> BLUR_SHIFT) * lv.tmax + (fx >> BLUR_SHIFT)] = stamp;
+                    tiles[(fy >> FLAG_SHIFT) * fpad + (fx >> FLAG_SHIFT)] = stamp;
                 }
             }
         }
@@ -503,15 +513,15 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
     const uint8_t* occ = lv.occ + (size_t)p * lv.fmax * lv.fpitch;
     const uint8_t stamp = occ_stamp(lv);
     uint8_t* state = lv.tilestate + ((size_t)p * lv.tmax + tby) * lv.tmax + tbx;
-    // activity: an occupied cell within the halo (r <= 16 = tile edge) lies in one of the 3x3 tiles around
+    // activity: an occupied cell within the halo lies in one of the 8 x 8-cell blocks within ceil(r / 8) blocks of the tile's four
     int any = 1;
     if (use_flags) {
         any = 0;
-        const uint8_t* tiles = lv.tilemask + (size_t)p * lv.tmax * lv.tmax;
-        const int nty = (fh + BLUR_TILE - 1) >> BLUR_SHIFT, ntx = (fw + BLUR_TILE - 1) >> BLUR_SHIFT;
-        if (tid < 9) {
-            const int yy = tby + tid / 3 - 1, xx = tbx + tid % 3 - 1;
-            if (yy >= 0 && yy < nty && xx >= 0 && xx < ntx) any = tiles[yy * lv.tmax + xx] == stamp;
+        const uint8_t* tiles = lv.tilemask + (size_t)p * flag_bytes(lv);
+        const int nsy = (fh + 7) >> FLAG_SHIFT, nsx = (fw + 7) >> FLAG_SHIFT, k = (r + 7) >> FLAG_SHIFT, e = 2 + 2 * k;
+        if (tid < e * e) {
+            const int yy = 2 * tby - k + tid / e, xx = 2 * tbx - k + tid % e;
+            if (yy >= 0 && yy < nsy && xx >= 0 && xx < nsx) any = tiles[yy * flag_pitch(lv) + xx] == stamp;
         }
         any = __syncthreads_or(any);
     }
@@ -706,6 +716,24 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
     DBG_CLOCK(54, dbg);
 }
 
+// A free tile is the free-space constant: one wave, 64 lanes x 16 bytes = the tile's 256 cells (the whole tile, also beyond
+// the current frame, so that the tile stays valid when the frame grows by its +-1 jitter), and its 4 x 4 block minima.
+__device__ __forceinline__ uint32_t fill_value(const Slam2dLevel& lv) {
+    const double v = lv.floor_value;
+    return v > 0.5 * v ? 0u : (uint32_t)rint(-v * lv.cost_scale);
+}
+__device__ __forceinline__ void fill_tile(const Slam2dLevel& lv, int p, int t, int lane, const uint32_t c) {
+    uint32_t* field = lv.field + (size_t)p * lv.fmax * lv.fpitch;
+    const int ty0 = (t / lv.tmax) * BLUR_TILE, tx0 = (t % lv.tmax) * BLUR_TILE;
+    const int y = lane >> 2, x = (lane & 3) * 4;
+    if (ty0 + y < lv.fmax && tx0 + x + 3 < lv.fpitch)
+        *reinterpret_cast<uint4*>(field + (size_t)(ty0 + y) * lv.fpitch + tx0 + x) = make_uint4(c, c, c, c);
+    if (lv.bnb && lane < 16) {                             // the tile's 4 x 4 block minima (branch and bound)
+        const int gp = lv.tmax << 2;
+        lv.gmin[((size_t)p * gp + (ty0 >> 2) + (lane >> 2)) * gp + (tx0 >> 2) + (lane & 3)] = c;
+    }
+}
+
 // Tile triage, one 1024-thread block per particle looping over its 16x16 field tiles:
 //  * tiles with an occupied cell in their 3x3 tile neighbourhood go to the blur work list;
 //  * free tiles get their minimum recorded and, if the field buffer does not already hold the
@@ -719,17 +747,27 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
 __global__ __launch_bounds__(TRIAGE_THREADS) void k_tile_triage(Slam2dLevel lv, int lazy) {
     // tile flags, tile states and the needed-tile bitmap of the particle are staged in LDS with one batch
     // of coalesced loads; everything after that runs out of LDS (the kernel is pure latency otherwise)
-    extern __shared__ __attribute__((aligned(16))) uint8_t tri_lds[];     // [ntile4] flags, [ntile4] states, [nneed] words
+    extern __shared__ __attribute__((aligned(16))) uint8_t tri_lds[];     // block flag bits, [ntile4] states, [nneed] words, [ntile] fill list
     __shared__ int base[2];
     const int p = blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    DBG_CLOCK(20, p == 0);
     const Slam2dFrame fr = lv.frames[p];
     const int nty = (fr.fh + BLUR_TILE - 1) >> BLUR_SHIFT, ntx = (fr.fw + BLUR_TILE - 1) >> BLUR_SHIFT;
     const int ntile = lv.tmax * lv.tmax, ntile4 = (ntile + 3) & ~3, nneed = (ntile + 31) >> 5;
     const int iters = (ntile + TRIAGE_THREADS - 1) / TRIAGE_THREADS;          // <= 32 (checked by the host)
-    uint8_t* tiles_s = tri_lds;
-    uint8_t* state_s = tri_lds + ntile4;
-    uint32_t* need_s = reinterpret_cast<uint32_t*>(tri_lds + 2 * ntile4);
+    // the block flags as BITS in LDS -- one 16-bit word per 16-byte load, rows of `rw` words with a zero word in front, kb zero
+    // rows above and below -- and, per tile row, the OR of the 2 + 2 kb flag rows its halo spans: a tile's test is one shift of
+    // two words of its row (byte flags and a 4 x 4 window of LDS reads per tile cost three times the kernel's compute)
+    const int kb = (lv.blur_radius + 7) >> FLAG_SHIFT;     // blocks the blur radius reaches beyond a tile (<= 2)
+    const int fp = flag_pitch(lv), frows = lv.tmax << 1;
+    const int rw = (fp >> 4) + 1, rw1 = rw + 1;
+    uint16_t* bits_s = reinterpret_cast<uint16_t*>(tri_lds);                     // [kb + frows + kb][rw]
+    uint16_t* rows_s = bits_s + (((frows + 2 * kb) * rw + 1) & ~1);              // [tmax][rw + 1] (a zero word at the end)
+    const int fbytes = (2 * ((((frows + 2 * kb) * rw + 1) & ~1) + lv.tmax * rw1) + 15) & ~15;
+    uint8_t* state_s = tri_lds + fbytes;
+    uint32_t* need_s = reinterpret_cast<uint32_t*>(tri_lds + fbytes + ntile4);
+    uint16_t* fill_s = reinterpret_cast<uint16_t*>(need_s + nneed);             // [ntile] the fill list
     const uint8_t stamp = occ_stamp(lv);
     uint8_t* state = lv.tilestate + (size_t)p * ntile;
     // every global load of the kernel's first half is issued before the first barrier -- flags, states AND the first words of
@@ -741,12 +779,25 @@ __global__ __launch_bounds__(TRIAGE_THREADS) void k_tile_triage(Slam2dLevel lv, 
 #pragma unroll
     for (int u = 0; u < PRE; ++u) { const int i = tid + u * TRIAGE_THREADS; pre[u] = i < nsl ? sl[i] : 0u; }
     {
-        const uint8_t* tiles = lv.tilemask + (size_t)p * ntile;
-        for (int t = tid; t < ntile; t += TRIAGE_THREADS) { tiles_s[t] = tiles[t] == stamp; state_s[t] = state[t]; }
+        const uint4* tq = reinterpret_cast<const uint4*>(lv.tilemask + (size_t)p * flag_bytes(lv));     // (rows of fp bytes, fp % 16 == 0)
+        const int qpr = fp >> 4, nq = frows * qpr;
+        for (int i = tid; i < nq; i += TRIAGE_THREADS) {
+            const uint4 v = tq[i];
+            // bytes 0 / 1 -> one bit each: the multiplier moves byte k's bit 0 to bit 24 + k (no two partial products meet)
+            const uint32_t m = ((bytes_equal(v.x, stamp) * 0x01020408u) >> 24) | (((bytes_equal(v.y, stamp) * 0x01020408u) >> 24) << 4) |
+                               (((bytes_equal(v.z, stamp) * 0x01020408u) >> 24) << 8) | (((bytes_equal(v.w, stamp) * 0x01020408u) >> 24) << 12);
+            const int row = i / qpr;
+            bits_s[(kb + row) * rw + 1 + (i - row * qpr)] = (uint16_t)m;
+        }
+        for (int i = tid; i < frows; i += TRIAGE_THREADS) bits_s[(kb + i) * rw] = 0;
+        for (int i = tid; i < kb * rw; i += TRIAGE_THREADS) { bits_s[i] = 0; bits_s[(kb + frows) * rw + i] = 0; }
+        for (int t = tid; t < ntile; t += TRIAGE_THREADS) state_s[t] = state[t];
         if (lazy) for (int w = tid; w < nneed; w += TRIAGE_THREADS) need_s[w] = 0u;
     }
     if (tid < 2) base[tid] = 0;
+    DBG_CLOCK(21, p == 0);
     __syncthreads();
+    DBG_CLOCK(22, p == 0);
     if (lazy) {                                            // the particle's needed tiles: OR over the theta slices
 #pragma unroll
         for (int u = 0; u < PRE; ++u)
@@ -755,27 +806,34 @@ __global__ __launch_bounds__(TRIAGE_THREADS) void k_tile_triage(Slam2dLevel lv, 
             const uint32_t v = sl[i];
             if (v) { const int w = i % nneed; if ((need_s[w] & v) != v) atomicOr(&need_s[w], v); }
         }
-        __syncthreads();
     }
+    for (int i = tid; i < lv.tmax * rw1; i += TRIAGE_THREADS) {                // the flag rows of a tile row's halo, ORed
+        const int ty = i / rw1, j = i - ty * rw1;
+        uint32_t v = 0u;
+        if (j < rw) for (int k = 0; k < 2 + 2 * kb; ++k) v |= bits_s[(2 * ty + k) * rw + j];
+        rows_s[i] = (uint16_t)v;
+    }
+    __syncthreads();
+    DBG_CLOCK(23, p == 0);
     uint32_t liveb = 0u, anyb = 0u;
     int has_free = 0;
     for (int it = 0; it < iters; ++it) {
         const int t = it * TRIAGE_THREADS + tid;
         const int ty = t / lv.tmax, tx = t - ty * lv.tmax;
         if (t < ntile && ty < nty && tx < ntx) {
-            int any = 0;
-#pragma unroll
-            for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const int yy = ty + dy, xx = tx + dx;
-                    if (yy >= 0 && yy < nty && xx >= 0 && xx < ntx) any |= tiles_s[yy * lv.tmax + xx];
-                }
+            // a wall within the blur radius of the tile <=> an occupied 8 x 8 block within kb blocks of the tile's four (flags
+            // beyond the frame and the border read 0)
+            // flag columns 2 tx - kb .. 2 tx + 1 + kb of the tile row's OR (bit 16 of the row = flag column 0)
+            const int bit = 2 * tx - kb + 16;
+            const uint16_t* r16 = rows_s + ty * rw1 + (bit >> 4);
+            const int any = (((uint32_t)r16[0] | ((uint32_t)r16[1] << 16)) >> (bit & 15)) & ((1u << (2 + 2 * kb)) - 1u);
             liveb |= 1u << it;
             if (any) anyb |= 1u << it; else has_free = 1;
         }
     }
+    DBG_CLOCK(24, p == 0);
     has_free = __syncthreads_or(has_free);
+    DBG_CLOCK(25, p == 0);
     // one free tile pins the field minimum (:43) to the analytic floor: k_blur_check_redo has nothing to do
     if (tid == 0) lv.frames[p].min_known = has_free;
     const bool everything = !lazy || !has_free;
@@ -799,30 +857,21 @@ __global__ __launch_bounds__(TRIAGE_THREADS) void k_tile_triage(Slam2dLevel lv, 
             int start = 0;
             if (lane == 0) start = atomicAdd(&base[which], __popcll(mask));
             start = __builtin_amdgcn_readfirstlane(start);
-            if (mine[which]) list[which * ntile + start + __popcll(mask & below)] = t;
+            if (mine[which]) {
+                list[which * ntile + start + __popcll(mask & below)] = t;
+                if (which) fill_s[start + __popcll(mask & below)] = (uint16_t)t;           // (t < 32 * 1024)
+            }
         }
     }
+    DBG_CLOCK(26, p == 0);
     __syncthreads();
     if (tid < 2) lv.tilecount[2 * p + tid] = base[tid];
-    // fill: one wave per tile, 64 lanes x 16 bytes = the tile's 256 cells (the whole tile, also beyond the
-    // current frame, so that the tile stays valid when the frame grows by its +-1 jitter)
+    DBG_CLOCK(27, p == 0);
+    // fill: one wave per tile, the tiles from the LDS copy of the list
     const int nfill = base[1];
-    const double v = lv.floor_value;
-    const uint32_t c = v > 0.5 * v ? 0u : (uint32_t)rint(-v * lv.cost_scale);
-    uint32_t* field = lv.field + (size_t)p * lv.fmax * lv.fpitch;
-    for (int b = wave; b < nfill; b += TRIAGE_THREADS / 64) {
-        const int t = list[ntile + b];
-        const int ty0 = (t / lv.tmax) * BLUR_TILE, tx0 = (t % lv.tmax) * BLUR_TILE;
-        const int y = lane >> 2, x = (lane & 3) * 4;
-        if (ty0 + y < lv.fmax && tx0 + x + 3 < lv.fpitch)
-            *reinterpret_cast<uint4*>(field + (size_t)(ty0 + y) * lv.fpitch + tx0 + x) = make_uint4(c, c, c, c);
-        if (lv.bnb && lane < 16) {                         // the tile's 4 x 4 block minima (branch and bound)
-            const int gp = lv.tmax << 2;
-            lv.gmin[((size_t)p * gp + (ty0 >> 2) + (lane >> 2)) * gp + (tx0 >> 2) + (lane & 3)] = c;
-        }
-    }
+    const uint32_t c = fill_value(lv);
+    for (int b = wave; b < nfill; b += TRIAGE_THREADS / 64) fill_tile(lv, p, fill_s[b], lane, c);
 }
-
 
 // Blur of the work list: gridDim.x one-wave blocks per particle walk that particle's active tiles.
 #ifndef BLUR_MIN_WAVES
@@ -3264,7 +3313,7 @@ static int check_field_args(const Slam2dLevel& lv, int P, bool lazy) {
     if (lv.tilemask != lv.occ + (size_t)P * lv.fmax * lv.fpitch || !lv.tilestate || !lv.tilemin || !lv.tilemax || !lv.tilelist || !lv.tilecount)
         return SLAM2D_E_BADARG;
     if (lazy && !lv.tileneed) return SLAM2D_E_BADARG;
-    if (lv.tmax * lv.tmax > 28000) return SLAM2D_E_TOOLARGE;        // k_tile_triage: 32 passes, 64 KB of LDS
+    if (lv.tmax * lv.tmax > 28000) return SLAM2D_E_TOOLARGE;        // k_tile_triage: 32 passes, 5 bytes of LDS per tile (144 KB)
     if (lv.bnb == 3) {                                 // angle bounds: small cubes only, windows of <= 5 x 5 cells
         const int nx = 2 * lv.ncell + 1;
         if (!lazy || !lv.gmin || !lv.gmin2 || !lv.pcells || !lv.bounds || !lv.bnb_best || !lv.seed_key) return SLAM2D_E_BADARG;
@@ -3289,7 +3338,7 @@ static int launch_frames(const Slam2dLidar& lid, const Slam2dLevel& lv, const Sl
     k_frame_axis<<<dim3(cdiv(lv.wmax, 256), P, 2), 256, 0, s>>>(lid, lv, d_maps, d_centre, centre_stride, d_flags, d_ranges);
     if (lv.occ_gen < 0 || lv.occ_gen > 255) return SLAM2D_E_BADARG;
     if (lv.occ_gen != 0) return 0;                     // generation stamps: nothing to clear
-    return (int)hipMemsetAsync(lv.occ, 0, (size_t)P * lv.fmax * lv.fpitch + (size_t)P * lv.tmax * lv.tmax, s);
+    return (int)hipMemsetAsync(lv.occ, 0, (size_t)P * lv.fmax * lv.fpitch + (size_t)P * flag_bytes(lv), s);
 }
 
 // occupied cells -> field image, tile triage (+ fill), blur + clamp, minimum check
@@ -3300,7 +3349,17 @@ static void launch_field(const Slam2dLevel& lv, const Slam2dMap* d_maps, int P, 
         k_occ_scatter<<<dim3(cdiv(cdiv(lv.wmax, 32) + 1, 64), cdiv(lv.wmax, SCATTER_ROWS), P), dim3(64, 4), (size_t)lv.wmax * sizeof(int32_t), s>>>(lv, d_maps);
     }
     const int ntile = lv.tmax * lv.tmax;
-    k_tile_triage<<<P, TRIAGE_THREADS, (size_t)2 * ((ntile + 3) & ~3) + 4 * ((ntile + 31) / 32), s>>>(lv, lazy ? 1 : 0);
+    {
+        const int kb = (lv.blur_radius + 7) >> FLAG_SHIFT;
+        const int rw = (flag_pitch(lv) >> 4) + 1;
+        const size_t lds = (size_t)((2 * ((((2 * lv.tmax + 2 * kb) * rw + 1) & ~1) + lv.tmax * (rw + 1)) + 15) & ~15) + ((ntile + 3) & ~3) + 4 * ((ntile + 31) / 32) + 2 * (size_t)ntile;
+        static size_t lds_allowed = 64 * 1024;
+        if (lds > lds_allowed) {                       // more than the default dynamic LDS limit: ask once (160 KB per CU on gfx950)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_triage), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+            lds_allowed = 160 * 1024 - 512;
+        }
+        k_tile_triage<<<P, TRIAGE_THREADS, lds, s>>>(lv, lazy ? 1 : 0);
+    }
     {
         StageScope prof(SLAM2D_STAGE_BLUR, s);
         static const int blur_blocks = [] { const char* e = getenv("SLAM2D_BLUR_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : SLAM2D_BLUR_BLOCKS_PER_PARTICLE; }();

@@ -599,8 +599,8 @@ class SearchLevel:
             frames=torch.zeros((P, C.sizeof(Slam2dFrame)), dtype=torch.uint8, device=device),
             axis_x=torch.zeros((P, self.wmax), dtype=i32, device=device),
             axis_y=torch.zeros((P, self.wmax), dtype=i32, device=device),
-            # occupied-cell image of every particle, followed by the 16x16 tile flags (generation-stamped bytes)
-            occ=torch.zeros(P * self.fmax * self.fpitch + P * self.tmax * self.tmax, dtype=torch.uint8, device=device),
+            # occupied-cell image of every particle, followed by the flags of its 8 x 8-cell blocks (generation-stamped bytes)
+            occ=torch.zeros(P * self.fmax * self.fpitch + P * 2 * self.tmax * ((2 * self.tmax + 17) & ~15), dtype=torch.uint8, device=device),
             field=torch.zeros((P, self.fmax, self.fpitch), dtype=i32, device=device),     # uint32 costs
             cells=torch.zeros((P, self.ntheta, self.kmax), dtype=i32, device=device),
             kcount=torch.zeros((P, self.ntheta), dtype=i32, device=device),

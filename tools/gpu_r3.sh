@@ -44,7 +44,7 @@ multi)
   timeout 600 python bench.py --gpus 2 --backend gloo --share-gpu --steps 20 --warmup 5 --no-variants > gpurun_out/bench_gpus2.json 2> gpurun_out/bench_gpus2.err
   echo "bench --gpus 2 (one GPU shared) rc=$?"; cut -c1-900 gpurun_out/bench_gpus2.json; tail -n 5 gpurun_out/bench_gpus2.err ;;
 clock)
-  timeout 600 SLAM2D_BENCH_GROUPS=1 python tools/dbg_clock.py config2 64 > gpurun_out/dbg_clock.log 2>&1
+  SLAM2D_BENCH_GROUPS=1 timeout 600 python tools/dbg_clock.py config2 64 > gpurun_out/dbg_clock.log 2>&1
   echo "clock rc=$?"; tail -n 12 gpurun_out/dbg_clock.log ;;
 pmc)
   for WL in ${PMC_WL:-config2 ref2level config5}; do
