@@ -548,7 +548,7 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
                     if (idx < ext * wpr) {
                         const int ly = idx / wpr, lw = idx - ly * wpr;
                         const uint32_t e = bytes_equal(v[i], stamp);
-                        *reinterpret_cast<uint32_t*>(&sm.occ[ly][4 * lw]) = e;
+                        *reinterpret_cast<uint32_t*>(&sm.occ[ly][4 * lw]) = e ^ 0x01010101u;                 // (RAD > 0: the LDS image holds 1 = free)
                         exact |= (e != 0u);
                     }
                 }
@@ -577,7 +577,7 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
                 if (idx < EXT_C * EXT_C) {
                     const int ly = idx / EXT_C, lx = idx - ly * EXT_C;
                     const uint8_t o = v[i] == stamp;
-                    sm.occ[ly][lx] = o;
+                    sm.occ[ly][lx] = o ^ 1;
                     exact |= o;
                 }
             }
@@ -625,14 +625,21 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
             static_assert(2 * EXT_C <= BLUR_THREADS, "one wave covers the axis-0 pass only for RAD <= 8");
             const int lx = tid % EXT_C, g = tid / EXT_C;
             if (g < 2) {
-                double f[8 + 2 * RAD];
+                // The inputs are 0.0 (occupied) or L, so a tap's pair sum is 0, L or 2L and its product with the weight is 0, L w or
+                // 2 (L w) EXACTLY: with f = 0 / 1 and lw = L * w the tap is fma(f_a + f_b, lw, acc) -- the product inside is exact,
+                // the one rounding is the sum's, as in SciPy's acc + (a + b) * w -- two operations instead of three.  (The centre term
+                // is selected, not multiplied: 0.0 * lw would be -0.0.)
+                double f[8 + 2 * RAD], lw[RAD + 1];
 #pragma unroll
-                for (int k = 0; k < 8 + 2 * RAD; ++k) f[k] = sm.occ[g * 8 + k][lx] ? 0.0 : L;
+                for (int k = 0; k < 8 + 2 * RAD; ++k) f[k] = __hiloint2double((int)((uint32_t)sm.occ[g * 8 + k][lx] * 0x3FF00000u), 0);     // 1 = free -> 1.0 (a
+                    // v_cvt_f64_u32 here costs the kernel 17 VGPRs and a third of its waves)
+#pragma unroll
+                for (int j = 0; j <= RAD; ++j) lw[j] = L * w[j];
 #pragma unroll
                 for (int o = 0; o < 8; ++o) {
-                    double acc = f[o + RAD] * w[RAD];
+                    double acc = f[o + RAD] != 0.0 ? lw[RAD] : 0.0;
 #pragma unroll
-                    for (int j = -RAD; j < 0; ++j) acc = acc + (f[o + RAD + j] + f[o + RAD - j]) * w[RAD + j];
+                    for (int j = -RAD; j < 0; ++j) acc = __builtin_fma(f[o + RAD + j] + f[o + RAD - j], lw[RAD + j], acc);
                     sm.mid[g * 8 + o][lx] = acc;
                 }
             }
@@ -653,12 +660,13 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
                 const int gy = ty0 + y, gx = tx0 + x0 + o;
                 if (gy < fh && gx < fw) {
                     lmin = fmin(lmin, acc);
-                    lmax = fmax(lmax, acc > thr ? 0.0 : acc);
+                    lmax = fmax(lmax, acc);                // (clamped after the loop: the clamp is monotone)
                     const uint32_t cst = acc > thr ? 0u : (uint32_t)rint(-acc * lv.cost_scale);
                     field[(size_t)gy * lv.fpitch + gx] = cst;
                     cmin = min(cmin, cst);
                 }
             }
+            if (lmax > thr) lmax = 0.0;
             if (lv.bnb) {                                  // rows y, y^1, y^2, y^3 of the block sit in lanes tid ^ 4, ^ 8
                 cmin = min(cmin, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)cmin, 0x124, 0xF, 0xF, false));   // row_ror:4
                 cmin = min(cmin, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)cmin, 0x128, 0xF, 0xF, false));   // row_ror:8
