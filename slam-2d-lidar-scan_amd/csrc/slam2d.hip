@@ -743,9 +743,10 @@ __device__ __forceinline__ void fill_tile(const Slam2dLevel& lv, int p, int t, i
 }
 
 // Tile triage, one 1024-thread block per particle looping over its 16x16 field tiles:
-//  * tiles with an occupied cell in their 3x3 tile neighbourhood go to the blur work list;
-//  * free tiles get their minimum recorded and, if the field buffer does not already hold the
-//    free-space constant there, are filled with it by this same block (no separate launch).
+//  * tiles with an occupied cell inside their blur halo -- an occupied 8x8-cell block (level->tilemask) within
+//    ceil(radius / 8) blocks of the tile's four -- go to the blur work list;
+//  * free tiles whose part of the field buffer does not already hold the free-space constant (tilestate) are
+//    filled with it by this same block (no separate launch).
 // lazy != 0 (slam2d_match): only tiles the sweep will read (lv.tileneed, marked by k_endpoints) are
 // blurred or filled; the others keep their stale content and their tilestate.  This needs the field
 // minimum (:43) to be known without computing the whole field: it is the analytic floor as soon as
