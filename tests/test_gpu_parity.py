@@ -665,7 +665,7 @@ def _tile_bits(level, p):
     return bits.reshape(level.tmax, level.tmax).astype(bool)
 
 
-@pytest.mark.parametrize("levels", ["single", "two"])
+@pytest.mark.parametrize("levels", ["single", "two", "radius12", "radius5"])
 def test_lazy_match_equals_full_build(pkg, levels):
     """slam2d_match (blur only the tiles the sweep reads) against slam2d_field_build + slam2d_sweep on
     separate, identically driven workspaces over a sequence of scans (the persistent tile state must
@@ -676,6 +676,11 @@ def test_lazy_match_equals_full_build(pkg, levels):
     if levels == "single":
         unit, R, fov, beams, size_m, wall = 0.1, 34.5, np.pi, 180, 90, 0.5
         smP = [2.05, 0.30, 2, 0.1, 0.25, 0.3, 0.15, 1]
+    elif levels in ("radius12", "radius5"):
+        # blur radii beside the reference's: 12 (the generic blur kernel; the triage's block flags reach TWO 8-cell blocks
+        # beyond a tile) and 5 (generic kernel, one block)
+        unit, R, fov, beams, size_m, wall = 0.1, 20.0, np.pi, 180, 60, 0.5
+        smP = [1.45, 0.25, 3.0 if levels == "radius12" else 1.3, 0.1, 0.25, 0.3, 0.15, 1]
     else:
         unit, R, fov, beams, size_m, wall = 0.05, 8.0, np.pi, 180, 30, 0.25
         smP = [1.4, 0.25, 2, 0.1, 0.25, 0.3, 0.15, 5]
