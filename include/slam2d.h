@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define SLAM2D_ABI_VERSION 10
+#define SLAM2D_ABI_VERSION 11
 #define SLAM2D_SPOKE_BAND 16         /* radial band width of the beam-major spoke table, in cells */
 
 /* library error codes (negative; positive values are hipError_t) */

@@ -40,7 +40,7 @@ MAX_BLUR_RADIUS = 16
 MAX_BEAMS = 2048
 SPOKE_BAND = 16
 SYNC_WORDS = 4
-ABI_VERSION = 10
+ABI_VERSION = 11
 MATCH_PRUNE_BY_PRIOR = 1
 PRUNE_MARGIN = 40.0
 BNB_MARGIN = 30.0

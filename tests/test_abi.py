@@ -39,7 +39,7 @@ def test_struct_mirrors(L):
     for name, st in _lib.STRUCTS.items():
         assert L.slam2d_sizeof(name.encode()) == ctypes.sizeof(st)
     assert L.slam2d_sizeof(b"nope") == -1
-    assert L.slam2d_abi_version() == 10
+    assert L.slam2d_abi_version() == 11
 
 
 def test_constants_match_header():
