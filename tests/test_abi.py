@@ -39,7 +39,7 @@ def test_struct_mirrors(L):
     for name, st in _lib.STRUCTS.items():
         assert L.slam2d_sizeof(name.encode()) == ctypes.sizeof(st)
     assert L.slam2d_sizeof(b"nope") == -1
-    assert L.slam2d_abi_version() == 11
+    assert L.slam2d_abi_version() == _lib.ABI_VERSION
 
 
 def test_constants_match_header():
@@ -80,3 +80,23 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(root, f)).read()
                 assert "oracle" not in src.replace("k_floor_check", ""), f"{f} mentions the oracle"
+
+
+def test_one_abi_version_everywhere(L):
+    """Header, ctypes binding, compiled library: one number (a literal anywhere else is a trap --
+    round 3 ended with the entry point asserting the previous one)."""
+    text = open(os.path.join(REPO, "include", "slam2d.h")).read()
+    (hdr,) = re.findall(r"#define\s+SLAM2D_ABI_VERSION\s+(\d+)", text)
+    assert int(hdr) == _lib.ABI_VERSION == L.slam2d_abi_version()
+    entry = open(os.path.join(REPO, "__graft_entry__.py")).read()
+    assert not re.search(r"ABI_VERSION\s*==\s*\d", entry), "literal ABI version in __graft_entry__.py"
+
+
+def test_graft_entry_build_runs_end_to_end():
+    """`__graft_entry__.build()` is what the driver and the README run: compile, load, import."""
+    import shutil
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    import __graft_entry__ as g
+    g.build()
+    assert os.path.exists(_lib.LIB_PATH)
