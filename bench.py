@@ -81,7 +81,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the variant measurements (brute-force sweep, prior-pruned "
                     "sweep, reference defaults, config-5 slice, config-3 closed loop)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of each CPU baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of each CPU baseline leg (two legs: one process, all cores)")
     ap.add_argument("--cpu-workers", type=int, default=0, help="processes of the all-cores CPU baseline (0: every host core)")
     ap.add_argument("--repeats", type=int, default=5, help="the K-step timed block is run this many times; value / ms_per_step are the "
                     "median block (every block is bracketed by barrier + synchronize)")
@@ -115,9 +115,17 @@ def launch_ranks(args):
 class Scenario:
     """Synthetic world, trajectory, scans and per-particle pose estimates of one workload."""
 
-    def __init__(self, cfg, P, n_scans, seed=0, rank=0):
+    MODES = ("tracked", "worst", "displaced")
+
+    def __init__(self, cfg, P, n_scans, seed=0, rank=0, mode="tracked"):
+        """mode "tracked": the scans are ray-cast from the very world the maps hold and every estimate lies within two cells of
+        the true pose -- the steady state of a converged filter, and the BEST case for the branch and bound (1 % of the pose tiles
+        survive).  "worst": SURVEY 8(d)'s structure-free input -- ranges ~ U(1, 0.999 R), seed 0, every endpoint cell unique,
+        nothing fits the map (the input behind the reference's 148.6 ms CPU figure).  "displaced": the tracked scans, but every
+        estimate 1.5 m and 0.2 rad off the true pose: the match lies far from the motion prior's ring."""
+        assert mode in self.MODES
         synth = importlib.import_module("slam-2d-lidar-scan_amd.synth")
-        self.cfg, self.P = cfg, P
+        self.cfg, self.P, self.mode = cfg, P, mode
         u = cfg["unit"]
         self.world = synth.make_world(cfg["map_m"], u, seed=seed, n_boxes=60)
         self.origin = (-cfg["map_m"] / 2, -cfg["map_m"] / 2)
@@ -140,6 +148,15 @@ class Scenario:
         # heading of the odometry step with a little odometry noise (an exactly lattice-aligned heading makes the
         # reference's arccos argument round above 1 -> NaN thetaWeight along that direction, Q-list in SURVEY App. A)
         self.psi = self.psi + rs.normal(0.0, 0.01, size=self.psi.shape)
+        if mode == "worst":
+            self.ranges = np.random.RandomState(0).uniform(1.0, 0.999 * cfg["max_range"], size=self.ranges.shape)
+        elif mode == "displaced":
+            rd = np.random.RandomState(2000 + rank)
+            ang = rd.uniform(-np.pi, np.pi, size=(n_scans, P))
+            k = int(round(1.5 / u))
+            self.est[:, :, 0] += u * np.rint(k * np.cos(ang))
+            self.est[:, :, 1] += u * np.rint(k * np.sin(ang))
+            self.est[:, :, 2] += 0.2 * rd.choice([-1.0, 1.0], size=(n_scans, P))
 
 
 class HotPath:
@@ -338,6 +355,32 @@ class HotPathGroups:
         self.ev_merged = C.c_void_p(self.L.slam2d_event_create())
         self.merged_once = False
         self.prune = False
+        # round 4: the whole step is issued by ONE library call (slam2d_groups_step); SLAM2D_BENCH_PYSTEP=1 keeps round 3's
+        # call-by-call issue from Python (~7 us of interpreter + ctypes per launch: 0.103 of the 0.131 ms step)
+        self.c_step = os.environ.get("SLAM2D_BENCH_PYSTEP", "0") != "1"
+        _lib = self.E._lib
+        self.cgroups = (_lib.Slam2dGroup * G)()
+        self.cscan = _lib.Slam2dScan()
+        self._maps_seen = [None] * G
+        self._bases = []
+        for g, sub in enumerate(self.subs):
+            cg = self.cgroups[g]
+            cg.coarse = C.pointer(sub.coarse.c)
+            if sub.fine is not None:
+                cg.fine = C.pointer(sub.fine.c)
+            cg.P, cg.est_stride = per, 3
+            cg.d_coarse, cg.d_fine = sub.m_coarse.data_ptr(), sub.m_fine.data_ptr()
+            cg.d_flags = sub.eng.flags.data_ptr()
+            cg.d_logw, cg.d_part = sub.d_logw.data_ptr(), self.part_of[g].data_ptr()
+            cg.stream, cg.ev_done = self.handles[g], self.ev_done[g]
+            self._bases.append((sub.d_est.data_ptr(), sub.d_est.stride(0) * 8, sub.d_psi.data_ptr(), sub.d_psi.stride(0) * 8,
+                                sub.d_uniform.data_ptr(), sub.d_uniform.stride(0) * 8))
+        sc = self.cscan
+        sc.d_logw_all, sc.n_local, sc.n_parts = self.d_logw.data_ptr(), P, G * self.world
+        sc.total_particles, sc.d_w, sc.d_stats = self.total_particles, self.d_w.data_ptr(), self.d_stats.data_ptr()
+        sc.norm_stream, sc.ev_merged = self.norm_handle, self.ev_merged
+        self._ranges_base, self._ranges_stride = h0.d_ranges.data_ptr(), h0.d_ranges.stride(0) * 8
+        self._lidar_ref = C.byref(h0.eng.lidar_c)
         torch.cuda.synchronize()
 
     @property
@@ -368,6 +411,55 @@ class HotPathGroups:
         return self.subs[0].algorithmic_bytes(scen)
 
     def step(self, s):
+        if self.c_step:
+            return self.step_c(s)
+        return self.step_py(s)
+
+    def step_c(self, s):
+        """One scan of all groups through ONE library call (slam2d_groups_step); sharded: the all-gather of the partials and
+        the merge follow from here."""
+        E, L = self.E, self.L
+        try:
+            for g, sub in enumerate(self.subs):
+                E._PINNED_STREAM = self.handles[g]           # (the little torch does here -- stamp reset, bit refresh -- goes to the group's stream)
+                eng = sub.eng
+                eng._before_update()
+                eng.refresh_bits()
+                for lv in sub.levels():
+                    lv.next_generation()
+                cg = self.cgroups[g]
+                if self._maps_seen[g] != eng.maps_version:
+                    cg.d_maps, self._maps_seen[g] = eng.d_maps.data_ptr(), eng.maps_version
+                e0, es, p0, ps, u0, us = self._bases[g]
+                cg.d_est, cg.d_psi_cs, cg.d_uniform = e0 + s * es, p0 + s * ps, u0 + s * us
+        finally:
+            E._PINNED_STREAM = None
+        sc = self.cscan
+        sc.d_ranges, sc.est_moving_dist = self._ranges_base + s * self._ranges_stride, float(self.subs[0].dist[s])
+        sc.options = E._lib.MATCH_PRUNE_BY_PRIOR if self.prune else 0
+        sc.d_parts, sc.n_parts, sc.total_particles = self.parts_all.data_ptr(), self.G * self.world, self.total_particles
+        sc.wait_merged, sc.merge = int(self.merged_once), 0 if self.sharded else 1
+        E._lib.check(L.slam2d_groups_step(self._lidar_ref, self.cgroups, self.G, C.byref(sc)), "slam2d_groups_step")
+        if self.sharded:
+            self._gather_and_merge()
+        self.merged_once = True
+
+    def _gather_and_merge(self):
+        E, L = self.E, self.L
+        with torch.cuda.stream(self.norm):
+            if self.via_host:                            # gloo (dry mode): the partials hop through host memory
+                mine = self.parts_local.cpu()
+                got = [torch.empty_like(mine) for _ in range(self.world)]
+                dist.all_gather(got, mine)
+                self.parts_all.copy_(torch.cat(got))
+            else:
+                dist.all_gather_into_tensor(self.parts_all, self.parts_local)
+        E._lib.check(L.slam2d_weights_merge(E._ptr(self.d_logw), self.P, E._ptr(self.parts_all), self.G * self.world,
+                                            self.total_particles, E._ptr(self.d_w), E._ptr(self.d_stats), self.norm_handle),
+                     "slam2d_weights_merge")
+        L.slam2d_event_record(self.ev_merged, self.norm_handle)
+
+    def step_py(self, s):
         E, L = self.E, self.L
         try:
             for g, sub in enumerate(self.subs):
@@ -498,14 +590,19 @@ def cpu_baseline(cfg, scen, target_seconds, workers):
             ctx = mp.get_context("fork")
             with ctx.Pool(workers, initializer=_cpu_worker_init, initargs=args) as pool:
                 pool.map(_cpu_unit, range(workers), chunksize=1)                   # workers warm (their matchers built)
-                n, t1 = 0, time.perf_counter()
+                n, t1, rates = 0, time.perf_counter(), []
                 while True:                                                         # rounds of one unit per worker, time-bounded
+                    ta = time.perf_counter()
                     pool.map(_cpu_unit, range(n, n + workers), chunksize=1)
                     n += workers
-                    el2 = time.perf_counter() - t1
+                    tb = time.perf_counter()
+                    rates.append(workers / (tb - ta))
+                    el2 = tb - t1
                     if el2 >= target_seconds:
                         break
             out.update(value=n / el2, cores=workers, single_core_value=single,
+                       spread={"rounds": len(rates), "min": min(rates), "median": statistics.median(rates), "max": max(rates),
+                               "note": "particle-scans/s of every round of one unit per worker; the figure moves with the box's other tenants"},
                        sample=f"{n} particle-scans on a {workers}-process pool ({el2:.1f} s); single process: {units} in {el:.1f} s; "
                               "NumPy port of the reference; LUT / setup excluded")
         except Exception as exc:                                                    # the single-core leg stands
@@ -668,7 +765,10 @@ def roofline_of(hot, scen, P, ms_per_step, stage_ms, launches_per_step_of, workl
                    measured_hbm_frac=(tr / (t_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if tr else None,
                    wasted=(tr / (proc_at or proc)) if tr and (proc_at or proc) else None,
                    wasted_note="HBM traffic / processed bytes, both of the scans the PMC run measured (tile counts move along the "
-                               "trajectory)" if proc_at else None, traffic_note=traffic_note,
+                               "trajectory)" if proc_at else None,
+                   traffic_note=traffic_note or "counter bytes replayed from profiles/traffic.json (builder-side rocprofv3 --pmc passes of this command, "
+                                                "2 FETCH_SIZE + WRITE_SIZE per the gfx950 guide, locked to slam2d.hip's SHA-256), divided by THIS run's "
+                                                "kernel time: not an independent measurement of this run",
                    processed_bytes_per_launch=proc, avg_launch_us=t_us, avg_launch_us_with_event_pair=raw_us,
                    event_pair_overhead_us=overhead_us,
                    whole_array_convention={"bytes_per_launch": whole_array, "frac": whole_array / (t_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
@@ -694,6 +794,8 @@ def roofline_of(hot, scen, P, ms_per_step, stage_ms, launches_per_step_of, workl
         # (the PMC summary counts launches per k_grid_update launch, i.e. per scan of ONE particle group)
         meas = sum(v.get("hbm_bytes_corrected", 0.0) * v.get("launches_per_step", 1.0) for k, v in traffic_all.items() if v.get("in_step")) \
             * launches_per_step_of.get("k_grid_update", len(hot.groups))
+    out["whole_step_traffic_note"] = ("measured_hbm_* replay profiles/traffic.json (see roofline.traffic_note)" if meas else
+                                      (traffic_note or "no PMC entries for this workload"))
     out["whole_step"] = {"processed_bytes_per_particle_scan": step_proc, "achieved": step_proc * P / t / 1e9,
                          "frac": step_proc * P / t / 1e9 / HBM_PEAK_GBS,
                          "measured_hbm_bytes_per_step": meas, "measured_hbm_frac": (meas / t / 1e9 / HBM_PEAK_GBS) if meas else None,
@@ -703,26 +805,51 @@ def roofline_of(hot, scen, P, ms_per_step, stage_ms, launches_per_step_of, workl
     return out
 
 
-def side_workload(name, P, K, W, device, rank):
-    """A short run of another workload for the `variants` block (same launch sequence, its own scenario)."""
+def side_workload(name, P, K, W, device, rank, mode="tracked", with_brute=False, groups=None):
+    """A short run of another workload / another input for the `variants` block (same launch sequence, its own scenario).
+    with_brute: the same scans again with every pose scored (k_sweep) -- what the branch and bound must not lose against."""
     cfg = WORKLOADS[name]
-    scen = Scenario(cfg, P, K + W, seed=0, rank=rank)
-    hot = make_hot_path(cfg, P, scen, device, bench_groups(None, P))
-    for s in range(W):
-        hot.step(s)
-    hot.take_flags()
-    blocks = []
-    for _ in range(3):
-        blocks.append(timed_run(hot, W, K)[0])
+    scen = Scenario(cfg, P, K + W, seed=0, rank=rank, mode=mode)
+    hot = make_hot_path(cfg, P, scen, device, bench_groups(groups, P))
+
+    def run():
+        for s in range(W):
+            hot.step(s)
         hot.take_flags()
-    el = statistics.median(blocks)
+        blocks = []
+        for _ in range(3):
+            blocks.append(timed_run(hot, W, K)[0])
+            hot.take_flags()
+        return statistics.median(blocks)
+    el = run()
     world = dist.get_world_size() if dist.is_initialized() else 1
     rf = roofline_of(hot, scen, P, 1e3 * el / K, {}, {}, name)
-    return dict(value=P * world * K / el, unit="particle-scans/s", ms_per_step=1e3 * el / K, steps=K, repeats=3, particles_per_gpu=P,
-                workload=cfg["note"], pose_hypotheses_per_particle_scan=hot.coarse.ntheta * hot.coarse.nx ** 2 +
-                (hot.fine.ntheta * hot.fine.nx ** 2 if hot.fine else 0),
-                branch_and_bound={k: bool(lv.bnb) for k, lv in (("coarse", hot.coarse), ("fine", hot.fine)) if lv is not None},
-                whole_step=rf["whole_step"], tile_stats=rf["tile_stats"])
+    out = dict(value=P * world * K / el, unit="particle-scans/s", ms_per_step=1e3 * el / K, steps=K, repeats=3, particles_per_gpu=P,
+               workload=cfg["note"], input=mode, pose_hypotheses_per_particle_scan=hot.coarse.ntheta * hot.coarse.nx ** 2 +
+               (hot.fine.ntheta * hot.fine.nx ** 2 if hot.fine else 0),
+               branch_and_bound={k: bool(lv.bnb) for k, lv in (("coarse", hot.coarse), ("fine", hot.fine)) if lv is not None},
+               particle_groups_per_gpu=len(hot.groups), whole_step=rf["whole_step"], tile_stats=rf["tile_stats"])
+    if with_brute and any(lv.bnb for lv in hot.levels()):
+        saved = [(lv, lv.c.bnb) for lv in hot.levels()]
+        for lv, _ in saved:
+            lv.c.bnb = 0
+        elb = run()
+        for lv, v in saved:
+            lv.c.bnb = v
+        out["brute_force_ms_per_step"] = 1e3 * elb / K
+        out["vs_brute_force"] = elb / el               # > 1: the default path is faster than scoring every pose
+    return out
+
+
+def p_sweep(name, counts, K, W, device, rank):
+    """particle-scans/s of one workload against the particles per GPU (default groups): does P = 64 fill the machine?"""
+    out = {}
+    for P in counts:
+        r = side_workload(name, P, K, W, device, rank)
+        out[str(P)] = dict(value=r["value"], ms_per_step=r["ms_per_step"], us_per_particle_scan=1e3 * r["ms_per_step"] / P,
+                           particle_groups_per_gpu=r["particle_groups_per_gpu"])
+        torch.cuda.empty_cache()
+    return out
 
 
 def config3_closed_loop(P, device):
@@ -753,6 +880,98 @@ def config3_closed_loop(P, device):
                 scans_per_sec=len(readings) / el, resamples=resamples, final_map=[m.rows, m.cols],
                 note="closed loop through ParticleFilter.run(): host decisions (growth, resampling), per-scan H2D staging, one packed "
                      "D2H per scan; scan s is enqueued before scan s-1's results are read")
+
+
+class _SerialParticle:
+    """The reference's Particle (Algorithm/FastSlam.py:64-140) restated as a CALLER of the drop-in classes: one OccupancyGrid and
+    one ScanMatcher per particle, one synchronous matchScan + one updateOccupancyGrid per scan -- the path a user takes who
+    swaps only Utils/OccupancyGrid.py and Utils/ScanMatcher_OGBased.py under the unchanged driver."""
+
+    def __init__(self, pkg, ogP, smP):
+        mapX, mapY, init_xy, unit, fov, max_range, beams, wall = ogP
+        self.og = pkg.OccupancyGrid(mapX, mapY, init_xy, unit, fov, beams, max_range, wall)
+        self.sm = pkg.ScanMatcher(self.og, *smP)
+        self.weight, self.traj = 1.0, []
+        self.prev_matched = self.prev_raw = self.prev_raw_heading = self.prev_heading = None
+
+    @staticmethod
+    def _heading(dx, dy):
+        d = math.sqrt(dx * dx + dy * dy)
+        return (math.acos(dx / d) if dy > 0 else -math.acos(dx / d)) if d != 0 else None
+
+    def update(self, reading, count):
+        if count == 1:
+            self.prev_raw_heading = self.prev_heading = None
+            matched, conf = reading, 1
+        else:
+            pr, pm = self.prev_raw, self.prev_matched
+            est = {"x": pm["x"], "y": pm["y"], "theta": pm["theta"] + reading["theta"] - pr["theta"], "range": reading["range"]}
+            dx, dy = reading["x"] - pr["x"], reading["y"] - pr["y"]
+            dist = math.sqrt(dx * dx + dy * dy)
+            raw_heading = est_heading = None
+            if dist > 0.3:
+                raw_heading = self._heading(dx, dy)
+                if self.prev_raw_heading is not None:
+                    est_heading = self.prev_heading + (raw_heading - self.prev_raw_heading)
+            matched, conf = self.sm.matchScan(est, dist, est_heading, count, matchMax=False)
+            self.prev_raw_heading = raw_heading
+            self.prev_heading = self._heading(matched["x"] - self.traj[-1][0], matched["y"] - self.traj[-1][1])
+        self.traj.append((matched["x"], matched["y"]))
+        self.og.updateOccupancyGrid(matched)
+        self.prev_matched, self.prev_raw = matched, reading
+        self.weight *= conf
+
+
+def dropin_serial(P, n_scans, device):
+    """The UNCHANGED-CALLER path (north_star: "drops in under FastSlam.py unchanged"): the reference's serial loop over P
+    particles (Algorithm/FastSlam.py:25-27) on the drop-in classes, Intel log, reference defaults -- host- and PCIe-inclusive
+    (one upload and one download per matchScan), never `value`."""
+    pkg = importlib.import_module("slam-2d-lidar-scan_amd")
+    dataio = importlib.import_module("slam-2d-lidar-scan_amd.dataio")
+    path = os.path.join(REPO, "tests", "golden", "intel_gfs.npz")
+    if not os.path.exists(path):
+        return None
+    readings = dataio.read_npz(path)[:n_scans]
+    u = 0.02
+    ogP = [50.0, 50.0, readings[0], u, math.pi, 10, 180, 5 * u]
+    smP = [1.4, 0.25, 2, 0.1, 0.25, 0.3, 0.15, 5]
+    np.random.seed(0)
+    parts = [_SerialParticle(pkg, ogP, smP) for _ in range(P)]
+    for count, rd in enumerate(readings[:3], start=1):                    # warm-up (first builds, allocations)
+        for pt in parts:
+            pt.update(rd, count)
+    torch.cuda.synchronize()
+    t_match = t_upd = 0.0
+    t0 = time.perf_counter()
+    for count, rd in enumerate(readings[3:], start=4):
+        for pt in parts:
+            pt.update(rd, count)
+        w = np.array([pt.weight for pt in parts])
+        s = w.sum()
+        for pt in parts:
+            pt.weight /= s                                                # normalizeWeights (:43-48); no resample in 50 scans
+    for pt in parts:
+        pt.og.flush()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    n = len(readings) - 3
+    # the two calls timed apart on one particle (synchronised around each)
+    pt = parts[0]
+    for count, rd in enumerate(readings[-8:], start=len(readings) + 1):
+        pm, pr = pt.prev_matched, pt.prev_raw
+        est = {"x": pm["x"], "y": pm["y"], "theta": pm["theta"] + rd["theta"] - pr["theta"], "range": rd["range"]}
+        torch.cuda.synchronize(); a = time.perf_counter()
+        matched, _ = pt.sm.matchScan(est, 0.1, None, count, matchMax=False)
+        b = time.perf_counter()
+        pt.og.updateOccupancyGrid(matched); pt.og.flush(); torch.cuda.synchronize()
+        c = time.perf_counter()
+        t_match += b - a; t_upd += c - b
+        pt.prev_matched = matched
+    return dict(value=P * n / el, unit="particle-scans/s", scans=n, particles=P, seconds=el, scans_per_sec=n / el,
+                ms_per_matchScan=1e3 * t_match / 8, ms_per_updateOccupancyGrid=1e3 * t_upd / 8,
+                note="the reference's serial per-particle loop (Algorithm/FastSlam.py:25-27,122-135) on the drop-in OccupancyGrid / "
+                     "ScanMatcher classes: one synchronous matchScan (one upload, one download) and one updateOccupancyGrid per "
+                     "particle and scan; host- and PCIe-inclusive")
 
 
 def spawn_check(args, world, rank):
@@ -924,10 +1143,19 @@ def main():
         for name, (p2, k2) in {"ref2level": (64, 40), "config5": (128, 12)}.items():
             if name != args.workload:
                 variants[name] = side_workload(name, p2, k2, 4, device, rank)
+        if args.workload == "config2":
+            # inputs the branch and bound does NOT like (the headline's scans fit the maps, 1 % of the pose tiles survive):
+            # SURVEY 8(d)'s structure-free scans and estimates far off the motion prior's ring, each next to the brute-force sweep
+            variants["config2_worst"] = side_workload("config2", P, 40, 6, device, rank, mode="worst", with_brute=True)
+            variants["config2_displaced"] = side_workload("config2", P, 40, 6, device, rank, mode="displaced", with_brute=True)
+            variants["p_sweep"] = p_sweep("config2", (16, 32, 64, 128, 256), 30, 6, device, rank)
         if world == 1 and args.workload == "config2":
             c3 = config3_closed_loop(64, device)
             if c3 is not None:
                 variants["config3_closed_loop"] = c3
+            ds = dropin_serial(64, 53, device)
+            if ds is not None:
+                variants["dropin_serial"] = ds
     else:
         rf_main = roofline_of(hot, scen, P, 1e3 * elapsed / K, stage_ms, launches_per_step_of, args.workload, overhead_us)
 

@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define SLAM2D_ABI_VERSION 11
+#define SLAM2D_ABI_VERSION 12
 #define SLAM2D_SPOKE_BAND 16         /* radial band width of the beam-major spoke table, in cells */
 
 /* library error codes (negative; positive values are hipError_t) */
@@ -418,6 +418,81 @@ int slam2d_weights_local(double* d_logw, const double* d_logconf, int32_t logcon
                          double* d_part, void* stream);
 int slam2d_weights_merge(double* d_logw, int32_t N, const double* d_parts, int32_t world,
                          int64_t total_particles, double* d_w, double* d_stats, void* stream);
+
+/* ---- one scan for several particle GROUPS, each on its own HIP stream, issued from C in ONE call ----
+ * Particles are independent during a scan (Algorithm/FastSlam.py:25-27); every kernel of the step is latency- or issue-bound
+ * at a few dozen particles, so a host driver steps its particles in G groups on G streams and joins them only in the weight
+ * normaliser (:30-48).  Issued call by call from Python that costs ~7 us of interpreter + ctypes time per launch (round 3:
+ * 0.103 of a 0.131 ms step); these entry points issue the same launches for all groups from C, so the host pays one call per
+ * scan (slam2d_groups_step) or two (match / commit: the pipelined closed loop reads the previous scan's report in between).
+ *
+ * A group is described by HOST pointers to its level descriptors -- either levels of its own or offset views of a larger
+ * level (every per-particle pointer advanced by the group's first particle; `tilemask` then no longer follows `occ`
+ * contiguously, which is accepted whenever occ_gen != 0: nothing is cleared) -- and by device pointers to its slices of the
+ * per-particle arrays. */
+typedef struct {
+    const Slam2dLevel* coarse;   /* HOST pointer */
+    const Slam2dLevel* fine;     /* HOST pointer; NULL: single-level match (the coarse result is the matched pose) */
+    const Slam2dMap*   d_maps;   /* the group's P map descriptors */
+    int32_t P;
+    int32_t est_stride;          /* doubles per row of d_est (>= 3) */
+    const double* d_est;         /* [P][est_stride] pose estimates handed in (open loop), or NULL: derive them from d_prev_pose
+                                    (slam2d_prior) into d_est_out / d_psi_out -- the closed loop */
+    const double* d_psi_cs;      /* [P][2] heading prior with d_est (NULL: None); ignored in the closed loop */
+    const double* d_uniform;     /* [P] soft-max draw at the coarse level; NULL: arg-max */
+    double* d_prev_pose;         /* closed loop: [P][3] previous matched poses, in/out (slam2d_post_match) */
+    double* d_heading;           /* closed loop: [P] prevMatchedMovingTheta, in/out */
+    double* d_est_out;           /* closed loop: [P][3] */
+    double* d_psi_out;           /* closed loop: [P][2] */
+    Slam2dMatch* d_coarse;       /* [P] */
+    Slam2dMatch* d_fine;         /* [P]; unused when fine == NULL */
+    uint32_t* d_flags;           /* [P] fault bits of this scan (the caller alternates two buffers between scans when groups may
+                                    run a scan apart and abort_mask is used: see Slam2dScan.d_abort_flags) */
+    double* d_logw;              /* [P] log-weights, a slice of Slam2dScan.d_logw_all */
+    double* d_part;              /* [3] out: this group's [max log w, sum, sum of squares] (slam2d_weights_local) */
+    double* d_report;            /* closed loop: [P][5] (slam2d_post_match) or NULL */
+    uint32_t* d_flag_snapshot;   /* closed loop: [P] the scan's fault bits, moved out of d_flags by the commit, or NULL */
+    void* stream;                /* the group's HIP stream */
+    void* ev_matched;            /* slam2d_event_create(): recorded behind the group's match (needed with abort_mask) or NULL */
+    void* ev_done;               /* recorded behind the group's map update */
+} Slam2dGroup;
+
+/* What all groups of a scan share. */
+typedef struct {
+    const double* d_ranges;      /* [beams] */
+    double est_moving_dist;
+    double raw_theta, prev_raw_theta, raw_turn;   /* closed loop: arguments of slam2d_prior */
+    int32_t has_turn;
+    uint32_t options;            /* as slam2d_match (coarse level) */
+    uint32_t abort_mask;         /* closed loop: as slam2d_scan_commit, decided over d_abort_flags[0 .. n_abort_flags): the fault
+                                    bits of ALL groups (their d_flags are slices of that array).  Every group's commit waits for
+                                    every group's ev_matched first */
+    int32_t n_abort_flags;
+    const uint32_t* d_abort_flags;
+    void* ev_inputs;             /* NULL, or an event every group's stream waits for before its match (inputs staged elsewhere) */
+    /* the weight normaliser over all groups (and, sharded, all ranks): slam2d_weights_merge on norm_stream behind every
+     * group's update */
+    double* d_logw_all;          /* [n_local] the groups' log-weights, consecutive */
+    int32_t n_local;
+    int32_t n_parts;             /* partials in d_parts: G x ranks */
+    const double* d_parts;       /* [n_parts][3]; one rank: the groups' d_part are its rows */
+    int64_t total_particles;
+    double* d_w;                 /* [n_local] out */
+    double* d_stats;             /* [2] out */
+    void* norm_stream;
+    void* ev_merged;             /* recorded behind the merge; a group's update waits for the previous scan's */
+    int32_t wait_merged;         /* 0: first scan, nothing to wait for */
+    int32_t merge;               /* 1: issue the merge here.  0: the caller does (sharded: an all-gather of the partials comes
+                                    first); norm_stream is still ordered behind every group's ev_done */
+} Slam2dScan;
+
+/* match of every group (prior when d_est == NULL, coarse level, fine level) on its stream; records ev_matched */
+int slam2d_groups_match(const Slam2dLidar* lidar, const Slam2dGroup* groups, int32_t G, const Slam2dScan* scan);
+/* map update at the matched poses + bookkeeping + the group's normaliser partial in ONE launch per group (closed loop:
+ * slam2d_scan_commit's work with the abort decided over all groups), then the merge.  */
+int slam2d_groups_commit(const Slam2dLidar* lidar, const Slam2dGroup* groups, int32_t G, const Slam2dScan* scan);
+/* both, group by group (a group's update is enqueued right behind its match): the open-loop step of bench.py */
+int slam2d_groups_step(const Slam2dLidar* lidar, const Slam2dGroup* groups, int32_t G, const Slam2dScan* scan);
 
 /* ParticleFilter.resample's state movement (Algorithm/FastSlam.py:56-61) for maps of
  * identical shape: dst[p] = src[d_index[p]].  Ragged maps are copied by the host with

@@ -40,7 +40,7 @@ MAX_BLUR_RADIUS = 16
 MAX_BEAMS = 2048
 SPOKE_BAND = 16
 SYNC_WORDS = 4
-ABI_VERSION = 11
+ABI_VERSION = 12
 MATCH_PRUNE_BY_PRIOR = 1
 PRUNE_MARGIN = 40.0
 BNB_MARGIN = 30.0
@@ -105,7 +105,30 @@ class Slam2dMatch(C.Structure):
                 ("pick", C.c_int32), ("argmax", C.c_int32)]
 
 
-STRUCTS = {"Slam2dMap": Slam2dMap, "Slam2dLidar": Slam2dLidar, "Slam2dFrame": Slam2dFrame,
+class Slam2dGroup(C.Structure):
+    """One particle group of a multi-stream scan (include/slam2d.h): HOST pointers to its level descriptors, device pointers
+    to its slices of the per-particle arrays, its stream and events."""
+    _fields_ = [("coarse", C.POINTER(Slam2dLevel)), ("fine", C.POINTER(Slam2dLevel)), ("d_maps", _vp),
+                ("P", C.c_int32), ("est_stride", C.c_int32),
+                ("d_est", _vp), ("d_psi_cs", _vp), ("d_uniform", _vp),
+                ("d_prev_pose", _vp), ("d_heading", _vp), ("d_est_out", _vp), ("d_psi_out", _vp),
+                ("d_coarse", _vp), ("d_fine", _vp), ("d_flags", _vp), ("d_logw", _vp), ("d_part", _vp),
+                ("d_report", _vp), ("d_flag_snapshot", _vp),
+                ("stream", _vp), ("ev_matched", _vp), ("ev_done", _vp)]
+
+
+class Slam2dScan(C.Structure):
+    """What all groups of a scan share (include/slam2d.h)."""
+    _fields_ = [("d_ranges", _vp), ("est_moving_dist", C.c_double),
+                ("raw_theta", C.c_double), ("prev_raw_theta", C.c_double), ("raw_turn", C.c_double),
+                ("has_turn", C.c_int32), ("options", C.c_uint32), ("abort_mask", C.c_uint32), ("n_abort_flags", C.c_int32),
+                ("d_abort_flags", _vp), ("ev_inputs", _vp),
+                ("d_logw_all", _vp), ("n_local", C.c_int32), ("n_parts", C.c_int32), ("d_parts", _vp),
+                ("total_particles", C.c_int64), ("d_w", _vp), ("d_stats", _vp),
+                ("norm_stream", _vp), ("ev_merged", _vp), ("wait_merged", C.c_int32), ("merge", C.c_int32)]
+
+
+STRUCTS = {"Slam2dGroup": Slam2dGroup, "Slam2dScan": Slam2dScan, "Slam2dMap": Slam2dMap, "Slam2dLidar": Slam2dLidar, "Slam2dFrame": Slam2dFrame,
            "Slam2dLevel": Slam2dLevel, "Slam2dMatch": Slam2dMatch, "Slam2dPartial": Slam2dPartial}
 
 # name -> (restype, argtypes); every symbol include/slam2d.h declares
@@ -130,6 +153,9 @@ SIGNATURES = {
                                     _vp, C.c_uint32, _vp]),
     "slam2d_scan_commit": (C.c_int, [C.POINTER(Slam2dLidar), _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _vp, C.c_uint32, _vp]),
+    "slam2d_groups_match": (C.c_int, [C.POINTER(Slam2dLidar), C.POINTER(Slam2dGroup), C.c_int32, C.POINTER(Slam2dScan)]),
+    "slam2d_groups_commit": (C.c_int, [C.POINTER(Slam2dLidar), C.POINTER(Slam2dGroup), C.c_int32, C.POINTER(Slam2dScan)]),
+    "slam2d_groups_step": (C.c_int, [C.POINTER(Slam2dLidar), C.POINTER(Slam2dGroup), C.c_int32, C.POINTER(Slam2dScan)]),
     "slam2d_weights_local": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _vp, _vp]),
     "slam2d_weights_merge": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, C.c_int64, _vp, _vp, _vp]),
     "slam2d_gather_maps": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int64, _vp]),

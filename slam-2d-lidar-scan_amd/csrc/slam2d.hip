@@ -886,15 +886,24 @@ __global__ __launch_bounds__(TRIAGE_THREADS) void k_tile_triage(Slam2dLevel lv, 
 #ifndef BLUR_MIN_WAVES
 #define BLUR_MIN_WAVES 1
 #endif
+// bpp > 0 (round 4): a 1-D grid in which block b runs on XCD b % 8 and all blocks of particle p on XCD p % 8, like the sweep's
+// and the update's -- x-adjacent tiles share the 128-byte lines of their occupancy halo (8 tiles wide), and with the blocks of a
+// particle dealt round the XCDs by blockIdx.x every XCD's L2 fetched its own copy of those lines (round 3: 34 MB of HBM
+// traffic per 32-particle launch for 6.9 MB processed, L2 hit rate 56 %).  bpp == 0: the (blocks, P) grid of rounds 1-3.
 template <int RAD>
-__global__ __launch_bounds__(BLUR_THREADS, BLUR_MIN_WAVES) void k_blur_clamp(Slam2dLevel lv) {
+__global__ __launch_bounds__(BLUR_THREADS, BLUR_MIN_WAVES) void k_blur_clamp(Slam2dLevel lv, int P, int bpp) {
     __shared__ BlurLds<RAD> sm;
-    const int p = blockIdx.y;
+    int p = blockIdx.y, first = blockIdx.x, stride = gridDim.x;
+    if (bpp > 0) {
+        const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+        p = (slot / bpp) * 8 + xcd; first = slot % bpp; stride = bpp;
+        if (p >= P) return;
+    }
     const int n = lv.tilecount[2 * p];
-    if ((int)blockIdx.x >= n) return;
+    if (first >= n) return;
     const Slam2dFrame fr = lv.frames[p];
     const int* list = lv.tilelist + (size_t)p * 2 * lv.tmax * lv.tmax;
-    for (int b = blockIdx.x; b < n; b += gridDim.x) {
+    for (int b = first; b < n; b += stride) {
         const int t = list[b];
         blur_tile<RAD>(lv, sm, p, fr, t / lv.tmax, t % lv.tmax, 0, false);
     }
@@ -2622,7 +2631,8 @@ __global__ __launch_bounds__(XS_THREADS) void k_exact_select(Slam2dLevel lv, con
             __syncthreads();                                           // list_s is rebuilt by the next pass / the tail
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // every storing wave drains its write-through stores
-        __syncthreads();
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);                       // (no instruction: the compiler may not move the score stores
+        __syncthreads();                                               //  below the ticket, nor the read-back loads above it)
         if (tid == 0) {
             const unsigned ticket = __hip_atomic_fetch_add(&lv.sync[p * SLAM2D_SYNC_WORDS], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = ticket == (unsigned)(nsplit - 1);
@@ -2631,6 +2641,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_exact_select(Slam2dLevel lv, con
         }
         __syncthreads();
         if (!last_s) return;
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
     }
     int n = 0;
     for (int base = 0; base < n_all; base += XS_TILES) {           // (block-uniform)
@@ -2840,6 +2851,7 @@ struct WeightsJob {
     const Slam2dMatch* fine; const Slam2dMatch* coarse; double* prev; double* heading; double* report;
     double* part;            // sharded filters: only the rank-local half (k_weights_local's work), the collective follows
     uint32_t abort_mask;     // slam2d_scan_commit: fault bits of the match that make the WHOLE launch a no-op (see there)
+    const uint32_t* abort_flags; int abort_n;   // slam2d_groups_commit: the abort is decided over the fault bits of ALL groups (NULL: flags[0 .. N))
 };
 // pose / heading / log-weight bookkeeping of one particle after its match (Algorithm/FastSlam.py:110-117,134-135)
 __device__ __forceinline__ void post_match_one(const Slam2dMatch* __restrict__ fine, const Slam2dMatch* __restrict__ coarse, const int p,
@@ -2985,7 +2997,9 @@ __global__ __launch_bounds__(256, UPDB_MIN_WAVES) void k_grid_update(Slam2dLidar
         // update, no bookkeeping, no weights.  The bits were set by earlier launches and are not cleared here, so every
         // block reads the same.
         bool bad = false;
-        for (int i = threadIdx.x; i < wj.N; i += blockDim.x) bad |= (flags[i] & wj.abort_mask) != 0u;
+        const uint32_t* af = wj.abort_flags ? wj.abort_flags : flags;
+        const int an = wj.abort_flags ? wj.abort_n : wj.N;
+        for (int i = threadIdx.x; i < an; i += blockDim.x) bad |= (af[i] & wj.abort_mask) != 0u;
         if (__syncthreads_or(bad)) {
             if (blockIdx.x == 0 && wj.flag_snapshot)
                 for (int i = threadIdx.x; i < wj.N; i += blockDim.x) wj.flag_snapshot[i] = flags[i];
@@ -2999,7 +3013,11 @@ __global__ __launch_bounds__(256, UPDB_MIN_WAVES) void k_grid_update(Slam2dLidar
                 post_match_one(wj.fine, wj.coarse, i, wj.prev, wj.heading, wj.logw, wj.report);
             __syncthreads();
         }
-        if (wj.part) weights_local_body(wj.logw, wj.logconf, wj.cstride, wj.N, wj.part);
+        if (wj.part) {
+            if (wj.flags && wj.flag_snapshot)              // (slam2d_groups_commit: the scan's fault bits move into the report)
+                for (int i = threadIdx.x; i < wj.N; i += blockDim.x) wj.flag_snapshot[i] = atomicExch(&wj.flags[i], 0u);
+            weights_local_body(wj.logw, wj.logconf, wj.cstride, wj.N, wj.part);
+        }
         else weights_body(wj.logw, wj.logconf, wj.cstride, wj.N, wj.w, wj.stats, wj.flags, wj.flag_snapshot, true);
         return;
     }
@@ -3180,7 +3198,13 @@ __global__ __launch_bounds__(256, UPDB_MIN_WAVES) void k_grid_update(Slam2dLidar
 // (so the result does not depend on the network's reduction order), normalises its own particles
 // and evaluates sum (w - 1/N)^2 = sum w^2 - 1/N over ALL N particles (Algorithm/FastSlam.py:32-35).
 __global__ __launch_bounds__(256) void k_weights_merge(double* logw, int N, const double* __restrict__ parts, int world,
-                                                       double total_particles, double* w, double* stats) {
+                                                       double total_particles, double* w, double* stats,
+                                                       const uint32_t* __restrict__ abort_flags, int abort_n, uint32_t abort_mask) {
+    if (abort_mask) {                                      // slam2d_groups_commit: a voided scan (see k_grid_update) has no partials to merge
+        bool bad = false;
+        for (int i = threadIdx.x; i < abort_n; i += blockDim.x) bad |= (abort_flags[i] & abort_mask) != 0u;
+        if (__syncthreads_or(bad)) return;
+    }
     double gm = -INFINITY;
     for (int r = 0; r < world; ++r) gm = fmax(gm, parts[3 * r]);
     double s1 = 0.0, s2 = 0.0;
@@ -3298,6 +3322,8 @@ int slam2d_sizeof(const char* name) {
     if (!strcmp(name, "Slam2dLevel")) return (int)sizeof(Slam2dLevel);
     if (!strcmp(name, "Slam2dMatch")) return (int)sizeof(Slam2dMatch);
     if (!strcmp(name, "Slam2dPartial")) return (int)sizeof(Slam2dPartial);
+    if (!strcmp(name, "Slam2dGroup")) return (int)sizeof(Slam2dGroup);
+    if (!strcmp(name, "Slam2dScan")) return (int)sizeof(Slam2dScan);
     return -1;
 }
 
@@ -3319,7 +3345,9 @@ static int check_level(const Slam2dLidar* lidar, const Slam2dLevel* lv, int P) {
 
 // ---- launch sequences shared by slam2d_field_build / slam2d_sweep / slam2d_match ----
 static int check_field_args(const Slam2dLevel& lv, int P, bool lazy) {
-    if (lv.tilemask != lv.occ + (size_t)P * lv.fmax * lv.fpitch || !lv.tilestate || !lv.tilemin || !lv.tilemax || !lv.tilelist || !lv.tilecount)
+    // (occ and tilemask are cleared by ONE memset when occ_gen == 0; with generation stamps nothing is cleared and a level may
+    // be an offset view of a larger one -- slam2d_groups_* -- whose flags do not follow its image)
+    if (!lv.occ || !lv.tilemask || (lv.occ_gen == 0 && lv.tilemask != lv.occ + (size_t)P * lv.fmax * lv.fpitch) || !lv.tilestate || !lv.tilemin || !lv.tilemax || !lv.tilelist || !lv.tilecount)
         return SLAM2D_E_BADARG;
     if (lazy && !lv.tileneed) return SLAM2D_E_BADARG;
     if (lv.tmax * lv.tmax > 28000) return SLAM2D_E_TOOLARGE;        // k_tile_triage: 32 passes, 5 bytes of LDS per tile (144 KB)
@@ -3351,8 +3379,8 @@ static int launch_frames(const Slam2dLidar& lid, const Slam2dLevel& lv, const Sl
 }
 
 // occupied cells -> field image, tile triage (+ fill), blur + clamp, minimum check
-static void launch_field(const Slam2dLevel& lv, const Slam2dMap* d_maps, int P, uint32_t* d_flags, bool lazy, hipStream_t s,
-                         bool scattered = false) {
+static int launch_field(const Slam2dLevel& lv, const Slam2dMap* d_maps, int P, uint32_t* d_flags, bool lazy, hipStream_t s,
+                        bool scattered = false) {
     if (!scattered) {
         StageScope prof(SLAM2D_STAGE_SCATTER, s);
         k_occ_scatter<<<dim3(cdiv(cdiv(lv.wmax, 32) + 1, 64), cdiv(lv.wmax, SCATTER_ROWS), P), dim3(64, 4), (size_t)lv.wmax * sizeof(int32_t), s>>>(lv, d_maps);
@@ -3362,22 +3390,34 @@ static void launch_field(const Slam2dLevel& lv, const Slam2dMap* d_maps, int P, 
         const int kb = (lv.blur_radius + 7) >> FLAG_SHIFT;
         const int rw = (flag_pitch(lv) >> 4) + 1;
         const size_t lds = (size_t)((2 * ((((2 * lv.tmax + 2 * kb) * rw + 1) & ~1) + lv.tmax * (rw + 1)) + 15) & ~15) + ((ntile + 3) & ~3) + 4 * ((ntile + 31) / 32) + 2 * (size_t)ntile;
-        static size_t lds_allowed = 64 * 1024;
-        if (lds > lds_allowed) {                       // more than the default dynamic LDS limit: ask once (160 KB per CU on gfx950)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_triage), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-            lds_allowed = 160 * 1024 - 512;
+        // more than the default dynamic LDS limit: ask once per device (160 KB per CU on gfx950); a device that does not grant it
+        // gets a clean error instead of a failed launch
+        static size_t lds_allowed[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        size_t& allowed = lds_allowed[dev >= 0 && dev < 64 ? dev : 0];
+        if (allowed == 0) allowed = 64 * 1024;
+        if (lds > allowed) {
+            const size_t want = 160 * 1024 - 512;
+            if (lds > want || hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_triage), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) != hipSuccess) {
+                (void)hipGetLastError();
+                return SLAM2D_E_TOOLARGE;
+            }
+            allowed = want;
         }
         k_tile_triage<<<P, TRIAGE_THREADS, lds, s>>>(lv, lazy ? 1 : 0);
     }
     {
         StageScope prof(SLAM2D_STAGE_BLUR, s);
         static const int blur_blocks = [] { const char* e = getenv("SLAM2D_BLUR_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : SLAM2D_BLUR_BLOCKS_PER_PARTICLE; }();
-        const dim3 bgrid(min(ntile, blur_blocks), P);
+        static const bool xcd_pin = [] { const char* e = getenv("SLAM2D_BLUR_XCD"); return !e || atoi(e) != 0; }();
+        const int bpp = xcd_pin ? min(ntile, blur_blocks) : 0;
+        const dim3 bgrid = xcd_pin ? dim3((unsigned)cdiv(P, 8) * 8 * bpp) : dim3(min(ntile, blur_blocks), P);
         switch (lv.blur_radius) {
-            case 2: k_blur_clamp<2><<<bgrid, BLUR_THREADS, 0, s>>>(lv); break;
-            case 4: k_blur_clamp<4><<<bgrid, BLUR_THREADS, 0, s>>>(lv); break;
-            case 8: k_blur_clamp<8><<<bgrid, BLUR_THREADS, 0, s>>>(lv); break;
-            default: k_blur_clamp<0><<<bgrid, BLUR_THREADS, 0, s>>>(lv); break;
+            case 2: k_blur_clamp<2><<<bgrid, BLUR_THREADS, 0, s>>>(lv, P, bpp); break;
+            case 4: k_blur_clamp<4><<<bgrid, BLUR_THREADS, 0, s>>>(lv, P, bpp); break;
+            case 8: k_blur_clamp<8><<<bgrid, BLUR_THREADS, 0, s>>>(lv, P, bpp); break;
+            default: k_blur_clamp<0><<<bgrid, BLUR_THREADS, 0, s>>>(lv, P, bpp); break;
         }
     }
     // gmin2 only where a tile was written (SLAM2D_GMIN2_FULL=1: over the whole frame, as before round 3)
@@ -3391,6 +3431,7 @@ static void launch_field(const Slam2dLevel& lv, const Slam2dMap* d_maps, int P, 
         case 8: k_blur_check_redo<8><<<cgrid, 256, 0, s>>>(lv, d_flags, dirty); break;
         default: k_blur_check_redo<0><<<cgrid, 256, 0, s>>>(lv, d_flags, dirty); break;
     }
+    return 0;
 }
 
 // beam endpoints, unique cells per theta, priors (/ needed tiles)
@@ -3520,7 +3561,7 @@ int slam2d_field_build(const Slam2dLidar* lidar, const Slam2dLevel* level, const
     Slam2dLevel lv = *level;
     lv.bnb = 0;                                        // the full build has no pooled image
     if ((rc = launch_frames(*lidar, lv, d_maps, P, d_centre, centre_stride, d_flags, false, s))) return rc;
-    launch_field(lv, d_maps, P, d_flags, false, s);
+    if ((rc = launch_field(lv, d_maps, P, d_flags, false, s))) return rc;
     return launch_status();
 }
 
@@ -3569,7 +3610,7 @@ int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2
         // branch and bound over 4x4 pose tiles: tile bounds + seed tiles, surviving tiles + selection
         if (framed && (rc = launch_frames(*lidar, lv, d_maps, P, d_est, est_stride, d_flags, true, s, d_ranges))) return rc;
         launch_endpoints(*lidar, lv, P, d_est, est_stride, d_ranges, est_moving_dist, d_psi_cs, d_flags, true, false, s, framed, own, merged);
-        launch_field(lv, d_maps, P, d_flags, true, s, merged);
+        if ((rc = launch_field(lv, d_maps, P, d_flags, true, s, merged))) return rc;
         const unsigned grid = (unsigned)cdiv(P, 8) * 8 * lv.ntheta;
         if (lv.bnb == 2) {
             StageScope prof(SLAM2D_STAGE_BOUND, s);
@@ -3591,7 +3632,7 @@ int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2
     // the endpoints need only the frame, so they run first and tell the field build which tiles matter
     if (framed && (rc = launch_frames(*lidar, lv, d_maps, P, d_est, est_stride, d_flags, true, s, d_ranges))) return rc;
     launch_endpoints(*lidar, lv, P, d_est, est_stride, d_ranges, est_moving_dist, d_psi_cs, d_flags, true, ring_chunks > 0, s, framed, own, merged);
-    launch_field(lv, d_maps, P, d_flags, true, s, merged);
+    if ((rc = launch_field(lv, d_maps, P, d_flags, true, s, merged))) return rc;
     if ((rc = launch_scores(lv, P, d_est, est_stride, d_uniform, d_out, s, ring_chunks))) return rc;
     return launch_status();
 }
@@ -3690,6 +3731,103 @@ int slam2d_scan_commit(const Slam2dLidar* lidar, const Slam2dMap* d_maps, int32_
                                     d_report, nullptr, abort_mask}, stream);
 }
 
+// ---- particle groups on several streams, one host call per scan (include/slam2d.h, "one scan for several particle GROUPS") ----
+static int groups_check(const Slam2dLidar* lidar, const Slam2dGroup* groups, int32_t G, const Slam2dScan* sc, bool commit) {
+    if (!lidar || !groups || !sc || G <= 0 || G > 64 || !sc->d_ranges) return SLAM2D_E_BADARG;
+    for (int i = 0; i < G; ++i) {
+        const Slam2dGroup& g = groups[i];
+        if (!g.coarse || !g.d_maps || g.P <= 0 || !g.d_coarse || (g.fine && !g.d_fine) || !g.d_flags || !g.ev_done) return SLAM2D_E_BADARG;
+        if (g.d_est ? g.est_stride < 3 : (!g.d_prev_pose || !g.d_heading || !g.d_est_out || !g.d_psi_out)) return SLAM2D_E_BADARG;
+        if (commit && (!g.d_logw || !g.d_part)) return SLAM2D_E_BADARG;
+        if (commit && sc->abort_mask && !g.ev_matched) return SLAM2D_E_BADARG;
+    }
+    if (commit) {
+        if (!sc->norm_stream && sc->merge) return SLAM2D_E_BADARG;
+        if (sc->merge && (!sc->d_logw_all || !sc->d_parts || !sc->d_w || !sc->d_stats || !sc->ev_merged || sc->n_local <= 0 || sc->n_parts <= 0 ||
+                          sc->total_particles < sc->n_local)) return SLAM2D_E_BADARG;
+        if (sc->abort_mask && (!sc->d_abort_flags || sc->n_abort_flags <= 0)) return SLAM2D_E_BADARG;
+    }
+    return 0;
+}
+
+static int group_match(const Slam2dLidar* lidar, const Slam2dGroup& g, const Slam2dScan& sc) {
+    hipStream_t s = (hipStream_t)g.stream;
+    int rc = 0;
+    if (sc.ev_inputs && (rc = (int)hipStreamWaitEvent(s, (hipEvent_t)sc.ev_inputs, 0))) return rc;
+    const double* est = g.d_est;
+    const double* psi = g.d_psi_cs;
+    int stride = g.est_stride;
+    if (!est) {                                        // closed loop: the pose prior from the previous matched poses
+        if ((rc = slam2d_prior(g.d_prev_pose, sc.raw_theta, sc.prev_raw_theta, sc.has_turn, sc.raw_turn, g.d_heading, g.P, g.d_est_out,
+                               g.d_psi_out, g.stream))) return rc;
+        est = g.d_est_out; psi = g.d_psi_out; stride = 3;
+    }
+    if ((rc = slam2d_match(lidar, g.coarse, g.d_maps, g.P, est, stride, sc.d_ranges, sc.est_moving_dist, psi, g.d_uniform, g.d_coarse,
+                           g.d_flags, sc.options, g.stream))) return rc;
+    if (g.fine && (rc = slam2d_match(lidar, g.fine, g.d_maps, g.P, reinterpret_cast<const double*>(g.d_coarse),
+                                     (int32_t)(sizeof(Slam2dMatch) / sizeof(double)), sc.d_ranges, sc.est_moving_dist, nullptr, nullptr,
+                                     g.d_fine, g.d_flags, 0u, g.stream))) return rc;
+    if (g.ev_matched) rc = (int)hipEventRecord((hipEvent_t)g.ev_matched, s);
+    return rc;
+}
+
+static int group_commit(const Slam2dLidar* lidar, const Slam2dGroup* groups, int32_t G, int i, const Slam2dScan& sc) {
+    const Slam2dGroup& g = groups[i];
+    hipStream_t s = (hipStream_t)g.stream;
+    int rc = 0;
+    if (sc.abort_mask)                                 // the abort is decided over every group's fault bits: wait for every group's match
+        for (int j = 0; j < G; ++j)
+            if (j != i && (rc = (int)hipStreamWaitEvent(s, (hipEvent_t)groups[j].ev_matched, 0))) return rc;
+    // the previous scan's merge works on the log-weights this launch rewrites
+    if (sc.wait_merged && sc.ev_merged && (rc = (int)hipStreamWaitEvent(s, (hipEvent_t)sc.ev_merged, 0))) return rc;
+    const Slam2dMatch* fin = g.fine ? g.d_fine : g.d_coarse;
+    const int md = (int)(sizeof(Slam2dMatch) / sizeof(double));
+    if (g.d_est)                                       // open loop: weight *= coarse confidence, update at the matched pose
+        rc = launch_update(lidar, g.d_maps, g.P, reinterpret_cast<const double*>(fin), md, sc.d_ranges, nullptr, g.d_flags,
+                           WeightsJob{g.d_logw, &g.d_coarse->log_confidence, md, g.P, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                      nullptr, nullptr, g.d_part, 0u, nullptr, 0}, g.stream);
+    else                                               // closed loop: slam2d_scan_commit's launch with the normaliser's local half
+        rc = launch_update(lidar, g.d_maps, g.P, reinterpret_cast<const double*>(fin), md, sc.d_ranges, nullptr, g.d_flags,
+                           WeightsJob{g.d_logw, nullptr, 1, g.P, nullptr, nullptr, g.d_flags, g.d_flag_snapshot, fin, g.d_coarse, g.d_prev_pose,
+                                      g.d_heading, g.d_report, g.d_part, sc.abort_mask, sc.d_abort_flags, sc.n_abort_flags}, g.stream);
+    if (rc) return rc;
+    return (int)hipEventRecord((hipEvent_t)g.ev_done, s);
+}
+
+static int groups_merge(const Slam2dGroup* groups, int32_t G, const Slam2dScan& sc) {
+    hipStream_t ns = (hipStream_t)sc.norm_stream;
+    int rc = 0;
+    for (int i = 0; i < G; ++i)
+        if ((rc = (int)hipStreamWaitEvent(ns, (hipEvent_t)groups[i].ev_done, 0))) return rc;
+    if (!sc.merge) return 0;                           // sharded: the caller's all-gather and slam2d_weights_merge follow on norm_stream
+    k_weights_merge<<<1, 256, 0, ns>>>(sc.d_logw_all, sc.n_local, sc.d_parts, sc.n_parts, (double)sc.total_particles, sc.d_w, sc.d_stats,
+                                       sc.d_abort_flags, sc.n_abort_flags, sc.d_abort_flags ? sc.abort_mask : 0u);
+    if ((rc = launch_status())) return rc;
+    return (int)hipEventRecord((hipEvent_t)sc.ev_merged, ns);
+}
+
+int slam2d_groups_match(const Slam2dLidar* lidar, const Slam2dGroup* groups, int32_t G, const Slam2dScan* scan) {
+    int rc = groups_check(lidar, groups, G, scan, false);
+    for (int i = 0; i < G && !rc; ++i) rc = group_match(lidar, groups[i], *scan);
+    return rc;
+}
+
+int slam2d_groups_commit(const Slam2dLidar* lidar, const Slam2dGroup* groups, int32_t G, const Slam2dScan* scan) {
+    int rc = groups_check(lidar, groups, G, scan, true);
+    for (int i = 0; i < G && !rc; ++i) rc = group_commit(lidar, groups, G, i, *scan);
+    return rc ? rc : groups_merge(groups, G, *scan);
+}
+
+int slam2d_groups_step(const Slam2dLidar* lidar, const Slam2dGroup* groups, int32_t G, const Slam2dScan* scan) {
+    int rc = groups_check(lidar, groups, G, scan, true);
+    if (!rc && scan->abort_mask) return SLAM2D_E_BADARG;      // (an abort needs every match before any commit: use the two calls)
+    for (int i = 0; i < G && !rc; ++i) {
+        rc = group_match(lidar, groups[i], *scan);
+        if (!rc) rc = group_commit(lidar, groups, G, i, *scan);
+    }
+    return rc ? rc : groups_merge(groups, G, *scan);
+}
+
 int slam2d_weights_local(double* d_logw, const double* d_logconf, int32_t logconf_stride, int32_t N, double* d_part,
                          void* stream) {
     if (!d_logw || !d_part || N <= 0 || (d_logconf && logconf_stride < 1)) return SLAM2D_E_BADARG;
@@ -3700,7 +3838,7 @@ int slam2d_weights_local(double* d_logw, const double* d_logconf, int32_t logcon
 int slam2d_weights_merge(double* d_logw, int32_t N, const double* d_parts, int32_t world, int64_t total_particles,
                          double* d_w, double* d_stats, void* stream) {
     if (!d_logw || !d_parts || !d_w || !d_stats || N <= 0 || world <= 0 || total_particles < N) return SLAM2D_E_BADARG;
-    k_weights_merge<<<1, 256, 0, (hipStream_t)stream>>>(d_logw, N, d_parts, world, (double)total_particles, d_w, d_stats);
+    k_weights_merge<<<1, 256, 0, (hipStream_t)stream>>>(d_logw, N, d_parts, world, (double)total_particles, d_w, d_stats, nullptr, 0, 0u);
     return launch_status();
 }
 

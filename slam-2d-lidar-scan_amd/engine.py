@@ -318,6 +318,7 @@ class MapState:
         # cells before an update could overflow a narrow one.  Cells handed in from elsewhere: unknown, assume the worst
         self.count_bound = 2 if fresh else (2 ** 31 if self.wide else _lib.COUNT_LIMIT)
         self._pending, self._defer = None, False
+        self.layout_version = 0          # bumped whenever `cells` / `bits` are re-allocated (growth, promotion): descriptors on the device are stale then
         self._alloc_bits()
         self._sync_coords()
         self.growth_log = []
@@ -361,9 +362,11 @@ class MapState:
         if self.wide:
             return
         self._materialise()
-        c = self.cells.to(torch.int64)
-        self.cells = (((c >> 16) & 0xFFFF) << 32) | (c & 0xFFFF)
+        with _on_launch_stream():           # (ordered with the launches of a pinned group stream)
+            c = self.cells.to(torch.int64)
+            self.cells = (((c >> 16) & 0xFFFF) << 32) | (c & 0xFFFF)
         self.wide = True
+        self.layout_version += 1            # another array in another format: every uploaded descriptor of this map is stale
 
     # -- growth: expandOccupancyGridHelper (:59-89) --
     def _side_to_grow(self, x, y):                                            # :108-118
@@ -421,11 +424,13 @@ class MapState:
         old, rows, cols, dc, dr = self._pending
         self._pending = None
         self.pitch = -(-self.cols // self.PITCH_ALIGN) * self.PITCH_ALIGN
-        cells = torch.full((self.rows, self.pitch), _lib.INIT_CELL_WIDE if self.wide else _lib.INIT_CELL, dtype=old.dtype, device=self.device)
-        cells[dr:dr + rows, dc:dc + cols] = old[:, :cols]
-        self.cells = cells
-        self._alloc_bits()
-        self._sync_coords()
+        with _on_launch_stream():
+            cells = torch.full((self.rows, self.pitch), _lib.INIT_CELL_WIDE if self.wide else _lib.INIT_CELL, dtype=old.dtype, device=self.device)
+            cells[dr:dr + rows, dc:dc + cols] = old[:, :cols]
+            self.cells = cells
+            self._alloc_bits()
+            self._sync_coords()
+        self.layout_version += 1
 
     def _grow(self, side, unit):
         """One growth step, on the device at once (expandOccupancyGrid)."""
@@ -514,13 +519,14 @@ class MapState:
         self.bits_valid = False
 
     def clone(self):
+        self._materialise()                 # (first: a pending growth changes pitch, rows and cols)
         m = MapState.__new__(MapState)
         m.device = self.device
         m.X, m.Y = self.X.copy(), self.Y.copy()
         m.rows, m.cols, m.pitch = self.rows, self.cols, self.pitch
-        self._materialise()
         m.cells = self.cells.clone()
         m._pending, m._defer = None, False
+        m.layout_version = 0
         m.wide, m.count_bound = self.wide, self.count_bound
         m.bits_pitch, m.bits, m.bits_valid = self.bits_pitch, self.bits.clone(), self.bits_valid
         m._sync_coords()
@@ -762,30 +768,50 @@ class ParticleEngine:
 
     def _rebound(self):
         self._bound_maps = list(self.maps)
-        self._max_bound = max(m.count_bound for m in self.maps)
+        # the largest bound among the maps that can still overflow (a wide map cannot: one promoted map must not make every
+        # later scan re-check -- and re-upload -- the others)
+        self._max_bound = max([m.count_bound for m in self.maps if not m.wide], default=0)
 
     def _before_update(self):
         """Move every map that the coming update could overflow (16-bit counts) to 64-bit cells first (MapState.promote) --
         the reference's float64 counts never saturate.  O(1) per scan until then."""
         self._pending_updates += 1
-        if self._max_bound + 2 * self._pending_updates > _lib.COUNT_LIMIT and not all(m.wide for m in self.maps):
+        if self._max_bound + 2 * self._pending_updates > _lib.COUNT_LIMIT:
             self.sync_bounds()
-            for m in self.maps:
-                if m.count_bound > _lib.COUNT_LIMIT:
+            promoted = False
+            for m in self.maps:                     # (sync_bounds has credited the coming update as well)
+                if not m.wide and m.count_bound > _lib.COUNT_LIMIT:
                     m.promote()
-            self.refresh_maps()
+                    promoted = True
+            if promoted:
+                self.refresh_maps()                 # (new arrays, new cell format: new descriptors)
+            else:
+                self._rebound()
 
     def refresh_maps(self):
         self.sync_bounds()
         self._pending_updates = 0
         self._rebound()
-        self.d_maps = upload_map_descs(self.maps, self.device)
+        with _on_launch_stream():
+            self.d_maps = upload_map_descs(self.maps, self.device)
+        self._layouts = [(id(m), m.layout_version) for m in self.maps]
         self.maps_version = getattr(self, "maps_version", 0) + 1      # limits / descriptors changed (growth, resample)
         self.refresh_bits()
 
     def refresh_bits(self):
-        """Rebuild the occupancy bits of every map the host has written since the last build."""
-        stale = [i for i, m in enumerate(self.maps) if not m.bits_valid]
+        """Rebuild the occupancy bits of every map the host has written since the last build -- and upload fresh descriptors
+        first when a map's arrays were re-allocated behind the engine's back (a growth or a promotion to 64-bit cells through
+        the map's own methods: OccupancyGrid.set_counts beyond 16 bits, checkAndExapndOG)."""
+        stale, moved = [], False
+        for i, (m, seen) in enumerate(zip(self.maps, self._layouts)):
+            if not m.bits_valid:
+                stale.append(i)
+            if seen[1] != m.layout_version or seen[0] != id(m):
+                moved = True
+        if moved or len(self.maps) != len(self._layouts):
+            for m in self.maps:
+                m._materialise()
+            return self.refresh_maps()
         if not stale:
             return
         self.sync_bounds()                 # the host wrote these maps (upload, growth, copy): their count bounds may have changed

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .engine import LidarModel, MapState, ParticleEngine, require_gpu
+from .engine import LidarModel, MapState, ParticleEngine, pinned_stream, require_gpu
 
 DEFAULT_DEVICE = "cuda:0"
 
@@ -45,6 +45,7 @@ class OccupancyGrid:
 
     @property
     def occupancyGridVisited(self):
+        self.flush()
         return self.map.download()[0]
 
     @occupancyGridVisited.setter
@@ -53,6 +54,7 @@ class OccupancyGrid:
 
     @property
     def occupancyGridTotal(self):
+        self.flush()
         return self.map.download()[1]
 
     @occupancyGridTotal.setter
@@ -76,6 +78,8 @@ class OccupancyGrid:
         if self._engine is None:
             self._engine = ParticleEngine(self.lidar, [self.map], self.device)
             self._engine_version = self.version
+            from .matcher import _call_buffers              # the engine's fault word and match buffers live in ONE download buffer
+            _call_buffers(self._engine, self.numSamplesPerRev)
         elif self._engine_version != self.version or self._engine.maps[0] is not self.map:
             self._engine.maps = [self.map]
             self._engine.refresh_maps()
@@ -125,11 +129,37 @@ class OccupancyGrid:
         if x - R < m.lim_x[0] or x + R > m.lim_x[1] or y - R < m.lim_y[0] or y + R > m.lim_y[1]:
             shifts = self._grow_for_update(x, y, theta, rng)      # rare: first scan of a small map
         eng = self.engine()
-        d_pose = eng.to_device([[x, y, theta]])
-        d_rng = eng.to_device(rng)
-        d_shift = eng.to_device(shifts[None], dtype=np.int32) if shifts is not None else None
-        eng.grid_update(d_pose, 3, d_rng, d_shift)
-        eng.take_flags()
+        if shifts is not None:                                      # (rare: synchronous, with its own uploads)
+            eng.grid_update(eng.to_device([[x, y, theta]]), 3, eng.to_device(rng), eng.to_device(shifts[None], dtype=np.int32))
+            eng.take_flags()
+            return
+        # pose + ranges in one pinned buffer and one copy; the launch is NOT waited for: the reference's method returns nothing,
+        # and everything that reads the map afterwards is ordered behind it on the stream.  Its fault bits are looked at by the next
+        # synchronising call on this grid (matchScan's download, a count download, flush()): round 3 paid 0.08 ms per call here.
+        io = self._update_io(eng, len(rng))
+        io["ev"].synchronize()                                      # the previous call's copy has left the pinned buffer
+        h = io["h"].numpy()
+        h[0:3] = (x, y, theta)
+        h[3:] = rng
+        with pinned_stream():
+            io["d"].copy_(io["h"], non_blocking=True)
+            io["ev"].record()
+            eng.grid_update(io["d"][0:3], 3, io["d"][3:], None)
+        self._update_pending = True
+
+    def _update_io(self, eng, beams):
+        io = getattr(eng, "_update_io", None)
+        if io is None or io["h"].numel() != 3 + beams:
+            io = eng._update_io = dict(h=torch.zeros(3 + beams, dtype=torch.float64).pin_memory(),
+                                       d=torch.zeros(3 + beams, dtype=torch.float64, device=self.device), ev=torch.cuda.Event())
+        return io
+
+    def flush(self):
+        """Wait for the last updateOccupancyGrid and raise on a fault it flagged (a cell outside the map, a count overflow)."""
+        if getattr(self, "_update_pending", False):
+            self._update_pending = False
+            if self._engine is not None:
+                self._engine.take_flags()
 
     def _update_points(self, x, y, theta, rng):
         """update=False variant (:153-159): world coordinates of the empty / occupied cells."""

@@ -13,9 +13,46 @@ import numpy as np
 import torch
 
 from . import _lib
-from .engine import MATCH_DOUBLES, ParticleEngine, SearchLevel
+from .engine import MATCH_DOUBLES, _MATCH_DTYPE, ParticleEngine, SearchLevel, pinned_stream
 
 _level_cache = {}
+
+
+class _CallBuffers:
+    """Host / device staging of one synchronous matchScan call, kept with the grid's one-particle engine: a pinned input
+    buffer (one H2D copy per call) and ONE device buffer holding both levels' results and the fault bits (one D2H copy and one
+    synchronisation per call; the engine's flag word and match buffers are views of it)."""
+
+    def __init__(self, eng, beams):
+        dev = eng.device
+        self.h_in = torch.zeros(6 + beams, dtype=torch.float64).pin_memory()
+        self.d_in = torch.zeros(6 + beams, dtype=torch.float64, device=dev)
+        self.d_out = torch.zeros(2 * MATCH_DOUBLES + 1, dtype=torch.float64, device=dev)
+        self.h_out = torch.zeros(2 * MATCH_DOUBLES + 1, dtype=torch.float64).pin_memory()
+        self.m_coarse = self.d_out[:MATCH_DOUBLES].view(1, MATCH_DOUBLES)
+        self.m_fine = self.d_out[MATCH_DOUBLES:2 * MATCH_DOUBLES].view(1, MATCH_DOUBLES)
+        eng.match_buf["coarse"], eng.match_buf["fine"] = self.m_coarse, self.m_fine
+        eng.flags = self.d_out[2 * MATCH_DOUBLES:].view(torch.int32)[:1]         # (take_flags and the kernels use this word from now on)
+
+    def download(self, eng):
+        """Both levels' results + the fault word in one copy; raises on a fatal bit like ParticleEngine.take_flags."""
+        self.h_out.copy_(self.d_out, non_blocking=True)
+        torch.cuda.current_stream(eng.device).synchronize()
+        host = self.h_out.numpy()
+        bits = int(host[2 * MATCH_DOUBLES:].view(np.uint32)[0])
+        if bits:
+            eng.flags.zero_()
+            if bits & _lib.FATAL_FLAGS:
+                raise _lib.Slam2dError(f"particle 0: {_lib.describe_flags(bits & _lib.FATAL_FLAGS)}")
+        m = host[:2 * MATCH_DOUBLES].view(_MATCH_DTYPE)
+        return m[0], m[1]
+
+
+def _call_buffers(eng, beams):
+    io = getattr(eng, "_call_io", None)
+    if io is None:
+        io = eng._call_io = _CallBuffers(eng, beams)
+    return io
 
 
 class _Exclusive:
@@ -109,23 +146,37 @@ class ScanMatcher:
             return reading, 1                                                  # :51-52
         ex, ey, eth = reading['x'], reading['y'], reading['theta']
         coarse, fine = self.coarse_level(), self.fine_level()
-        with _Exclusive(coarse, fine):
-            eng = self.og.engine()
-            d_est = eng.to_device([[ex, ey, eth]])
-            d_rng = eng.to_device(rMeasure)
-            d_psi = eng.to_device(eng.psi_table([estMovingTheta]))
-            d_u = None
+        with _Exclusive(coarse, fine), pinned_stream():
+            og = self.og
+            og.checkAndExapndOG([ex - coarse.reach, ex + coarse.reach], [ey - coarse.reach, ey + coarse.reach])   # :27 (coarse window)
+            eng = og.engine()
+            io = _call_buffers(eng, og.numSamplesPerRev)
+            # everything the call uploads in ONE pinned buffer and one copy: [x, y, theta | cos, sin of the heading | uniform | ranges]
+            h = io.h_in.numpy()
+            h[0:3] = (ex, ey, eth)
+            h[3:5] = eng.psi_table([estMovingTheta])[0]
             if not matchMax:                        # one draw from the legacy global stream, like np.random.choice (:138)
-                d_u = eng.to_device([np.random.random_sample()])
-            m_coarse, m_fine = eng.match_buffer("coarse"), eng.match_buffer("fine")
-            eng = self._build_field(eng, coarse, d_est, 3, ex, ey)
-            eng.sweep(coarse, d_est, 3, d_rng, estMovingDist, d_psi, d_u, m_coarse)
-            eng.take_flags()
-            c = eng.read_matches(m_coarse)[0]
-            eng = self._build_field(eng, fine, m_coarse, MATCH_DOUBLES, float(c["x"]), float(c["y"]))
-            eng.sweep(fine, m_coarse, MATCH_DOUBLES, d_rng, estMovingDist, None, None, m_fine)
-            eng.take_flags()
-            f = eng.read_matches(m_fine)[0]
+                h[5] = np.random.random_sample()
+            h[6:] = rMeasure
+            io.d_in.copy_(io.h_in, non_blocking=True)
+            d_est, d_psi, d_u, d_rng = io.d_in[0:3], io.d_in[3:5], None if matchMax else io.d_in[5:6], io.d_in[6:]
+            m_coarse, m_fine = io.m_coarse, io.m_fine
+            # The fine window is centred on the coarse result, at most (ncell + 1) coarse cells from the estimate: when the coarse
+            # window widened by that much lies inside the map, the fine window cannot need growth (:27 at the fine level) and the
+            # call needs no host round trip between the levels -- one synchronisation per matchScan instead of two (round 3:
+            # 0.86 ms per call).  Only the tiles the sweep reads are blurred (slam2d_match): this method hands no field out.
+            margin = (coarse.ncell + 1) * coarse.step
+            m = og.map
+            settled = not (ex - coarse.reach - margin < m.lim_x[0] or ex + coarse.reach + margin > m.lim_x[1] or
+                           ey - coarse.reach - margin < m.lim_y[0] or ey + coarse.reach + margin > m.lim_y[1])
+            eng.match(coarse, d_est, 3, d_rng, estMovingDist, d_psi, d_u, m_coarse)
+            if not settled:
+                c = io.download(eng)[0]
+                og.checkAndExapndOG([float(c["x"]) - fine.reach, float(c["x"]) + fine.reach],
+                                    [float(c["y"]) - fine.reach, float(c["y"]) + fine.reach])
+                eng = og.engine()
+            eng.match(fine, m_coarse, MATCH_DOUBLES, d_rng, estMovingDist, None, None, m_fine)
+            c, f = io.download(eng)
             matched = {"x": float(f["x"]), "y": float(f["y"]), "theta": float(f["theta"]), "range": rMeasure}
             self.last = dict(coarse=c.copy(), fine=f.copy())
             return matched, np.float64(c["confidence"])                            # :79

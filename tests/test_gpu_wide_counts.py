@@ -91,3 +91,27 @@ def test_batched_filter_promotes_and_resamples_wide_maps(pkg, intel_readings):
         gv, gt = pf.engine.maps[i].download()
         assert np.array_equal(gv, p.og.visited) and np.array_equal(gt, p.og.total), f"particle {i}"
         assert tuple(pf.prev_matched[i]) == (p.prevMatchedReading["x"], p.prevMatchedReading["y"], p.prevMatchedReading["theta"])
+
+
+def test_promotion_behind_an_attached_engine(pkg, intel_readings):
+    """A grid whose one-particle engine has already uploaded its map descriptor receives counts that need 64-bit cells
+    (set_counts promotes the map in place: another array, another cell format).  The next update must see the new array --
+    round 3's engine kept the stale descriptor (freed 32-bit buffer, wide = 0)."""
+    r0 = intel_readings[0]
+    og = pkg.OccupancyGrid(30, 30, r0, 0.02, np.pi, 180, 10, 0.1)
+    ogo = so.GridOracle(30, 30, r0, 0.02, np.pi, 180, 10, 0.1)
+    og.updateOccupancyGrid(intel_readings[0])                  # builds the engine on the narrow map
+    ogo.updateOccupancyGrid(intel_readings[0])
+    assert not og.map.wide and og._engine is not None
+    v, t = _seeded_counts(ogo.visited.shape, 5, 70000)
+    og.set_counts(v, t)
+    ogo.visited[:], ogo.total[:] = v, t
+    assert og.map.wide
+    for reading in intel_readings[1:3]:
+        og.updateOccupancyGrid(reading)
+        ogo.updateOccupancyGrid(reading)
+    assert np.array_equal(og.occupancyGridVisited, ogo.visited) and np.array_equal(og.occupancyGridTotal, ogo.total)
+    sm, smo = pkg.ScanMatcher(og, *REF_SM), so.MatcherOracle(ogo, *REF_SM)
+    got, _ = sm.matchScan(dict(intel_readings[3]), 0.1, None, 5)
+    want, _ = smo.matchScan(dict(intel_readings[3]), 0.1, None, 5)
+    assert (got["x"], got["y"], got["theta"]) == (want["x"], want["y"], want["theta"])
