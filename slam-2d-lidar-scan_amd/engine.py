@@ -302,6 +302,7 @@ class MapState:
     int32 tensor."""
 
     PITCH_ALIGN = 16
+    layout_version = 0      # (class default: maps assembled field by field -- resample's gather, clone -- start at 0 too)
 
     def __init__(self, X, Y, device, cells=None):
         self.device = device
