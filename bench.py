@@ -869,17 +869,29 @@ def config3_closed_loop(P, device):
     for count, raw in enumerate(readings[:5], start=1):          # warm-up: first scans
         pf.updateParticles(raw, count)
         pf.weightUnbalanced()
-    pf = pkg.ParticleFilter(P, ogP, smP, device=device, rng=np.random.RandomState(0))
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    resamples = len(pf.run(readings))                 # the pipelined driver: same decisions as the per-call loop
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    m = pf.engine.maps[int(np.argmax(pf.weights))]
-    return dict(value=P * len(readings) / el, unit="particle-scans/s", scans=len(readings), particles=P, seconds=el,
-                scans_per_sec=len(readings) / el, resamples=resamples, final_map=[m.rows, m.cols],
-                note="closed loop through ParticleFilter.run(): host decisions (growth, resampling), per-scan H2D staging, one packed "
-                     "D2H per scan; scan s is enqueued before scan s-1's results are read")
+    def leg(force=(), groups=None):
+        pf = pkg.ParticleFilter(P, ogP, smP, device=device, rng=np.random.RandomState(0), groups=groups)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        resamples = pf.run(readings, force_resample=set(force))      # the pipelined driver: same decisions as the per-call loop
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        m = pf.engine.maps[int(np.argmax(pf.weights))]
+        return dict(value=P * len(readings) / el, unit="particle-scans/s", scans=len(readings), particles=P, seconds=el,
+                    scans_per_sec=len(readings) / el, resamples=len(resamples), state_moving_resamples=pf.stats["state_moving_resamples"],
+                    scans_voided_and_repeated=pf.stats.get("aborted", 0), scans_redone=pf.stats["redo"], particle_groups=pf.n_groups,
+                    final_map=[m.rows, m.cols])
+    out = leg()
+    out["note"] = ("closed loop through ParticleFilter.run(): host decisions (growth, resampling), per-scan H2D staging, one packed D2H per "
+                   "scan; scan s is enqueued before scan s-1's results are read; the particles in groups on their own streams "
+                   "(slam2d_groups_match / slam2d_groups_commit: two library calls per scan)")
+    out["one_group"] = {k: v for k, v in leg(groups=1).items() if k in ("value", "seconds", "scans_per_sec", "particle_groups")}
+    # the same log with a resample forced every 100 scans (64 particles never degenerate by themselves on this log): the gather
+    # of 64 maps, the stop of the group streams and the redone speculative scan are inside the timed figure
+    forced = leg(force=range(100, len(readings), 100))
+    out["forced_resample_every_100"] = {k: v for k, v in forced.items() if k in ("value", "seconds", "scans_per_sec", "resamples",
+                                                                                "state_moving_resamples", "scans_redone")}
+    return out
 
 
 class _SerialParticle:

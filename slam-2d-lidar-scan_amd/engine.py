@@ -671,6 +671,32 @@ class SearchLevel:
             **({k: t[k].data_ptr() for k in ("gmin", "gmin2", "pcells", "bounds", "bnb_best", "seed_key")} if self.abound else {}),
             **({k: t[k].data_ptr() for k in ("gmin", "gmin2", "pcells", "bounds", "tile_pmax", "bnb_best")} if self.bnb else {}))
 
+    _PER_PARTICLE = ("frames", "axis_x", "axis_y", "field", "cells", "kcount", "prior", "cube", "partials", "tilestate", "tilemin",
+                     "tilemax", "tilelist", "tilecount", "tileneed", "freerow", "prune_state", "beam_xy", "sync", "gmin", "gmin2",
+                     "pcells", "bounds", "tile_pmax", "bnb_best", "gmin3d", "p3cells", "bounds1", "seed_key")
+
+    def view(self, p0, p1):
+        """A Slam2dLevel describing particles [p0, p1) of this level: the same parameters, every per-particle pointer advanced to
+        particle p0 (the C ABI takes base pointers, so a group of particles is an offset view of every array; include/slam2d.h,
+        slam2d_groups_*).  The ring of the prior pruning is written per call and therefore the view's own.  The view's
+        generation stamp follows the parent's: call ``sync_view(view)`` after ``next_generation()``."""
+        v = Slam2dLevel.from_buffer_copy(self.c)
+        for k in self._PER_PARTICLE:
+            tz = self.t.get(k)
+            if tz is not None and getattr(self.c, k):
+                setattr(v, k, tz.data_ptr() + p0 * tz.stride(0) * tz.element_size())
+        img = self.fmax * self.fpitch
+        fb = 2 * self.tmax * ((2 * self.tmax + 17) & ~15)
+        v.occ = self.t["occ"].data_ptr() + p0 * img
+        v.tilemask = self.t["occ"].data_ptr() + self.P * img + p0 * fb
+        ring = torch.zeros_like(self.t["ring"])
+        self._view_rings = getattr(self, "_view_rings", []) + [ring]
+        v.ring = ring.data_ptr()
+        return v
+
+    def sync_view(self, v):
+        v.occ_gen = self.c.occ_gen
+
     def next_generation(self):
         """Advance the occupancy-image generation stamp (Slam2dLevel.occ_gen) for the next build: the
         image is zeroed once per 254 builds instead of at every build."""

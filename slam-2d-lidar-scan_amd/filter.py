@@ -96,10 +96,13 @@ class ParticleFilter:
     the reference's single-trajectory driver does, Utils/ScanMatcher_OGBased.py:244); no uniform is drawn then.  With one
     particle, ``ParticleFilter(1, ..., match_max=True).run(readings)`` is that driver (``:226-256``) on the batched path.
     ``bnb``: score the pose cubes by branch and bound over 4x4 pose tiles (include/slam2d.h) -- None: wherever
-    the cube is large enough for it to pay (engine.bnb_default), True / False: wherever applicable / nowhere."""
+    the cube is large enough for it to pay (engine.bnb_default), True / False: wherever applicable / nowhere.
+    ``groups``: ``run()`` steps the particles in this many groups, each on its own HIP stream, joined only by the weight
+    normaliser (slam2d_groups_match / slam2d_groups_commit: what bench.py's open loop does) -- None: two from 32 particles
+    up (SLAM2D_FILTER_GROUPS overrides), one for a sharded filter.  Results are those of one group."""
 
     def __init__(self, numParticles, ogParameters, smParameters, device=None, growable=True, rng=None,
-                 total_particles=None, first_index=0, group=None, bnb=None, match_max=False):
+                 total_particles=None, first_index=0, group=None, bnb=None, match_max=False, groups=None):
         (mapX, mapY, initXY, unit, fov, max_range, beams, wall) = ogParameters            # :66
         (sr, half_rad, sigma, move_sigma, max_dev, turn_sigma, miss, cf) = smParameters   # :67-68
         self.device = require_gpu(device or "cuda:0")
@@ -175,6 +178,10 @@ class ParticleFilter:
         env = os.environ.get("SLAM2D_PRUNE", "auto")
         self.prune_by_prior = env == "1" or (env != "0" and self.coarse.ntheta * self.coarse.nx ** 2 * beams >= BNB_MIN_WORK)
         self.step = 0
+        env_g = os.environ.get("SLAM2D_FILTER_GROUPS", "")
+        g = int(env_g) if env_g.isdigit() else (groups if groups is not None else (2 if P >= 32 else 1))
+        self.n_groups = g if (g > 1 and P % g == 0 and not self.sharded) else 1
+        self._grp = None                                 # streams, events, level views: built by the first grouped run()
         # run(): scans redone step by step (discarded speculative match); resample(): all / those that moved any state
         self.stats = {"redo": 0, "aborted": 0, "resamples": 0, "state_moving_resamples": 0}
 
@@ -294,6 +301,9 @@ class ParticleFilter:
         # pending = (count, reading, raw_heading, event, state of the random stream before the scan's uniforms) of the scan in flight
         resamples, pending = [], None
         events = [torch.cuda.Event(), torch.cuda.Event()]
+        grouped = self.n_groups > 1 and self.lazy_field and not self.sharded
+        if grouped and self._grp is None:
+            self._setup_groups()
 
         stream_rng = self.rng if self.rng is not None else np.random
         # A scan is speculated without knowing whether one of its search windows leaves a map (the reference would grow that map
@@ -331,6 +341,7 @@ class ParticleFilter:
 
         def plain(count, reading):
             """One scan through the unpipelined calls."""
+            self._quiesce_groups()
             self.updateParticles(reading, count)
             unb = self.weightUnbalanced()
             if on_scan is not None:
@@ -340,8 +351,13 @@ class ParticleFilter:
 
         def discard_speculation(rng_state):
             """Throw away what is in flight: its fault flags and its draws from the random stream."""
-            torch.cuda.current_stream().synchronize()
-            eng.flags.zero_()
+            if grouped:
+                torch.cuda.synchronize(self.device)
+                self._grp.flags2.zero_()
+                self._grp.active = False
+            else:
+                torch.cuda.current_stream().synchronize()
+                eng.flags.zero_()
             if rng_state is not None:
                 stream_rng.set_state(rng_state)
 
@@ -366,6 +382,7 @@ class ParticleFilter:
                         prev_count = pending[0]
                         was_aborted(pending)
                         if finish(pending):
+                            self._quiesce_groups()
                             resamples.append((prev_count, self.resample()))
                         pending = None
                     plain(count, reading)
@@ -378,8 +395,12 @@ class ParticleFilter:
             dist, raw_heading, has_turn, turn = self._raw_odometry(reading, prev_raw, prev_raw_heading)
             rng_state = stream_rng.get_state()
             state_before = rng_state
-            self._stage_inputs(parity, np.asarray(reading['range'], dtype=np.float64), None if self.match_max else self._draw_uniforms())
-            self._enqueue_match(reading, prev_raw, dist, has_turn, turn)          # speculative: scan count-1 not seen yet
+            if grouped:
+                self._stage_inputs_group(parity, np.asarray(reading['range'], dtype=np.float64), None if self.match_max else self._draw_uniforms())
+                self._enqueue_match_groups(reading, prev_raw, dist, has_turn, turn, parity)
+            else:
+                self._stage_inputs(parity, np.asarray(reading['range'], dtype=np.float64), None if self.match_max else self._draw_uniforms())
+                self._enqueue_match(reading, prev_raw, dist, has_turn, turn)          # speculative: scan count-1 not seen yet
             redo = False
             if pending is not None:
                 prev_count = pending[0]
@@ -394,6 +415,7 @@ class ParticleFilter:
                 if finish(pending):
                     # the reference draws the resample indices BEFORE this scan's uniforms: rewind, resample, redo the scan
                     stream_rng.set_state(rng_state)
+                    self._quiesce_groups()                      # (the speculative match of this scan reads the maps a resample moves)
                     idx = self.resample()
                     resamples.append((prev_count, idx))
                     rng_state = None
@@ -413,17 +435,143 @@ class ParticleFilter:
                 discard_speculation(rng_state)
                 plain(count, reading)
                 continue
-            self._enqueue_commit(abort_mask)
-            ev = events[parity]
-            ev.record()
+            if grouped:
+                ev = self._enqueue_commit_groups(abort_mask, parity)
+            else:
+                self._enqueue_commit(abort_mask)
+                ev = events[parity]
+                ev.record()
             pending = (count, reading, raw_heading, ev, state_before)
         if pending is not None:
             if was_aborted(pending):
                 redo_aborted(pending)
             elif finish(pending):
+                self._quiesce_groups()
                 resamples.append((pending[0], self.resample()))
-        eng.take_flags()        # a bit the last update raised after its launch's snapshot (slam2d_scan_commit) is still there
+        self._quiesce_groups()
+        if grouped:             # both buffers of fault bits (a bit an update raised after its launch's snapshot is still there)
+            f = self._grp.flags2.cpu().numpy().view(np.uint32)
+            self._grp.flags2.zero_()
+            bad = np.argwhere(f & _lib.FATAL_FLAGS)
+            if bad.size:
+                b, pp = bad[0]
+                raise _lib.Slam2dError(f"particle {int(pp)}: {_lib.describe_flags(int(f[b, pp]) & _lib.FATAL_FLAGS)}")
+        else:
+            eng.take_flags()    # a bit the last update raised after its launch's snapshot (slam2d_scan_commit) is still there
         return resamples
+
+    # ---- particle groups on streams (run() only): slam2d_groups_match / slam2d_groups_commit ----
+    def _setup_groups(self):
+        """Streams, events, offset views of both levels and the C descriptors of the groups.  The fault bits get a second buffer:
+        a group may be a scan ahead of another, and the commit of scan s decides its abort over ALL groups' bits of scan s --
+        scans alternate between the two buffers (include/slam2d.h, Slam2dScan.d_abort_flags)."""
+        L, eng, P, G, dev = _lib.lib(), self.engine, self.numParticles, self.n_groups, self.device
+        per = P // G
+        grp = type("Groups", (), {})()
+        grp.per = per
+        grp.flags2 = torch.zeros((2, P), dtype=torch.int32, device=dev)
+        eng.flags = grp.flags2[0]                        # (the call-by-call path keeps using buffer 0)
+        grp.d_in = [self._d_in, torch.zeros_like(self._d_in)]
+        grp.streams = [torch.cuda.Stream(dev) for _ in range(G)]
+        grp.norm = torch.cuda.Stream(dev)
+        grp.ev_matched = [C.c_void_p(L.slam2d_event_create()) for _ in range(G)]
+        grp.ev_done = [C.c_void_p(L.slam2d_event_create()) for _ in range(G)]
+        grp.ev_merged, grp.ev_inputs = C.c_void_p(L.slam2d_event_create()), C.c_void_p(L.slam2d_event_create())
+        grp.ready = [torch.cuda.Event(), torch.cuda.Event()]
+        grp.parts = torch.zeros((G, 3), dtype=torch.float64, device=dev)
+        grp.coarse = [self.coarse.view(g * per, (g + 1) * per) for g in range(G)]
+        grp.fine = [self.fine.view(g * per, (g + 1) * per) for g in range(G)]
+        grp.c = (_lib.Slam2dGroup * G)()
+        grp.scan = _lib.Slam2dScan()
+        for g in range(G):
+            cg = grp.c[g]
+            cg.coarse, cg.fine = C.pointer(grp.coarse[g]), C.pointer(grp.fine[g])
+            cg.P, cg.est_stride = per, 3
+            cg.stream = C.c_void_p(grp.streams[g].cuda_stream)
+            cg.ev_matched, cg.ev_done = grp.ev_matched[g], grp.ev_done[g]
+            cg.d_part = grp.parts[g].data_ptr()
+        sc = grp.scan
+        sc.n_local, sc.n_parts, sc.total_particles = P, G, P
+        sc.d_parts = grp.parts.data_ptr()
+        sc.norm_stream, sc.ev_merged, sc.ev_inputs = C.c_void_p(grp.norm.cuda_stream), grp.ev_merged, grp.ev_inputs
+        sc.merge = 1
+        grp.merged_once, grp.active = False, False
+        self._grp = grp
+
+    def _bind_groups(self, parity):
+        """Per-scan pointers of the group descriptors (resampling replaces pose / heading tensors, growth the map descriptors)."""
+        grp, eng, per = self._grp, self.engine, self._grp.per
+        B = self.lidar.beams
+        d_in = grp.d_in[parity]
+        flags = grp.flags2[parity]
+        sm = C.sizeof(_lib.Slam2dMap)
+        for lv, views in ((self.coarse, grp.coarse), (self.fine, grp.fine)):
+            for v in views:
+                lv.sync_view(v)
+        for g in range(self.n_groups):
+            cg, p0 = grp.c[g], g * per
+            cg.d_maps = eng.d_maps.data_ptr() + p0 * sm
+            cg.d_uniform = None if self.match_max else d_in.data_ptr() + (B + p0) * 8
+            cg.d_prev_pose, cg.d_heading = self.d_pose.data_ptr() + p0 * 24, self.d_head.data_ptr() + p0 * 8
+            cg.d_est_out, cg.d_psi_out = self.d_est.data_ptr() + p0 * 24, self.d_psi.data_ptr() + p0 * 16
+            cg.d_coarse, cg.d_fine = self.m_coarse.data_ptr() + p0 * MATCH_DOUBLES * 8, self.m_fine.data_ptr() + p0 * MATCH_DOUBLES * 8
+            cg.d_flags = flags.data_ptr() + p0 * 4
+            cg.d_logw = self.d_logw.data_ptr() + p0 * 8
+            cg.d_report = self.d_report.data_ptr() + p0 * 40
+            cg.d_flag_snapshot = self._d_flagsnap.data_ptr() + p0 * 4
+        sc = grp.scan
+        sc.d_ranges = d_in.data_ptr()
+        sc.d_abort_flags, sc.n_abort_flags = flags.data_ptr(), self.numParticles
+        sc.d_logw_all, sc.d_w, sc.d_stats = self.d_logw.data_ptr(), self.d_w.data_ptr(), self.d_stats.data_ptr()
+
+    def _quiesce_groups(self):
+        """Before anything that runs on the main stream over all particles (the call-by-call path, a resample, a growth): wait
+        for the group streams."""
+        if self._grp is not None and self._grp.active:
+            torch.cuda.synchronize(self.device)
+            self._grp.active = False
+
+    def _stage_inputs_group(self, parity, ranges, uniforms):
+        """Scan inputs through pinned buffer `parity` into the device buffer of the same parity (a group may still be reading the
+        other one); the groups' streams wait for the copy (Slam2dScan.ev_inputs)."""
+        h, B = self._h_in[parity], self.lidar.beams
+        h.numpy()[:B] = ranges
+        if uniforms is not None:
+            h.numpy()[B:] = uniforms
+        self._grp.d_in[parity].copy_(h, non_blocking=True)
+
+    def _enqueue_match_groups(self, reading, prev_raw, dist, has_turn, turn, parity):
+        eng, grp, L = self.engine, self._grp, _lib.lib()
+        eng.refresh_bits()
+        for lv in (self.coarse, self.fine):
+            if lv.c.occ_gen >= 254:                      # the stamp wraps: the occupancy images are zeroed -- with every stream idle
+                torch.cuda.synchronize(self.device)
+            lv.next_generation()
+        self._bind_groups(parity)
+        L.slam2d_event_record(grp.ev_inputs, _stream())  # behind the staging copy (and a bit refresh) on the main stream
+        sc = grp.scan
+        sc.est_moving_dist, sc.raw_theta, sc.prev_raw_theta = float(dist), float(reading['theta']), float(prev_raw['theta'])
+        sc.has_turn, sc.raw_turn = int(has_turn), float(turn)
+        sc.options = _lib.MATCH_PRUNE_BY_PRIOR if self.prune_by_prior else 0
+        sc.abort_mask = 0
+        _lib.check(L.slam2d_groups_match(C.byref(eng.lidar_c), grp.c, self.n_groups, C.byref(sc)), "slam2d_groups_match")
+        grp.active = True
+
+    def _enqueue_commit_groups(self, abort_mask, parity):
+        eng, grp, L = self.engine, self._grp, _lib.lib()
+        seen = eng.maps_version
+        eng._before_update()
+        if eng.maps_version != seen:                     # a map was promoted to 64-bit cells (new arrays, on the main stream)
+            torch.cuda.synchronize(self.device)
+            self._bind_groups(parity)
+        sc = grp.scan
+        sc.abort_mask, sc.wait_merged = int(abort_mask), int(grp.merged_once)
+        _lib.check(L.slam2d_groups_commit(C.byref(eng.lidar_c), grp.c, self.n_groups, C.byref(sc)), "slam2d_groups_commit")
+        grp.merged_once = True
+        with torch.cuda.stream(grp.norm):                # behind the merge: report, weights, variance and the fault-bit snapshot
+            self._h_pack.copy_(self._d_pack, non_blocking=True)
+            grp.ready[parity].record()
+        return grp.ready[parity]
 
     def _enqueue_match(self, reading, prev_raw, dist, has_turn, turn):
         """prior + coarse + fine match of one scan for all particles (slam2d_scan_match: one library call); reads the

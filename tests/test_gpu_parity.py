@@ -379,7 +379,18 @@ def test_pipelined_driver_reproduces_reference_runs(pkg, intel_readings, golden)
     _pipelined_run_against(pkg, load_golden(golden), intel_readings)
 
 
-@pytest.mark.parametrize("driver", ["calls", "run", "run_bnb"])
+@pytest.mark.parametrize("golden,groups", [("flow_fastslam_growth.npz", 3), ("flow_fastslam_long.npz", 2), ("flow_fastslam_long.npz", 3)])
+def test_grouped_pipelined_driver_reproduces_reference_runs(pkg, intel_readings, golden, groups):
+    """The pipelined driver with the particles in groups on their own HIP streams (slam2d_groups_match / slam2d_groups_commit:
+    one library call each per scan, the groups joined only by the normaliser's merge; the abort of a scan whose window left a
+    map decided over ALL groups' fault bits): the reference's results scan for scan -- growth inside speculated scans, natural and
+    forced resamples (every one a full stop of the group streams), the random stream's state at the end."""
+    pf = _pipelined_run_against(pkg, load_golden(golden), intel_readings, groups=groups)
+    assert pf.n_groups == groups and pf._grp is not None and pf._grp.merged_once
+    assert pf.stats["aborted"] > 0 or golden != "flow_fastslam_long.npz"
+
+
+@pytest.mark.parametrize("driver", ["calls", "run", "run_bnb", "run_groups"])
 def test_batched_filter_csail_matches_reference(pkg, csail_readings, driver):
     """The reference's FastSLAM on its second log (CSAIL, 361 beams; 3 particles x 60 scans from a 10 m map, two forced
     resamples): per-call loop, pipelined driver, and the latter with branch and bound forced on."""
@@ -387,7 +398,7 @@ def test_batched_filter_csail_matches_reference(pkg, csail_readings, driver):
     if driver == "calls":
         _batched_filter_against(pkg, z, csail_readings)
     else:
-        _pipelined_run_against(pkg, z, csail_readings, bnb=(driver == "run_bnb") or None)
+        _pipelined_run_against(pkg, z, csail_readings, bnb=(driver == "run_bnb") or None, groups=3 if driver == "run_groups" else 1)
 
 
 def test_batched_filter_growth_matches_reference(pkg, intel_readings):
