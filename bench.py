@@ -61,8 +61,9 @@ WORKLOADS = {
                     note="2000x2000@0.05m map, 1081 beams over 1.5 pi, coarse 702^2/139x41x41 + fine 1403^2/139x5x5"),
 }
 WORKLOAD_PARTICLES = {"config5": 128}
-PROF_EVERY_MAX = 7  # the dominant kernel keeps a HIP event pair around every n-th of its launches inside the timed region (n <= 7,
-#                     chosen so that at least ~20 launches are timed: an event pair holds the stream for ~6 us on each side)
+PROF_EVERY_MAX = int(os.environ.get("SLAM2D_BENCH_PROF_EVERY", "41"))  # (round 4: 7 -> 41: measured 0.1312 ms per step with a pair round every 7th launch, 0.1280 with every 51st, 0.1419 with every launch)
+# the dominant kernel keeps a HIP event pair around every n-th of its launches inside the timed region (n <= 41, chosen so
+# that at least ~20 launches are timed: an event pair holds the stream for ~6 us on each side of the kernel)
 KERNEL_SOURCE = os.path.join(REPO, "slam-2d-lidar-scan_amd", "csrc", "slam2d.hip")
 
 
@@ -90,6 +91,8 @@ def parse():
     ap.add_argument("--share-gpu", action="store_true", help="dry mode: ranks beyond the visible GPUs share them (rank r -> GPU r %% count)")
     ap.add_argument("--groups", type=int, default=None, help="particle groups per GPU, each on its own HIP stream (default: 2 from 32 "
                     "particles per GPU up, SLAM2D_BENCH_GROUPS overrides; 1 = one stream)")
+    ap.add_argument("--total-particles", type=int, default=None, help="STRONG scaling: this many particles over all ranks (e.g. 512 = "
+                    "BASELINE config 4, 1024 with --workload config5 = config 5); default: --particles per rank (weak scaling)")
     ap.add_argument("--spawn-check", action="store_true", help="launch plumbing only (no GPU work): every rank joins a gloo group, "
                     "rank 0 prints the rank count it saw")
     return ap.parse_args()
@@ -439,6 +442,8 @@ class HotPathGroups:
         sc.options = E._lib.MATCH_PRUNE_BY_PRIOR if self.prune else 0
         sc.d_parts, sc.n_parts, sc.total_particles = self.parts_all.data_ptr(), self.G * self.world, self.total_particles
         sc.wait_merged, sc.merge = int(self.merged_once), 0 if self.sharded else 1
+        if os.environ.get("SLAM2D_BENCH_UNCOUPLED") == "1":       # timing experiment: the groups never meet (no normaliser)
+            sc.wait_merged, sc.merge = 0, 0
         E._lib.check(L.slam2d_groups_step(self._lidar_ref, self.cgroups, self.G, C.byref(sc)), "slam2d_groups_step")
         if self.sharded:
             self._gather_and_merge()
@@ -881,11 +886,12 @@ def config3_closed_loop(P, device):
                     scans_per_sec=len(readings) / el, resamples=len(resamples), state_moving_resamples=pf.stats["state_moving_resamples"],
                     scans_voided_and_repeated=pf.stats.get("aborted", 0), scans_redone=pf.stats["redo"], particle_groups=pf.n_groups,
                     final_map=[m.rows, m.cols])
+    leg()                                              # (first leg: allocator warm-up, 1.6 GB of maps)
     out = leg()
     out["note"] = ("closed loop through ParticleFilter.run(): host decisions (growth, resampling), per-scan H2D staging, one packed D2H per "
-                   "scan; scan s is enqueued before scan s-1's results are read; the particles in groups on their own streams "
-                   "(slam2d_groups_match / slam2d_groups_commit: two library calls per scan)")
-    out["one_group"] = {k: v for k, v in leg(groups=1).items() if k in ("value", "seconds", "scans_per_sec", "particle_groups")}
+                   "scan; scan s is enqueued before scan s-1's results are read")
+    out["two_groups"] = {k: v for k, v in leg(groups=2).items() if k in ("value", "seconds", "scans_per_sec", "particle_groups")}
+    out["two_groups"]["note"] = "the particles in two groups on two streams (slam2d_groups_match / slam2d_groups_commit): no gain in the closed loop"
     # the same log with a resample forced every 100 scans (64 particles never degenerate by themselves on this log): the gather
     # of 64 maps, the stop of the group streams and the redone speculative scan are inside the timed figure
     forced = leg(force=range(100, len(readings), 100))
@@ -986,6 +992,42 @@ def dropin_serial(P, n_scans, device):
                      "particle and scan; host- and PCIe-inclusive")
 
 
+def normaliser_probe(cfg, P, scen, device, K, W, G, base_ms):
+    """What the SHARDED weight normaliser adds to a step -- its all-gather (RCCL, here over a one-rank group: the call, the
+    stream hand-over to the collective's stream and back) and the merge launch that replaces the in-launch normaliser -- and
+    the weak-scaling figure that follows from it: the data path has no other collective (Algorithm/FastSlam.py:25-27), so a
+    rank of an N-GPU job runs this step plus the all-gather's latency over xGMI.  A PREDICTION for the first multi-GPU run to be
+    checked against, not a measurement of it."""
+    made = False
+    try:
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ["MASTER_PORT"] = str(_free_port())
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+            made = True
+        os.environ["SLAM2D_FORCE_DIST"] = "1"
+        hot = make_hot_path(cfg, P, scen, device, G)
+        assert hot.sharded
+        for s in range(W):
+            hot.step(s)
+        hot.take_flags()
+        ms = 1e3 * statistics.median([timed_run(hot, W, K)[0] for _ in range(3)]) / K
+        hot.take_flags()
+        added = max(ms - base_ms, 0.0)
+        eff = base_ms / (base_ms + added)
+        return dict(ms_per_step_sharded_one_rank=ms, ms_per_step_unsharded=base_ms, normaliser_added_us=1e3 * added,
+                    predicted_weak_scaling_efficiency=eff, predicted_speedup_at_8_gpus=8 * eff,
+                    note="one-rank RCCL group on this GPU; the 8-rank all-gather of 8 x 48 bytes adds its xGMI latency (a few us) on top: "
+                         "expect slightly below the predicted figure")
+    except Exception as exc:
+        return dict(error=repr(exc))
+    finally:
+        os.environ.pop("SLAM2D_FORCE_DIST", None)
+        if made:
+            dist.destroy_process_group()
+
+
 def spawn_check(args, world, rank):
     """Launch plumbing only (CPU): every rank joins a gloo group and adds 1; rank 0 prints what it saw."""
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -1018,6 +1060,10 @@ def main():
     force_dist = os.environ.get("SLAM2D_FORCE_DIST") == "1"     # exercise the sharded code path on one GPU
     cfg = WORKLOADS[args.workload]
     P, K, W, R = args.particles or WORKLOAD_PARTICLES.get(args.workload, 64), args.steps, args.warmup, max(1, args.repeats)
+    if args.total_particles:
+        if args.total_particles % world:
+            raise SystemExit(f"bench.py: --total-particles {args.total_particles} is no multiple of the {world} ranks")
+        P = args.total_particles // world
     nprobe = min(8, K)
     scen = Scenario(cfg, P, W + max(K, nprobe), seed=0, rank=rank)
     cpu = None
@@ -1168,6 +1214,8 @@ def main():
             ds = dropin_serial(64, 53, device)
             if ds is not None:
                 variants["dropin_serial"] = ds
+        if world == 1 and not dist.is_initialized():
+            variants["sharded_normaliser_probe"] = normaliser_probe(cfg, P, scen, device, min(K, 60), W, G, 1e3 * elapsed / K)
     else:
         rf_main = roofline_of(hot, scen, P, 1e3 * elapsed / K, stage_ms, launches_per_step_of, args.workload, overhead_us)
 
@@ -1178,7 +1226,7 @@ def main():
             "metric": f"scans/sec ({cfg['beams']}-beam) x particles at fixed search volume",
             "value": total_units / elapsed, "unit": "particle-scans/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if args.total_particles else "weak", "vs_baseline": None,
             "dtype": "u32 fixed-point field, u64 exact accumulate, f64 priors/scores, u32 packed counts", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {cfg['note']}", "particles_per_gpu": P,
                        "total_particles": P * world, "pose_hypotheses_per_particle_scan":

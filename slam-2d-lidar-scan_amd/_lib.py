@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SLAM2D_LIB") or os.path.join(PKG_DIR, "libslam2d_hip.
 SRC_PATH = os.path.join(PKG_DIR, "csrc", "slam2d.hip")
 INCLUDE_DIR = os.path.join(REPO_DIR, "include")
 
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread"]
 
 # fault bits (include/slam2d.h SLAM2D_F_*)
 F_WINDOW_OUTSIDE_MAP = 0x01

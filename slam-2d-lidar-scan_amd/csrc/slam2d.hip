@@ -3,7 +3,7 @@
 // occupancy-grid update, weight normalisation.  See include/slam2d.h for the
 // contract and DESIGN.md for the layout and roofline of each kernel.
 //
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -pthread
 //   -ffp-contract=off is REQUIRED: every cell index is a trunc/rint of an fp64
 //   expression that sits on a lattice point, and the blur reproduces SciPy's
 //   operation order; a fused multiply-add anywhere changes results.
@@ -15,6 +15,10 @@
 #include <math.h>
 #include <limits.h>
 #include <stdlib.h>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 
 #include "slam2d.h"
 
@@ -41,10 +45,12 @@ StageProf g_prof[SLAM2D_STAGE_COUNT];
 unsigned g_prof_mask = 0;
 int g_prof_every = 1;                // an event pair around every g_prof_every-th launch of an enabled stage
 
+std::mutex g_prof_mutex;             // (the groups of slam2d_groups_* may be issued from several host threads)
 struct StageScope {
     int stage; hipStream_t s; int slot = -1;
     StageScope(int st, hipStream_t stream) : stage(st), s(stream) {
         if (st >= 0 && ((g_prof_mask >> st) & 1u)) {
+            std::lock_guard<std::mutex> lk(g_prof_mutex);
             StageProf& p = g_prof[st];
             if (p.seen++ % g_prof_every == 0 && p.used < p.capacity) { slot = p.used++; (void)hipEventRecord(p.start[slot], s); }
         }
@@ -3806,25 +3812,94 @@ static int groups_merge(const Slam2dGroup* groups, int32_t G, const Slam2dScan& 
     return (int)hipEventRecord((hipEvent_t)sc.ev_merged, ns);
 }
 
-int slam2d_groups_match(const Slam2dLidar* lidar, const Slam2dGroup* groups, int32_t G, const Slam2dScan* scan) {
-    int rc = groups_check(lidar, groups, G, scan, false);
-    for (int i = 0; i < G && !rc; ++i) rc = group_match(lidar, groups[i], *scan);
+// One host thread per group beyond the first: a HIP launch costs the calling thread ~4-5 us, a group's scan 7-15 launches, so
+// issuing G groups from one thread takes G x 35-70 us -- as long as the device needs for the whole scan from two groups up
+// (round 4: 0.076-0.109 ms of a 0.133 ms step with two groups, host-bound with four; the closed loop, twice the launches per
+// scan, ran SLOWER in two groups than in one).  The workers spin briefly between scans (a condition variable's wake-up costs as
+// much as the job) and sleep when no scan has come for a while.  SLAM2D_GROUP_THREADS=0: everything from the calling thread.
+enum { JOB_MATCH = 1, JOB_COMMIT = 2, JOB_STEP = 3 };
+static int run_group_job(int kind, const Slam2dLidar* lidar, const Slam2dGroup* groups, int G, int i, const Slam2dScan& sc) {
+    int rc = 0;
+    if (kind & JOB_MATCH) rc = group_match(lidar, groups[i], sc);
+    if (!rc && (kind & JOB_COMMIT)) rc = group_commit(lidar, groups, G, i, sc);
     return rc;
+}
+struct GroupWorker {
+    std::atomic<int> state{0};           // 0 idle, 1 job posted, 2 done
+    std::atomic<bool> sleeping{false};
+    std::mutex m;
+    std::condition_variable cv;
+    int kind = 0, G = 0, i = 0, dev = 0, rc = 0;
+    const Slam2dLidar* lidar = nullptr;
+    const Slam2dGroup* groups = nullptr;
+    const Slam2dScan* sc = nullptr;
+    void loop() {
+        int cur_dev = -1;
+        for (;;) {
+            int spins = 0;
+            while (state.load(std::memory_order_acquire) != 1) {
+                if (++spins < 200000) { __builtin_ia32_pause(); continue; }      // ~1-2 ms of polling, then sleep
+                std::unique_lock<std::mutex> lk(m);
+                sleeping.store(true);
+                cv.wait(lk, [&] { return state.load(std::memory_order_acquire) == 1; });
+                sleeping.store(false);
+            }
+            if (dev != cur_dev) { (void)hipSetDevice(dev); cur_dev = dev; }
+            rc = run_group_job(kind, lidar, groups, G, i, *sc);
+            state.store(2, std::memory_order_release);
+        }
+    }
+};
+static GroupWorker* group_worker(int k) {
+    static std::mutex mk;
+    static GroupWorker* pool[64] = {};
+    std::lock_guard<std::mutex> lk(mk);
+    if (!pool[k]) {
+        pool[k] = new GroupWorker;                       // (never freed: the thread sleeps until the process ends)
+        std::thread(&GroupWorker::loop, pool[k]).detach();
+    }
+    return pool[k];
+}
+static int run_groups(int kind, const Slam2dLidar* lidar, const Slam2dGroup* groups, int32_t G, const Slam2dScan* scan) {
+    static const bool threads = [] { const char* e = getenv("SLAM2D_GROUP_THREADS"); return !e || atoi(e) != 0; }();
+    if (!threads || G < 2) {
+        int rc = 0;
+        for (int i = 0; i < G && !rc; ++i) rc = run_group_job(kind, lidar, groups, G, i, *scan);
+        return rc;
+    }
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    GroupWorker* w[64];
+    for (int i = 1; i < G; ++i) {
+        GroupWorker* g = w[i] = group_worker(i - 1);
+        g->kind = kind; g->lidar = lidar; g->groups = groups; g->G = G; g->i = i; g->sc = scan; g->dev = dev;
+        g->state.store(1, std::memory_order_seq_cst);
+        if (g->sleeping.load()) { { std::lock_guard<std::mutex> lk(g->m); } g->cv.notify_one(); }
+    }
+    int rc = run_group_job(kind, lidar, groups, G, 0, *scan);
+    for (int i = 1; i < G; ++i) {
+        while (w[i]->state.load(std::memory_order_acquire) != 2) __builtin_ia32_pause();
+        if (!rc) rc = w[i]->rc;
+        w[i]->state.store(0, std::memory_order_release);
+    }
+    return rc;
+}
+
+int slam2d_groups_match(const Slam2dLidar* lidar, const Slam2dGroup* groups, int32_t G, const Slam2dScan* scan) {
+    const int rc = groups_check(lidar, groups, G, scan, false);
+    return rc ? rc : run_groups(JOB_MATCH, lidar, groups, G, scan);
 }
 
 int slam2d_groups_commit(const Slam2dLidar* lidar, const Slam2dGroup* groups, int32_t G, const Slam2dScan* scan) {
     int rc = groups_check(lidar, groups, G, scan, true);
-    for (int i = 0; i < G && !rc; ++i) rc = group_commit(lidar, groups, G, i, *scan);
+    if (!rc) rc = run_groups(JOB_COMMIT, lidar, groups, G, scan);     // (every ev_matched was recorded by the match call before this one)
     return rc ? rc : groups_merge(groups, G, *scan);
 }
 
 int slam2d_groups_step(const Slam2dLidar* lidar, const Slam2dGroup* groups, int32_t G, const Slam2dScan* scan) {
     int rc = groups_check(lidar, groups, G, scan, true);
     if (!rc && scan->abort_mask) return SLAM2D_E_BADARG;      // (an abort needs every match before any commit: use the two calls)
-    for (int i = 0; i < G && !rc; ++i) {
-        rc = group_match(lidar, groups[i], *scan);
-        if (!rc) rc = group_commit(lidar, groups, G, i, *scan);
-    }
+    if (!rc) rc = run_groups(JOB_STEP, lidar, groups, G, scan);
     return rc ? rc : groups_merge(groups, G, *scan);
 }
 

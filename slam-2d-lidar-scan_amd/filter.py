@@ -9,6 +9,7 @@ this class handles the particles of one rank.
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -98,8 +99,10 @@ class ParticleFilter:
     ``bnb``: score the pose cubes by branch and bound over 4x4 pose tiles (include/slam2d.h) -- None: wherever
     the cube is large enough for it to pay (engine.bnb_default), True / False: wherever applicable / nowhere.
     ``groups``: ``run()`` steps the particles in this many groups, each on its own HIP stream, joined only by the weight
-    normaliser (slam2d_groups_match / slam2d_groups_commit: what bench.py's open loop does) -- None: two from 32 particles
-    up (SLAM2D_FILTER_GROUPS overrides), one for a sharded filter.  Results are those of one group."""
+    normaliser (slam2d_groups_match / slam2d_groups_commit: what bench.py's open loop does) -- None: one (SLAM2D_FILTER_GROUPS
+    overrides): measured on the Intel log at 64 particles the closed loop gains nothing from two groups (0.253 s against 0.246 s for
+    910 scans; four: 0.43 s) -- unlike the open loop, every scan ends in a download the host waits for, so the groups cannot drift
+    apart and fill each other's gaps.  Results are those of one group."""
 
     def __init__(self, numParticles, ogParameters, smParameters, device=None, growable=True, rng=None,
                  total_particles=None, first_index=0, group=None, bnb=None, match_max=False, groups=None):
@@ -179,7 +182,7 @@ class ParticleFilter:
         self.prune_by_prior = env == "1" or (env != "0" and self.coarse.ntheta * self.coarse.nx ** 2 * beams >= BNB_MIN_WORK)
         self.step = 0
         env_g = os.environ.get("SLAM2D_FILTER_GROUPS", "")
-        g = int(env_g) if env_g.isdigit() else (groups if groups is not None else (2 if P >= 32 else 1))
+        g = int(env_g) if env_g.isdigit() else (groups if groups is not None else 1)
         self.n_groups = g if (g > 1 and P % g == 0 and not self.sharded) else 1
         self._grp = None                                 # streams, events, level views: built by the first grouped run()
         # run(): scans redone step by step (discarded speculative match); resample(): all / those that moved any state
@@ -566,6 +569,8 @@ class ParticleFilter:
             self._bind_groups(parity)
         sc = grp.scan
         sc.abort_mask, sc.wait_merged = int(abort_mask), int(grp.merged_once)
+        if os.environ.get("SLAM2D_FILTER_NO_ABORT") == "1":      # timing experiment only (a window leaving a map is then fatal)
+            sc.abort_mask = 0
         _lib.check(L.slam2d_groups_commit(C.byref(eng.lidar_c), grp.c, self.n_groups, C.byref(sc)), "slam2d_groups_commit")
         grp.merged_once = True
         with torch.cuda.stream(grp.norm):                # behind the merge: report, weights, variance and the fault-bit snapshot

@@ -138,3 +138,37 @@ def test_single_process_normaliser_matches_numpy():
     ref = np.exp(lw - lw.max()); ref /= ref.sum()
     np.testing.assert_allclose(w.numpy(), ref, rtol=1e-13)
     np.testing.assert_allclose(float(var), ((ref - 1 / 33) ** 2).sum(), rtol=1e-10)
+
+
+@pytest.mark.parametrize("world,total", [(8, 512), (8, 1024), (8, 509), (4, 64), (3, 10)])
+def test_point_to_point_order_is_identical_on_both_sides(world, total):
+    """NCCL / RCCL matches the point-to-point operations of a group call BY ORDER per (sender, receiver) pair, not by tag (gloo,
+    which the multi-process tests here run on, matches by tag and would hide a mismatch).  For random resample draws at the
+    8-rank sizes of BASELINE configs 4 and 5: the sequence of particles rank a sends to rank b is exactly the sequence rank b
+    receives from rank a -- and the receiver sizes every landing buffer from the SENDER's particle (migrate_ragged's size
+    table), so ragged maps fit.  Pure plan arithmetic: no process group needed.  (Algorithm/FastSlam.py:50-62.)"""
+    rs = np.random.RandomState(world * 1000 + total)
+    for trial in range(6):
+        w = rs.dirichlet(np.full(total, 0.05 if trial % 2 else 1.0))           # degenerate and flat weight vectors
+        idx = rs.choice(total, total, p=w)
+        rows = rs.randint(100, 200, total)                                      # every particle's map has its own extent
+        plans = [par.resample_plan(idx, total, world, r) for r in range(world)]
+        moved = 0
+        for a in range(world):
+            fa, _ = par.shard_range(total, world, a)
+            for b in range(world):
+                if a == b:
+                    continue
+                fb, _ = par.shard_range(total, world, b)
+                sent = [(tag, rows[fa + src]) for dst_rank, src, tag in plans[a][1] if dst_rank == b]
+                # the receiver looks the size up under the SOURCE particle's global index, indices[tag] (migrate_ragged)
+                recv = [(tag, rows[int(idx[tag])]) for src_rank, dst, tag in plans[b][2] if src_rank == a]
+                assert sent == recv, f"pair {a}->{b}: send and receive sequences differ"
+                assert [t for t, _ in sent] == sorted(t for t, _ in sent)
+                moved += len(sent)
+        # every destination slot is filled exactly once: locally or by one receive
+        for r in range(world):
+            first, count = par.shard_range(total, world, r)
+            filled = sorted([d for d, _ in plans[r][0]] + [d for _, d, _ in plans[r][2]])
+            assert filled == list(range(count))
+        assert moved == sum(par.owner_of(int(idx[d]), total, world) != par.owner_of(d, total, world) for d in range(total))
