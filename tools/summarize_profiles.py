@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turn the rocprofv3 outputs of tools/gpu_r3.sh (stages `kstat` and `pmc`) under gpurun_out/ into the small summaries
+"""Turn the rocprofv3 outputs of tools/gpu_r4.sh (stages `kstat` and `pmc`) under gpurun_out/ into the small summaries
 committed under profiles/:
 
   profiles/<round>_<workload>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of `python bench.py --workload <wl>`
@@ -19,7 +19,7 @@ import json
 import os
 import shutil
 
-ROUND = os.environ.get("ROUND", "r03")
+ROUND = os.environ.get("ROUND", "r04")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(ROOT)
 os.makedirs("profiles", exist_ok=True)
@@ -35,6 +35,9 @@ def short(name):
 
 
 for wl in ("config2", "ref2level", "config5"):
+    one = glob.glob(f"gpurun_out/kstat_{wl}_1group/**/k_kernel_stats.csv", recursive=True)
+    if one:                                              # all particles in ONE launch sequence (SLAM2D_BENCH_GROUPS=1)
+        shutil.copy(one[0], f"profiles/{ROUND}_{wl}_kernel_stats_1group.csv")
     found = glob.glob(f"gpurun_out/kstat_{wl}/**/k_kernel_stats.csv", recursive=True)
     if found:
         shutil.copy(found[0], f"profiles/{ROUND}_{wl}_kernel_stats.csv")
