@@ -337,6 +337,7 @@ class HotPathGroups:
         self.subs = [HotPath(cfg, per, ScenarioView(scen, g * per, (g + 1) * per), device) for g in range(G)]
         h0 = self.subs[0]
         self.E, self.L, self.lidar, self.coarse, self.fine, self.lazy = h0.E, h0.L, h0.lidar, h0.coarse, h0.fine, h0.lazy
+        self.par = h0.par
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.sharded = dist.is_initialized() and (self.world > 1 or os.environ.get("SLAM2D_FORCE_DIST") == "1")
@@ -350,6 +351,7 @@ class HotPathGroups:
         self.part_of = [self.parts_local[3 * g:3 * g + 3] for g in range(G)]
         self.parts_all = torch.zeros(3 * G * self.world, dtype=torch.float64, device=device) if self.sharded else self.parts_local
         self.via_host = self.sharded and dist.get_backend() == "gloo"
+        self.rccl = self.par.DirectRccl.create(device) if self.sharded and not self.via_host else None    # None: through torch.distributed
         self.streams = [torch.cuda.Stream(device) for _ in range(G)]
         self.norm = torch.cuda.Stream(device)
         self.handles = [C.c_void_p(st.cuda_stream) for st in self.streams]
@@ -451,14 +453,17 @@ class HotPathGroups:
 
     def _gather_and_merge(self):
         E, L = self.E, self.L
-        with torch.cuda.stream(self.norm):
-            if self.via_host:                            # gloo (dry mode): the partials hop through host memory
-                mine = self.parts_local.cpu()
-                got = [torch.empty_like(mine) for _ in range(self.world)]
-                dist.all_gather(got, mine)
-                self.parts_all.copy_(torch.cat(got))
-            else:
-                dist.all_gather_into_tensor(self.parts_all, self.parts_local)
+        if self.rccl is not None:                        # ONE ncclAllGather on the normaliser's stream, straight from librccl
+            self.rccl.all_gather(self.parts_local.data_ptr(), self.parts_all.data_ptr(), 3 * self.G, self.norm_handle)
+        else:
+            with torch.cuda.stream(self.norm):
+                if self.via_host:                        # gloo (dry mode): the partials hop through host memory
+                    mine = self.parts_local.cpu()
+                    got = [torch.empty_like(mine) for _ in range(self.world)]
+                    dist.all_gather(got, mine)
+                    self.parts_all.copy_(torch.cat(got))
+                else:
+                    dist.all_gather_into_tensor(self.parts_all, self.parts_local)
         E._lib.check(L.slam2d_weights_merge(E._ptr(self.d_logw), self.P, E._ptr(self.parts_all), self.G * self.world,
                                             self.total_particles, E._ptr(self.d_w), E._ptr(self.d_stats), self.norm_handle),
                      "slam2d_weights_merge")
@@ -992,6 +997,10 @@ def dropin_serial(P, n_scans, device):
                      "particle and scan; host- and PCIe-inclusive")
 
 
+def par_mod():
+    return importlib.import_module("slam-2d-lidar-scan_amd.parallel")
+
+
 def normaliser_probe(cfg, P, scen, device, K, W, G, base_ms):
     """What the SHARDED weight normaliser adds to a step -- its all-gather (RCCL, here over a one-rank group: the call, the
     stream hand-over to the collective's stream and back) and the merge launch that replaces the in-launch normaliser -- and
@@ -1007,16 +1016,37 @@ def normaliser_probe(cfg, P, scen, device, K, W, G, base_ms):
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
             made = True
         os.environ["SLAM2D_FORCE_DIST"] = "1"
-        hot = make_hot_path(cfg, P, scen, device, G)
-        assert hot.sharded
+
+        def leg(direct):
+            os.environ["SLAM2D_DIRECT_RCCL"] = "1" if direct else "0"
+            hot = make_hot_path(cfg, P, scen, device, G)
+            assert hot.sharded
+            for s in range(W):
+                hot.step(s)
+            hot.take_flags()
+            ms = 1e3 * statistics.median([timed_run(hot, W, K)[0] for _ in range(3)]) / K
+            hot.take_flags()
+            return ms, getattr(hot, "rccl", None) is not None
+        # the unsharded step again, HERE: a process that has created and dropped dozens of streams (the variants before this
+        # one) gets its new streams placed on fewer hardware queues, and every leg of this probe must see the same placement
+        os.environ.pop("SLAM2D_FORCE_DIST", None)
+        hot0 = make_hot_path(cfg, P, scen, device, G)
+        assert not hot0.sharded
         for s in range(W):
-            hot.step(s)
-        hot.take_flags()
-        ms = 1e3 * statistics.median([timed_run(hot, W, K)[0] for _ in range(3)]) / K
-        hot.take_flags()
-        added = max(ms - base_ms, 0.0)
+            hot0.step(s)
+        hot0.take_flags()
+        base_here = 1e3 * statistics.median([timed_run(hot0, W, K)[0] for _ in range(3)]) / K
+        hot0.take_flags()
+        del hot0
+        os.environ["SLAM2D_FORCE_DIST"] = "1"
+        ms, direct = leg(True)
+        ms_c10d = leg(False)[0] if direct else ms
+        added = max(ms - base_here, 0.0)
         eff = base_ms / (base_ms + added)
-        return dict(ms_per_step_sharded_one_rank=ms, ms_per_step_unsharded=base_ms, normaliser_added_us=1e3 * added,
+        return dict(ms_per_step_sharded_one_rank=ms, ms_per_step_unsharded=base_here, ms_per_step_headline=base_ms, normaliser_added_us=1e3 * added,
+                    collective="ncclAllGather straight from librccl on the normaliser's stream" if direct else "torch.distributed all_gather_into_tensor",
+                    direct_rccl_error=None if direct else par_mod().DirectRccl.last_error,
+                    ms_per_step_through_torch_distributed=ms_c10d,
                     predicted_weak_scaling_efficiency=eff, predicted_speedup_at_8_gpus=8 * eff,
                     note="one-rank RCCL group on this GPU; the 8-rank all-gather of 8 x 48 bytes adds its xGMI latency (a few us) on top: "
                          "expect slightly below the predicted figure")
@@ -1024,6 +1054,7 @@ def normaliser_probe(cfg, P, scen, device, K, W, G, base_ms):
         return dict(error=repr(exc))
     finally:
         os.environ.pop("SLAM2D_FORCE_DIST", None)
+        os.environ.pop("SLAM2D_DIRECT_RCCL", None)
         if made:
             dist.destroy_process_group()
 

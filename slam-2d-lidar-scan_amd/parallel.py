@@ -74,6 +74,87 @@ def normalize_sharded(logw_local, total, group=None):
     return w, logw, variance
 
 
+class DirectRccl:
+    """The normaliser's all-gather as ONE ``ncclAllGather`` call on the caller's own HIP stream, straight from librccl.
+
+    Through ``torch.distributed`` the 24-48 bytes per rank cost the host ~100 us per scan (c10d's dispatch, its work objects
+    and the hand-over to and from the process group's private stream: measured 0.232 against 0.128 ms per step on one rank,
+    round 4) -- as much as the whole step's kernels, which would cap an 8-GPU job near 4.4x.  RCCL's own call costs a few us
+    and needs no stream hand-over: the collective sits on the stream that already waits for the groups' updates, the merge
+    launch follows it in stream order.  ``torch.distributed`` (backend nccl) is still what forms the job: it carries the
+    unique id to the ranks once, and it stays the fallback -- ``create`` returns None whenever anything here fails, does not
+    finish within its time limit or fails its self-check (every rank contributes f(rank); every rank must see all of them).
+    SLAM2D_DIRECT_RCCL=0 disables it."""
+
+    _DOUBLE = 8                                            # ncclFloat64 (rccl.h)
+
+    @classmethod
+    def create(cls, device, group=None, timeout=60.0):
+        import os
+        import threading
+        if os.environ.get("SLAM2D_DIRECT_RCCL", "1") == "0" or not dist.is_initialized() or dist.get_backend(group) != "nccl":
+            return None
+        box = {}
+
+        def work():
+            try:
+                box["obj"] = cls(device, group)
+            except Exception as exc:                       # any failure: the c10d path stands
+                box["err"] = repr(exc)
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        th.join(timeout)
+        if th.is_alive() or "obj" not in box:
+            cls.last_error = "timed out" if th.is_alive() else box.get("err")
+            return None
+        return box["obj"]
+
+    last_error = None
+
+    def __init__(self, device, group=None):
+        import ctypes as C
+        import os
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        torch.cuda.set_device(device)                      # (this may be a helper thread: the device is per thread)
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")      # the RCCL torch itself runs on
+        self.L = L = C.CDLL(path if os.path.exists(path) else "librccl.so")
+
+        class Uid(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+        L.ncclGetUniqueId.argtypes, L.ncclGetUniqueId.restype = [C.POINTER(Uid)], C.c_int
+        L.ncclCommInitRank.argtypes, L.ncclCommInitRank.restype = [C.POINTER(C.c_void_p), C.c_int, Uid, C.c_int], C.c_int
+        L.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+        L.ncclAllGather.restype = C.c_int
+        uid = Uid()
+        if self.rank == 0 and L.ncclGetUniqueId(C.byref(uid)) != 0:
+            raise RuntimeError("ncclGetUniqueId failed")
+        t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).to(device)
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        C.memmove(C.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
+        self.comm = C.c_void_p()
+        rc = L.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank)
+        if rc != 0:
+            raise RuntimeError(f"ncclCommInitRank: error {rc}")
+        self._as_ptr = C.c_void_p
+        # self-check on the caller's device: every rank contributes (rank + 1) * [1.5, 2.5, 3.5]
+        mine = torch.tensor([1.5, 2.5, 3.5], dtype=torch.float64, device=device) * (self.rank + 1)
+        got = torch.zeros(3 * self.world, dtype=torch.float64, device=device)
+        st = torch.cuda.current_stream(device)
+        st.synchronize()
+        self.all_gather(mine.data_ptr(), got.data_ptr(), 3, st.cuda_stream)
+        st.synchronize()
+        want = torch.cat([torch.tensor([1.5, 2.5, 3.5], dtype=torch.float64) * (r + 1) for r in range(self.world)])
+        if not torch.equal(got.cpu(), want):
+            raise RuntimeError("direct RCCL all-gather failed its self-check")
+
+    def all_gather(self, send_ptr, recv_ptr, count, stream_handle):
+        """recv[rank * count ...] = send[0 .. count) of every rank, float64, enqueued on ``stream_handle`` (a hipStream_t)."""
+        rc = self.L.ncclAllGather(self._as_ptr(send_ptr), self._as_ptr(recv_ptr), count, self._DOUBLE, self.comm,
+                                  stream_handle if isinstance(stream_handle, self._as_ptr) else self._as_ptr(stream_handle))
+        if rc != 0:
+            raise RuntimeError(f"ncclAllGather: error {rc}")
+
+
 class ShardedNormalizer:
     """``normalize_sharded`` for device-resident particles as two HIP launches around the one
     collective: ``slam2d_weights_local`` (log-weights += log-confidence, this rank's three partials),
@@ -87,6 +168,7 @@ class ShardedNormalizer:
         self.part = torch.zeros(3, dtype=torch.float64, device=device)
         self.parts = torch.zeros(3 * self.world, dtype=torch.float64, device=device)
         self.via_host = dist.is_initialized() and dist.get_backend(group) == "gloo"
+        self.rccl = DirectRccl.create(device, group) if dist.is_initialized() and not self.via_host else None
         # overlap: the collective and the merge run on a side stream, so the launch stream goes straight on to the next
         # scan's match (which needs no weight); the results are ordered by events -- the next call waits for this merge
         # before it touches logw, readers of w / stats call wait() first
@@ -146,6 +228,8 @@ class ShardedNormalizer:
             got = [torch.empty_like(mine) for _ in range(self.world)]
             dist.all_gather(got, mine, group=self.group)
             self.parts.copy_(torch.cat(got))
+        elif self.rccl is not None:                           # one RCCL call on the launch stream itself (no c10d, no stream hop)
+            self.rccl.all_gather(self.part.data_ptr(), self.parts.data_ptr(), 3, stream)
         else:
             dist.all_gather_into_tensor(self.parts, self.part, group=self.group)
         self.check(self.lib.slam2d_weights_merge(logw.data_ptr(), n, self.parts.data_ptr(), self.world, self.total,
