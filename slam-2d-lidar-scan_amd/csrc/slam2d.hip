@@ -3012,6 +3012,7 @@ __global__ __launch_bounds__(256, UPDB_MIN_WAVES) void k_grid_update(Slam2dLidar
             return;
         }
     }
+    DBG_CLOCK(58, wj.logw && blockIdx.x == 0);
     if (wj.logw && blockIdx.x == 0) {                      // one extra block: the normaliser, beside the update (one launch less;
         //                                                    block 0, so that it starts with the launch and not as its tail)
         if (wj.fine) {                                     // ... after the scan's bookkeeping (the update blocks take their
@@ -3025,9 +3026,11 @@ __global__ __launch_bounds__(256, UPDB_MIN_WAVES) void k_grid_update(Slam2dLidar
             weights_local_body(wj.logw, wj.logconf, wj.cstride, wj.N, wj.part);
         }
         else weights_body(wj.logw, wj.logconf, wj.cstride, wj.N, wj.w, wj.stats, wj.flags, wj.flag_snapshot, true);
+        DBG_CLOCK(59, true);
         return;
     }
     const int bidx = blockIdx.x - (wj.logw ? 1 : 0);       // (a particle's blocks still share blockIdx.x % 8, i.e. their XCD)
+    DBG_CLOCK(60, bidx == 0);
     const int xcd = bidx & 7, q = bidx >> 3;
     const int p = (q / groups) * 8 + xcd, g = q % groups;
     if (p >= P) return;
@@ -3197,6 +3200,7 @@ __global__ __launch_bounds__(256, UPDB_MIN_WAVES) void k_grid_update(Slam2dLidar
             }
         }
     }
+    DBG_CLOCK(62, bidx == 0);
     if (f) atomicOr(&flags[p], f);
 }
 
