@@ -1246,7 +1246,19 @@ def main():
             if ds is not None:
                 variants["dropin_serial"] = ds
         if world == 1 and not dist.is_initialized():
-            variants["sharded_normaliser_probe"] = normaliser_probe(cfg, P, scen, device, min(K, 60), W, G, 1e3 * elapsed / K)
+            # (on a helper thread with a time limit: forming a process group is the one thing in this run that could wait for
+            # somebody else; the JSON line must come out regardless)
+            import threading
+            box = {}
+
+            def probe():
+                torch.cuda.set_device(device)
+                box["r"] = normaliser_probe(cfg, P, scen, device, min(K, 60), W, G, 1e3 * elapsed / K)
+            th = threading.Thread(target=probe, daemon=True)
+            th.start()
+            th.join(120.0)
+            variants["sharded_normaliser_probe"] = box.get("r", {"error": "no result within 120 s"})
+            main.hung_probe = th.is_alive()
     else:
         rf_main = roofline_of(hot, scen, P, 1e3 * elapsed / K, stage_ms, launches_per_step_of, args.workload, overhead_us)
 
@@ -1283,7 +1295,9 @@ def main():
             out["variants"] = variants
         if cpu is not None:
             out["cpu_baseline"] = cpu
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if getattr(main, "hung_probe", False):
+        os._exit(0)                                    # (a stuck helper thread must not keep the process)
     if dist.is_initialized():
         dist.destroy_process_group()
 

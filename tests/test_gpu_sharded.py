@@ -107,6 +107,8 @@ def _rccl_worker(port, out_path):
             stats = torch.zeros(2, dtype=torch.float64, device=dev)
             norm = None if mode == "plain" else par.ShardedNormalizer(L, E._lib.check, dev, n, overlap=mode.startswith("overlap"))
             assert norm is None or norm.overlap == mode.startswith("overlap")
+            if mode == "inorder":                    # round 4: the in-order normaliser's all-gather is ONE ncclAllGather straight from librccl
+                assert norm.rccl is not None, f"DirectRccl fell back to torch.distributed: {par.DirectRccl.last_error}"
             hist = []
             for s in range(scans):
                 if norm is None:

@@ -172,3 +172,14 @@ def test_point_to_point_order_is_identical_on_both_sides(world, total):
             filled = sorted([d for d, _ in plans[r][0]] + [d for _, d, _ in plans[r][2]])
             assert filled == list(range(count))
         assert moved == sum(par.owner_of(int(idx[d]), total, world) != par.owner_of(d, total, world) for d in range(total))
+
+
+def test_direct_rccl_is_only_for_nccl_groups():
+    """parallel.DirectRccl (the normaliser's all-gather straight from librccl) must decline -- and leave torch.distributed in
+    charge -- without a process group, and it can be switched off."""
+    assert par.DirectRccl.create(torch.device("cpu")) is None
+    os.environ["SLAM2D_DIRECT_RCCL"] = "0"
+    try:
+        assert par.DirectRccl.create(torch.device("cpu")) is None
+    finally:
+        os.environ.pop("SLAM2D_DIRECT_RCCL")
