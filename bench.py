@@ -77,7 +77,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS) + ["config3"],
+                    help="config3: the CLOSED loop over the bundled Intel log (ParticleFilter.run, host decisions, growth, resampling; "
+                         "sharded over the ranks with --gpus N: BASELINE config 4 is --gpus 8 --workload config3 --total-particles 512)")
+    ap.add_argument("--resample-every", type=int, default=100, help="config3: force a resample every this many scans (0: only the reference's own trigger)")
     ap.add_argument("--particles", type=int, default=None, help="particles per GPU (default 64; config5: 128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the variant measurements (brute-force sweep, prior-pruned "
@@ -1059,6 +1062,56 @@ def normaliser_probe(cfg, P, scen, device, K, W, G, base_ms):
             dist.destroy_process_group()
 
 
+def closed_loop_sharded(args, world, rank, device):
+    """BASELINE configs 3 / 4 as one command: FastSLAM over the bundled Intel log (910 scans x 180 beams, reference defaults, maps
+    growing from 50 m) through ParticleFilter.run(), the particles sharded over the ranks -- per scan one all-gather of the
+    normaliser's partials, per resample the weights' all-gather and the point-to-point migration of whole particles
+    (parallel.migrate_ragged).  Host-, PCIe- and collective-inclusive: a `step` is one scan of all particles."""
+    pkg = importlib.import_module("slam-2d-lidar-scan_amd")
+    dataio = importlib.import_module("slam-2d-lidar-scan_amd.dataio")
+    par = par_mod()
+    readings = dataio.read_npz(os.path.join(REPO, "tests", "golden", "intel_gfs.npz"))
+    K = min(args.steps, len(readings)) if args.steps != 100 else len(readings)        # (the default --steps means the whole log)
+    readings = readings[:K]
+    total = args.total_particles or (args.particles or 64) * world
+    first, count = par.shard_range(total, world, rank)
+    u = 0.02
+    ogP = [50.0, 50.0, readings[0], u, math.pi, 10, 180, 5 * u]
+    smP = [1.4, 0.25, 2, 0.1, 0.25, 0.3, 0.15, 5]
+    force = set(range(args.resample_every, K, args.resample_every)) if args.resample_every > 0 else set()
+
+    def leg():
+        kw = dict(total_particles=total, first_index=first) if world > 1 else {}
+        pf = pkg.ParticleFilter(count, ogP, smP, device=device, rng=np.random.RandomState(0), **kw)
+        if dist.is_initialized():
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = pf.run(readings, force_resample=force)
+        torch.cuda.synchronize()
+        if dist.is_initialized():
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if dist.is_initialized():
+            t = _ctl([el], device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, pf, res
+    leg()                                                  # warm-up (allocator, first builds)
+    el, pf, res = leg()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "scans/sec (180-beam) x particles, closed loop over the Intel log", "value": total * K / el, "unit": "particle-scans/s",
+            "n_gpus": world, "steps": K, "warmup": 0, "ms_per_step": 1e3 * el / K, "higher_is_better": True,
+            "scaling": "strong" if args.total_particles else "weak", "vs_baseline": None,
+            "dtype": "u32 fixed-point field, u64 exact accumulate, f64 priors/scores, u32 packed counts", "data": "bundled Intel log (tests/golden/intel_gfs.npz)",
+            "config": {"workload": "config3: FastSLAM closed loop, reference defaults, 910-scan Intel log, maps growing from 50 m",
+                       "total_particles": total, "particles_per_gpu": count, "resample_every": args.resample_every,
+                       "parallelism": f"particles sharded x{world}" if world > 1 else "single GPU"},
+            "scans_per_sec": K / el, "resamples": len(res), "state_moving_resamples": pf.stats["state_moving_resamples"],
+            "scans_redone": pf.stats["redo"], "final_map_of_particle_0": [pf.engine.maps[0].rows, pf.engine.maps[0].cols]}), flush=True)
+
+
 def spawn_check(args, world, rank):
     """Launch plumbing only (CPU): every rank joins a gloo group and adds 1; rank 0 prints what it saw."""
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -1089,16 +1142,17 @@ def main():
     if args.spawn_check:
         sys.exit(spawn_check(args, world, rank))
     force_dist = os.environ.get("SLAM2D_FORCE_DIST") == "1"     # exercise the sharded code path on one GPU
-    cfg = WORKLOADS[args.workload]
+    cfg = WORKLOADS.get(args.workload, WORKLOADS["ref2level"])
     P, K, W, R = args.particles or WORKLOAD_PARTICLES.get(args.workload, 64), args.steps, args.warmup, max(1, args.repeats)
     if args.total_particles:
         if args.total_particles % world:
             raise SystemExit(f"bench.py: --total-particles {args.total_particles} is no multiple of the {world} ranks")
         P = args.total_particles // world
     nprobe = min(8, K)
-    scen = Scenario(cfg, P, W + max(K, nprobe), seed=0, rank=rank)
+    closed = args.workload == "config3"
+    scen = None if closed else Scenario(cfg, P, W + max(K, nprobe), seed=0, rank=rank)
     cpu = None
-    if not args.no_cpu_baseline and world == 1 and rank == 0:
+    if not closed and not args.no_cpu_baseline and world == 1 and rank == 0:
         cpu = cpu_baseline(cfg, scen, args.cpu_seconds, args.cpu_workers)      # before HIP is initialised: the pool forks
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
@@ -1122,6 +1176,11 @@ def main():
         ranks_seen = int(census.item())
         if ranks_seen != world or dist.get_world_size() != world:
             raise SystemExit(f"bench.py: the {args.backend} group holds {ranks_seen} ranks, expected {world}")
+    if args.workload == "config3":
+        closed_loop_sharded(args, world, rank, device)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
     E = importlib.import_module("slam-2d-lidar-scan_amd.engine")
     lib = E._lib.lib()
     G = bench_groups(args.groups, P)

@@ -47,3 +47,20 @@ def test_driver_form_prints_the_contract_line():
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1 and rf["event_pairs"]["launches_timed"] >= 3
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert d["steps"] == 5 and d["timed_blocks"]["repeats"] == 5 and d["cpu_baseline"]["kind"] == "port"
+
+
+def test_closed_loop_workload_sharded_dry_mode():
+    """BASELINE configs 3 / 4 as one command (`--workload config3`): the closed loop over the Intel log through
+    ParticleFilter.run(), here 16 particles over two ranks on the one GPU (gloo), 200 scans with a forced resample (weights
+    all-gathered, whole particles migrated between the ranks), and the same on one rank: the job must finish with one line,
+    strong scaling declared, and the resample counted."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    two = _bench(["--workload", "config3", "--gpus", "2", "--backend", "gloo", "--share-gpu", "--total-particles", "16", "--steps", "200"])
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["config"]["particles_per_gpu"] == 8
+    assert two["resamples"] == 1 and two["steps"] == 200 and two["value"] > 0
+    one = _bench(["--workload", "config3", "--particles", "16", "--steps", "200"])
+    assert one["n_gpus"] == 1 and one["config"]["total_particles"] == 16 and one["resamples"] == 1
+    # the shared seeded stream makes the sharded run the same filter: the same map growth for particle 0
+    assert one["final_map_of_particle_0"] == two["final_map_of_particle_0"]
