@@ -355,8 +355,8 @@ class HotPathGroups:
         self.parts_all = torch.zeros(3 * G * self.world, dtype=torch.float64, device=device) if self.sharded else self.parts_local
         self.via_host = self.sharded and dist.get_backend() == "gloo"
         self.rccl = self.par.DirectRccl.create(device) if self.sharded and not self.via_host else None    # None: through torch.distributed
-        self.streams = [torch.cuda.Stream(device) for _ in range(G)]
-        self.norm = torch.cuda.Stream(device)
+        pool = self.E.group_streams(device, G + 1)           # the same streams for every hot path of the process (see there)
+        self.streams, self.norm = pool[1:], pool[0]
         self.handles = [C.c_void_p(st.cuda_stream) for st in self.streams]
         self.norm_handle = C.c_void_p(self.norm.cuda_stream)
         self.ev_done = [C.c_void_p(self.L.slam2d_event_create()) for _ in range(G)]       # events without timing, through the C ABI
@@ -1042,14 +1042,15 @@ def normaliser_probe(cfg, P, scen, device, K, W, G, base_ms):
         hot0.take_flags()
         del hot0
         os.environ["SLAM2D_FORCE_DIST"] = "1"
-        ms, direct = leg(True)
-        ms_c10d = leg(False)[0] if direct else ms
+        ms_c10d = leg(False)[0]                              # the default: torch.distributed.all_gather_into_tensor
+        ms_direct, direct = leg(True)                        # the option: one ncclAllGather straight from librccl
+        ms = ms_c10d
         added = max(ms - base_here, 0.0)
         eff = base_ms / (base_ms + added)
         return dict(ms_per_step_sharded_one_rank=ms, ms_per_step_unsharded=base_here, ms_per_step_headline=base_ms, normaliser_added_us=1e3 * added,
-                    collective="ncclAllGather straight from librccl on the normaliser's stream" if direct else "torch.distributed all_gather_into_tensor",
+                    collective="torch.distributed all_gather_into_tensor (the default)",
+                    ms_per_step_with_direct_ncclAllGather=ms_direct if direct else None,
                     direct_rccl_error=None if direct else par_mod().DirectRccl.last_error,
-                    ms_per_step_through_torch_distributed=ms_c10d,
                     predicted_weak_scaling_efficiency=eff, predicted_speedup_at_8_gpus=8 * eff,
                     note="one-rank RCCL group on this GPU; the 8-rank all-gather of 8 x 48 bytes adds its xGMI latency (a few us) on top: "
                          "expect slightly below the predicted figure")

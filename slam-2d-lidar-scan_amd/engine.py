@@ -80,6 +80,22 @@ class _on_launch_stream:
         return False
 
 
+_GROUP_STREAMS = {}
+
+
+def group_streams(device, n):
+    """``n`` HIP streams for particle groups (+ the normaliser's), created ONCE per device and handed out again to every later
+    caller.  torch hands out its 32 pooled streams round-robin, and which hardware queue a pooled stream sits on decides how
+    well the groups overlap: the twelfth set of three fresh streams in one process measured 0.146 ms per step against 0.130 for
+    the first eleven (round 4, tools/exp_stream_modes.py), later sets in a long bench run 0.23.  The first streams of a process
+    are spread over distinct queues; everybody gets those."""
+    key = str(torch.device(device))
+    have = _GROUP_STREAMS.setdefault(key, [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(device))
+    return have[:n]
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 

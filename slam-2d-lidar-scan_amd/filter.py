@@ -475,8 +475,9 @@ class ParticleFilter:
         grp.flags2 = torch.zeros((2, P), dtype=torch.int32, device=dev)
         eng.flags = grp.flags2[0]                        # (the call-by-call path keeps using buffer 0)
         grp.d_in = [self._d_in, torch.zeros_like(self._d_in)]
-        grp.streams = [torch.cuda.Stream(dev) for _ in range(G)]
-        grp.norm = torch.cuda.Stream(dev)
+        from .engine import group_streams
+        pool = group_streams(dev, G + 1)
+        grp.streams, grp.norm = pool[1:], pool[0]
         grp.ev_matched = [C.c_void_p(L.slam2d_event_create()) for _ in range(G)]
         grp.ev_done = [C.c_void_p(L.slam2d_event_create()) for _ in range(G)]
         grp.ev_merged, grp.ev_inputs = C.c_void_p(L.slam2d_event_create()), C.c_void_p(L.slam2d_event_create())

@@ -75,16 +75,18 @@ def normalize_sharded(logw_local, total, group=None):
 
 
 class DirectRccl:
-    """The normaliser's all-gather as ONE ``ncclAllGather`` call on the caller's own HIP stream, straight from librccl.
+    """The normaliser's all-gather as ONE ``ncclAllGather`` call on the caller's own HIP stream, straight from librccl -- an
+    OPTION (SLAM2D_DIRECT_RCCL=1), off by default.
 
-    Through ``torch.distributed`` the 24-48 bytes per rank cost the host ~100 us per scan (c10d's dispatch, its work objects
-    and the hand-over to and from the process group's private stream: measured 0.232 against 0.128 ms per step on one rank,
-    round 4) -- as much as the whole step's kernels, which would cap an 8-GPU job near 4.4x.  RCCL's own call costs a few us
-    and needs no stream hand-over: the collective sits on the stream that already waits for the groups' updates, the merge
-    launch follows it in stream order.  ``torch.distributed`` (backend nccl) is still what forms the job: it carries the
-    unique id to the ranks once, and it stays the fallback -- ``create`` returns None whenever anything here fails, does not
-    finish within its time limit or fails its self-check (every rank contributes f(rank); every rank must see all of them).
-    SLAM2D_DIRECT_RCCL=0 disables it."""
+    Measured on one rank (round 4, ``bench.py`` ``variants.sharded_normaliser_probe``): the sharded step costs 1.3 us more than
+    the unsharded one with this call and 2.1 us more through ``torch.distributed.all_gather_into_tensor`` -- the collective is
+    not what a scan waits for either way.  (An earlier measurement of +100 us "through c10d" turned out to be the placement of
+    freshly created streams on the hardware queues, see ``engine.group_streams``.)  The direct call saves the hand-over to and
+    from the process group's private stream and ~30 us of host time per scan, which matters only to a host-bound loop; it has
+    never run with two ranks (RCCL refuses two ranks on one GPU), so ``torch.distributed`` stays the default.  When enabled:
+    ``torch.distributed`` (backend nccl) still forms the job and carries the unique id to the ranks once, and ``create`` returns
+    None -- c10d stays in charge -- whenever anything here fails, does not finish within its time limit or fails its self-check
+    (every rank contributes f(rank); every rank must see all of them)."""
 
     _DOUBLE = 8                                            # ncclFloat64 (rccl.h)
 
@@ -92,7 +94,7 @@ class DirectRccl:
     def create(cls, device, group=None, timeout=60.0):
         import os
         import threading
-        if os.environ.get("SLAM2D_DIRECT_RCCL", "1") == "0" or not dist.is_initialized() or dist.get_backend(group) != "nccl":
+        if os.environ.get("SLAM2D_DIRECT_RCCL", "0") != "1" or not dist.is_initialized() or dist.get_backend(group) != "nccl":
             return None
         box = {}
 

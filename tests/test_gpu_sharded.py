@@ -98,6 +98,7 @@ def _rccl_worker(port, out_path):
         par = importlib.import_module("slam-2d-lidar-scan_amd.parallel")
         L = E._lib.lib()
         n, scans = 64, 25
+        os.environ["SLAM2D_DIRECT_RCCL"] = "1"        # the in-order mode below goes through parallel.DirectRccl, the overlapped one through c10d
         rng = np.random.default_rng(5)
         conf = torch.from_numpy(rng.normal(-40.0, 6.0, size=(scans, n))).to(dev)
         res = {}
@@ -107,7 +108,7 @@ def _rccl_worker(port, out_path):
             stats = torch.zeros(2, dtype=torch.float64, device=dev)
             norm = None if mode == "plain" else par.ShardedNormalizer(L, E._lib.check, dev, n, overlap=mode.startswith("overlap"))
             assert norm is None or norm.overlap == mode.startswith("overlap")
-            if mode == "inorder":                    # round 4: the in-order normaliser's all-gather is ONE ncclAllGather straight from librccl
+            if mode == "inorder":                    # round 4 option: the in-order normaliser's all-gather as ONE ncclAllGather straight from librccl
                 assert norm.rccl is not None, f"DirectRccl fell back to torch.distributed: {par.DirectRccl.last_error}"
             hist = []
             for s in range(scans):

@@ -177,9 +177,9 @@ def test_point_to_point_order_is_identical_on_both_sides(world, total):
 def test_direct_rccl_is_only_for_nccl_groups():
     """parallel.DirectRccl (the normaliser's all-gather straight from librccl) must decline -- and leave torch.distributed in
     charge -- without a process group, and it can be switched off."""
-    assert par.DirectRccl.create(torch.device("cpu")) is None
-    os.environ["SLAM2D_DIRECT_RCCL"] = "0"
+    assert par.DirectRccl.create(torch.device("cpu")) is None              # off by default
+    os.environ["SLAM2D_DIRECT_RCCL"] = "1"
     try:
-        assert par.DirectRccl.create(torch.device("cpu")) is None
+        assert par.DirectRccl.create(torch.device("cpu")) is None          # asked for, but there is no nccl group to ride on
     finally:
         os.environ.pop("SLAM2D_DIRECT_RCCL")
