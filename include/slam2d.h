@@ -14,7 +14,9 @@
  *   - plain C: PODs, raw pointers, sizes; no C++ or torch types.
  *   - every pointer named d_* (and every pointer inside the structs) is DEVICE memory
  *     owned by the caller (the Python side allocates it as torch tensors);
- *     the library allocates nothing and keeps no state between calls.
+ *     the library allocates no device memory and keeps no state between calls -- except the sleeping host threads of
+ *     slam2d_groups_* (one per particle group beyond the first, created on first use; SLAM2D_GROUP_THREADS=0: none) and
+ *     the event pairs of slam2d_prof_*.  The slam2d_groups_* calls are not re-entrant (one caller at a time).
  *   - every call enqueues work on `stream` (a hipStream_t passed as void*) and returns
  *     without synchronising; results are ordered after the call on that stream.
  *   - return value: 0 on success, otherwise a hipError_t code (> 0) or a
