@@ -2491,6 +2491,7 @@ __global__ __launch_bounds__(64) void k_bound2(Slam2dLevel lv, int P) {
 #define XS_MAX_PER 32
 #define XS_CELLS 8192                // cell-list entries staged in LDS (ntheta * kmax: config 2 6480, reference 5400)
 #define XS_SPLIT_MAX 8
+#define XS_SPLIT_LIGHT 4             // blocks per particle that work when one list pass holds all surviving tiles
 #define SLAM2D_BNB_MAX_THETA 256
 // SPLIT: nsplit blocks per particle (all of them on the particle's XCD, for the field's sake).  Every block scans the
 // particle's bounds (the same list comes out everywhere) and scores its share of the surviving tiles -- with one block
@@ -2634,6 +2635,16 @@ __global__ __launch_bounds__(XS_THREADS) void k_exact_select(Slam2dLevel lv, con
         }
     };
     if constexpr (SPLIT) {
+        // Round 4: how many of the particle's blocks work depends on how many tiles survived.  The launch carries up to
+        // XS_SPLIT_MAX blocks per particle; a particle with few surviving tiles (one list pass: the tracked case, 30-180 tiles)
+        // keeps the four that measured best there, the others leave after their scan -- every block finds the same n_all, so
+        // all agree on who stays and the ticket counts to that number.  A particle with many (a scan that does not fit its map:
+        // hundreds to a thousand) uses all of them: k_exact_select 119 -> 92 us and 132 -> 92 us on the inputs of
+        // bench.py's config2_displaced / config2_worst.  The scores and the order of every later stage do not depend on the
+        // split, so results are the same bits either way.
+        const int nsplit_all = nsplit;
+        nsplit = n_all > XS_TILES ? nsplit_all : min(nsplit_all, XS_SPLIT_LIGHT);
+        if (part >= nsplit) return;
         // ---- this block's share of the tiles, all passes; then the ticket ----
         for (int base = 0; base < n_all; base += XS_TILES) {           // (block-uniform)
             build_list(base);
@@ -3564,8 +3575,7 @@ static int ring_slot_bound(const Slam2dLevel& lv, double est_dist) {
 static int exact_split(const Slam2dLevel& lv, int P) {
     static const int forced = [] { const char* e = getenv("SLAM2D_XS_SPLIT"); return e ? atoi(e) : 0; }();
     if (!lv.sync) return 1;
-    int n = forced > 0 ? forced : 256 / (P > 0 ? P : 1);
-    if (forced <= 0 && n > 4) n = 4;
+    int n = forced > 0 ? forced : 256 / (P > 0 ? P : 1);      // (the kernel lets only XS_SPLIT_LIGHT of them work on a particle with few tiles)
     if (n > XS_SPLIT_MAX) n = XS_SPLIT_MAX;
     return n < 1 ? 1 : n;
 }
