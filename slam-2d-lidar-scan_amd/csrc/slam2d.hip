@@ -896,8 +896,28 @@ __global__ __launch_bounds__(TRIAGE_THREADS) void k_tile_triage(Slam2dLevel lv, 
 // and the update's -- x-adjacent tiles share the 128-byte lines of their occupancy halo (8 tiles wide), and with the blocks of a
 // particle dealt round the XCDs by blockIdx.x every XCD's L2 fetched its own copy of those lines (round 3: 34 MB of HBM
 // traffic per 32-particle launch for 6.9 MB processed, L2 hit rate 56 %).  bpp == 0: the (blocks, P) grid of rounds 1-3.
+// tail != 0 (round 4: levels without bounds, where that was all k_blur_check_redo was launched for): the minimum check of a frame
+// WITHOUT a free tile -- rare: then every tile was listed and blurred against the analytic floor -- is done by the last of the
+// particle's blur blocks to finish (arrival counter lv.sync[p][1]; plain stores + agent release before the ticket, agent acquire
+// after it: the slow, always-valid form -- it runs once in a blue moon).  A frame with a free tile, the normal case, costs nothing.
 template <int RAD>
-__global__ __launch_bounds__(BLUR_THREADS, BLUR_MIN_WAVES) void k_blur_clamp(Slam2dLevel lv, int P, int bpp) {
+__device__ __forceinline__ void blur_check_tail(const Slam2dLevel& lv, BlurLds<RAD>& sm, const int p, Slam2dFrame fr, uint32_t* flags) {
+    const int tid = threadIdx.x;
+    const int nty = (fr.fh + BLUR_TILE - 1) >> BLUR_SHIFT, ntx = (fr.fw + BLUR_TILE - 1) >> BLUR_SHIFT;
+    const double* __restrict__ tm = lv.tilemin + (size_t)p * lv.tmax * lv.tmax;
+    double m = INFINITY;
+    for (int t = tid; t < nty * ntx; t += BLUR_THREADS) m = fmin(m, tm[(t / ntx) * lv.tmax + (t % ntx)]);
+    m = wave64_min(m);
+    if (tid == 0) {
+        lv.frames[p].field_min = m;
+        if (m != lv.floor_value) { lv.frames[p].redo = 1; atomicOr(&flags[p], SLAM2D_F_FLOOR_REDO); }
+    }
+    if (m == lv.floor_value) return;                   // (wave-uniform)
+    fr.field_min = m;
+    for (int t = 0; t < nty * ntx; ++t) blur_tile<RAD>(lv, sm, p, fr, t / ntx, t % ntx, 1, true);
+}
+template <int RAD>
+__global__ __launch_bounds__(BLUR_THREADS, BLUR_MIN_WAVES) void k_blur_clamp(Slam2dLevel lv, int P, int bpp, uint32_t* flags, int tail) {
     __shared__ BlurLds<RAD> sm;
     int p = blockIdx.y, first = blockIdx.x, stride = gridDim.x;
     if (bpp > 0) {
@@ -912,6 +932,17 @@ __global__ __launch_bounds__(BLUR_THREADS, BLUR_MIN_WAVES) void k_blur_clamp(Sla
     for (int b = first; b < n; b += stride) {
         const int t = list[b];
         blur_tile<RAD>(lv, sm, p, fr, t / lv.tmax, t % lv.tmax, 0, false);
+    }
+    if (tail && !fr.min_known) {                       // (block-uniform; rare)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                       // this wave's per-tile minima leave the XCD's L2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned ticket = 0u;
+        if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(&lv.sync[p * SLAM2D_SYNC_WORDS + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
+        if (ticket != (unsigned)(min(n, stride) - 1)) return;                   // (blocks of this particle that had a tile)
+        if (threadIdx.x == 0) __hip_atomic_store(&lv.sync[p * SLAM2D_SYNC_WORDS + 1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        blur_check_tail<RAD>(lv, sm, p, fr, flags);
     }
 }
 
@@ -3406,12 +3437,18 @@ static int launch_frames(const Slam2dLidar& lid, const Slam2dLevel& lv, const Sl
 
 // occupied cells -> field image, tile triage (+ fill), blur + clamp, minimum check
 static int launch_field(const Slam2dLevel& lv, const Slam2dMap* d_maps, int P, uint32_t* d_flags, bool lazy, hipStream_t s,
-                        bool scattered = false) {
+                        bool scattered = false, bool field_max_needed = true) {
     if (!scattered) {
         StageScope prof(SLAM2D_STAGE_SCATTER, s);
         k_occ_scatter<<<dim3(cdiv(cdiv(lv.wmax, 32) + 1, 64), cdiv(lv.wmax, SCATTER_ROWS), P), dim3(64, 4), (size_t)lv.wmax * sizeof(int32_t), s>>>(lv, d_maps);
     }
     const int ntile = lv.tmax * lv.tmax;
+    // Without bounds (no gmin2 to derive), without the sweep's free-tile masks and without the prior pruning (which reads the
+    // field's maximum) k_blur_check_redo has ONE duty left: the minimum check of a frame without a free tile -- the blur's last
+    // block does it (k_blur_clamp, tail).  One launch per level less: 2 x 6 us per scan at the reference's defaults.
+    // SLAM2D_FOLD_CHECK=0: the separate launch.
+    static const bool fold = [] { const char* e = getenv("SLAM2D_FOLD_CHECK"); return !e || atoi(e) != 0; }();
+    const bool folded = fold && lazy && !lv.bnb && !sweep_skips(lv) && !field_max_needed && lv.sync != nullptr;
     {
         const int kb = (lv.blur_radius + 7) >> FLAG_SHIFT;
         const int rw = (flag_pitch(lv) >> 4) + 1;
@@ -3439,13 +3476,15 @@ static int launch_field(const Slam2dLevel& lv, const Slam2dMap* d_maps, int P, u
         static const bool xcd_pin = [] { const char* e = getenv("SLAM2D_BLUR_XCD"); return !e || atoi(e) != 0; }();
         const int bpp = xcd_pin ? min(ntile, blur_blocks) : 0;
         const dim3 bgrid = xcd_pin ? dim3((unsigned)cdiv(P, 8) * 8 * bpp) : dim3(min(ntile, blur_blocks), P);
+        const int tail = folded ? 1 : 0;
         switch (lv.blur_radius) {
-            case 2: k_blur_clamp<2><<<bgrid, BLUR_THREADS, 0, s>>>(lv, P, bpp); break;
-            case 4: k_blur_clamp<4><<<bgrid, BLUR_THREADS, 0, s>>>(lv, P, bpp); break;
-            case 8: k_blur_clamp<8><<<bgrid, BLUR_THREADS, 0, s>>>(lv, P, bpp); break;
-            default: k_blur_clamp<0><<<bgrid, BLUR_THREADS, 0, s>>>(lv, P, bpp); break;
+            case 2: k_blur_clamp<2><<<bgrid, BLUR_THREADS, 0, s>>>(lv, P, bpp, d_flags, tail); break;
+            case 4: k_blur_clamp<4><<<bgrid, BLUR_THREADS, 0, s>>>(lv, P, bpp, d_flags, tail); break;
+            case 8: k_blur_clamp<8><<<bgrid, BLUR_THREADS, 0, s>>>(lv, P, bpp, d_flags, tail); break;
+            default: k_blur_clamp<0><<<bgrid, BLUR_THREADS, 0, s>>>(lv, P, bpp, d_flags, tail); break;
         }
     }
+    if (folded) return 0;                              // the minimum check rode in the blur's launch: nothing else to do at this level
     // gmin2 only where a tile was written (SLAM2D_GMIN2_FULL=1: over the whole frame, as before round 3)
     static const bool full = [] { const char* e = getenv("SLAM2D_GMIN2_FULL"); return e && atoi(e) == 1; }();
     const int dirty = lazy && !full ? 1 : 0;
@@ -3661,7 +3700,7 @@ int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2
     // the endpoints need only the frame, so they run first and tell the field build which tiles matter
     if (framed && (rc = launch_frames(*lidar, lv, d_maps, P, d_est, est_stride, d_flags, true, s, d_ranges))) return rc;
     launch_endpoints(*lidar, lv, P, d_est, est_stride, d_ranges, est_moving_dist, d_psi_cs, d_flags, true, ring_chunks > 0, s, framed, own, merged);
-    if ((rc = launch_field(lv, d_maps, P, d_flags, true, s, merged))) return rc;
+    if ((rc = launch_field(lv, d_maps, P, d_flags, true, s, merged, ring_chunks > 0))) return rc;      // (the ring pass reads the field's maximum)
     if ((rc = launch_scores(lv, P, d_est, est_stride, d_uniform, d_out, s, ring_chunks))) return rc;
     return launch_status();
 }
