@@ -1523,8 +1523,59 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef SWEEP_DEPTH
 #define SWEEP_DEPTH 8
 #endif
+// arg-max, confidence and matched pose of particle p from the sweep's partials (k_select<0> without the soft-max draw: the very
+// expressions and summation order), by ONE wave -- the sweep's last-arriving block of the particle (k_sweep, sel_out).  The
+// partials were published with write-through stores by other blocks: they are read past this CU's L1.
+__device__ __forceinline__ Slam2dPartial load_partial_through(const Slam2dPartial* src) {
+    const unsigned long long* u = reinterpret_cast<const unsigned long long*>(src);
+    const unsigned long long a = __hip_atomic_load(u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(u + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long c = __hip_atomic_load(u + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    Slam2dPartial pt;
+    pt.max = __longlong_as_double((long long)a); pt.sumexp = __longlong_as_double((long long)b);
+    pt.argmax = (int)(unsigned)c; pt.has_nan = (int)(c >> 32);
+    return pt;
+}
+__device__ __forceinline__ void select_argmax_from_partials(const Slam2dLevel& lv, const int p, const int nW, const double* __restrict__ est,
+                                                            const int estride, Slam2dMatch* out) {
+    const int lane = threadIdx.x & 63;
+    const int nx = 2 * lv.ncell + 1, npose = nx * nx;
+    const Slam2dPartial* pt0 = lv.partials + (size_t)p * lv.npartial;
+    Best me{-INFINITY, INT_MAX, 0};
+    for (int w = lane; w < nW; w += WAVE) {
+        const Slam2dPartial pt = load_partial_through(pt0 + w);
+        Best cand{pt.max, pt.argmax, pt.has_nan};
+        if (better(cand, me)) me = cand;
+    }
+    me = wave_best_fast(me);
+    const double M = me.v;
+    const int per = (nW + WAVE - 1) / WAVE;
+    const int w0 = lane * per, w1 = min(nW, w0 + per);
+    double mine = 0.0;
+    for (int w = w0; w < w1; ++w) { const Slam2dPartial pt = load_partial_through(pt0 + w); mine += pt.sumexp * exp(pt.max - M); }
+    const double incl = wave_scan_incl_f64(mine);
+    const double total = readlane_f64(incl, WAVE - 1);
+    if (lane == 0) {
+        const int pick = me.i;
+        Slam2dMatch m;
+        const int it = pick / npose, rem = pick - it * npose;
+        const int iy = rem / nx, ix = rem - iy * nx;
+        const double ex = est[(size_t)p * estride], ey = est[(size_t)p * estride + 1], eth = est[(size_t)p * estride + 2];
+        m.x = ex + (double)(ix - lv.ncell) * lv.step;                               // :142-143
+        m.y = ey + (double)(iy - lv.ncell) * lv.step;
+        m.theta = eth + lv.thetas[it];
+        m.confidence = exp(M) * total;                                              // :141
+        m.log_confidence = M + log(total);
+        m.best_score = M;
+        m.pick = pick;
+        m.argmax = me.i;
+        out[p] = m;
+    }
+}
+
 template <int RQ, int mode, bool SKIP>
-__global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks, int bpp) {
+__global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks, int bpp, const double* __restrict__ sel_est = nullptr,
+                                               int sel_estride = 0, Slam2dMatch* sel_out = nullptr) {
     // mode 0: the whole cube.  mode 1 (RQ = 1): only the slots of the prior's ring (lv.ring).  mode 2: the
     // whole cube, for the particles the ring pass could not settle (lv.prune_state[p] != 0) -- see write_priors.
     // SKIP (RQ = 1): a wave-load whose whole patch (its 6-7 pose rows x all dx, at the cell) lies in tiles that
@@ -1715,7 +1766,15 @@ __global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks
     if (lane == 0) {
         Slam2dPartial pt;
         pt.max = me.v; pt.sumexp = ex; pt.argmax = me.i; pt.has_nan = me.nan;
-        lv.partials[(size_t)p * lv.npartial + it * chunks + ch] = pt;
+        Slam2dPartial* dst = lv.partials + (size_t)p * lv.npartial + it * chunks + ch;
+        if (mode == 0 && sel_out != nullptr) {             // (the particle's last block reads it in this launch: write-through)
+            unsigned long long* u = reinterpret_cast<unsigned long long*>(dst);
+            __hip_atomic_store(u, (unsigned long long)__double_as_longlong(pt.max), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(u + 1, (unsigned long long)__double_as_longlong(pt.sumexp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(u + 2, ((unsigned long long)(unsigned)pt.has_nan << 32) | (unsigned)pt.argmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            *dst = pt;
+        }
     }
     }
     };
@@ -1727,6 +1786,23 @@ __global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks
         }
     } else {
         sweep_chunk(w - it * groups);
+    }
+    if constexpr (mode == 0) {
+        // Round 4 (sel_out != NULL: a level matched by arg-max, i.e. no soft-max draw, which would need the cube): the block takes a
+        // ticket from the particle's third arrival counter once its partials are out, and the particle's LAST block selects --
+        // k_select's work without its launch.
+        if (sel_out != nullptr && wave == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            unsigned ticket = 0u;
+            if (lane == 0) ticket = __hip_atomic_fetch_add(&lv.sync[p * SLAM2D_SYNC_WORDS + 2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
+            if (ticket == (unsigned)(bpp - 1)) {
+                if (lane == 0) __hip_atomic_store(&lv.sync[p * SLAM2D_SYNC_WORDS + 2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                select_argmax_from_partials(lv, p, lv.ntheta * chunks, sel_est, sel_estride, sel_out);
+            }
+        }
     }
 }
 
@@ -3348,7 +3424,8 @@ __global__ void k_fill(uint32_t* cells, long long n, uint32_t value) {
 // C ABI
 // ------------------------------------------------------------------------------------
 template <int R>
-static void launch_sweep(const Slam2dLevel& lv, int P, int chunks, hipStream_t s, int mode = 0) {
+static void launch_sweep(const Slam2dLevel& lv, int P, int chunks, hipStream_t s, int mode = 0, const double* sel_est = nullptr,
+                         int sel_estride = 0, Slam2dMatch* sel_out = nullptr) {
     const int bpp = lv.ntheta * cdiv(chunks, mode == 2 ? SWEEP_REST_CHUNKS : (mode == 0 ? SWEEP_MAIN_CHUNKS : 1));   // blocks per particle
     const unsigned grid = cdiv(P, 8) * 8 * bpp;
     static const bool no_skip = [] { const char* e = getenv("SLAM2D_SWEEP_NOSKIP"); return e && atoi(e) == 1; }();
@@ -3358,12 +3435,12 @@ static void launch_sweep(const Slam2dLevel& lv, int P, int chunks, hipStream_t s
     if constexpr (R == 1) {
         if (mode == 1) { k_sweep<1, 1, false><<<grid, 256, 0, s>>>(lv, P, chunks, bpp); return; }
         if (skip) {
-            if (mode == 0) k_sweep<1, 0, true><<<grid, 256, 0, s>>>(lv, P, chunks, bpp);
+            if (mode == 0) k_sweep<1, 0, true><<<grid, 256, 0, s>>>(lv, P, chunks, bpp, sel_est, sel_estride, sel_out);
             else k_sweep<1, 2, true><<<grid, 256, 0, s>>>(lv, P, chunks, bpp);
             return;
         }
     }
-    if (mode == 0) k_sweep<R, 0, false><<<grid, 256, 0, s>>>(lv, P, chunks, bpp);
+    if (mode == 0) k_sweep<R, 0, false><<<grid, 256, 0, s>>>(lv, P, chunks, bpp, sel_est, sel_estride, sel_out);
     else if (mode == 2) k_sweep<R, 2, false><<<grid, 256, 0, s>>>(lv, P, chunks, bpp);
 }
 
@@ -3573,15 +3650,21 @@ static int launch_scores(const Slam2dLevel& lv, int P, const double* d_est, int 
         k_select<0><<<P, WAVE, 0, s>>>(lv, 1, 1, d_est, est_stride, d_uniform, d_out);
         return 0;
     }
+    // a level matched by arg-max (no soft-max draw: the fine level, matchMax) needs nothing of the cube for its selection: the
+    // sweep's last block of every particle does it from the partials (k_sweep, sel_out) and k_select is not launched
+    // (SLAM2D_FUSE_SELECT=0: the separate launch)
+    static const bool fuse_sel = [] { const char* e = getenv("SLAM2D_FUSE_SELECT"); return !e || atoi(e) != 0; }();
+    const bool fused = fuse_sel && mode == 0 && d_uniform == nullptr && lv.sync != nullptr;
     {
         StageScope prof(SLAM2D_STAGE_SWEEP, s);
         switch (bestR) {
-            case 1: launch_sweep<1>(lv, P, chunks, s, mode); break;
-            case 2: launch_sweep<2>(lv, P, chunks, s, mode); break;
-            case 3: launch_sweep<3>(lv, P, chunks, s, mode); break;
-            default: launch_sweep<4>(lv, P, chunks, s, mode); break;
+            case 1: launch_sweep<1>(lv, P, chunks, s, mode, fused ? d_est : nullptr, est_stride, fused ? d_out : nullptr); break;
+            case 2: launch_sweep<2>(lv, P, chunks, s, mode, fused ? d_est : nullptr, est_stride, fused ? d_out : nullptr); break;
+            case 3: launch_sweep<3>(lv, P, chunks, s, mode, fused ? d_est : nullptr, est_stride, fused ? d_out : nullptr); break;
+            default: launch_sweep<4>(lv, P, chunks, s, mode, fused ? d_est : nullptr, est_stride, fused ? d_out : nullptr); break;
         }
     }
+    if (fused) return 0;
     {
         StageScope prof(SLAM2D_STAGE_SELECT, s);
         if (mode == 0) k_select<0><<<P, WAVE, 0, s>>>(lv, chunks, bestR, d_est, est_stride, d_uniform, d_out);
