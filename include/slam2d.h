@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define SLAM2D_ABI_VERSION 12
+#define SLAM2D_ABI_VERSION 13
 #define SLAM2D_SPOKE_BAND 16         /* radial band width of the beam-major spoke table, in cells */
 
 /* library error codes (negative; positive values are hipError_t) */
@@ -398,7 +398,9 @@ int slam2d_grid_update_weights_local(const Slam2dLidar* lidar, const Slam2dMap* 
  *                         SLAM2D_F_WINDOW_OUTSIDE_MAP: if the match raised such a bit for ANY particle -- the reference would
  *                         have grown that map first (checkAndExapndOG, Utils/ScanMatcher_OGBased.py:27) -- the whole launch is
  *                         a no-op (no bookkeeping, no map update, no weights; d_flag_snapshot receives the bits, d_flags keeps
- *                         them) and the host grows the maps and runs the scan again.
+ *                         them) and the host grows the maps and runs the scan again.  ABI 13: the voided launch leaves the
+ *                         COARSE matched poses in d_report[i][0..2] (the other columns keep their old content): what the host
+ *                         needs to grow the maps for the fine windows (:27 at the fine level) without matching again.
  * Arguments as in the calls they bundle. */
 int slam2d_scan_match(const Slam2dLidar* lidar, const Slam2dLevel* coarse, const Slam2dLevel* fine, const Slam2dMap* d_maps,
                       int32_t P, const double* d_prev_pose, double raw_theta, double prev_raw_theta, int32_t has_turn,
@@ -514,6 +516,13 @@ int slam2d_map_refresh_bits(const Slam2dMap* d_maps, const int32_t* d_index, int
  *   d_out_u8[i][j] (may be NULL) the same as 8-bit grey, rint(255 * value). */
 int slam2d_map_image(const Slam2dMap* d_maps, int32_t p, int32_t x0, int32_t x1, int32_t y0, int32_t y1, int32_t flipud,
                      double* d_out, uint8_t* d_out_u8, void* stream);
+
+/* ABI 13: expandOccupancyGrid (Utils/OccupancyGrid.py:59-100) for the count array, a whole growth SEQUENCE at once: every cell
+ * of the caller-allocated new map (descriptors in HOST memory; new_map->cells [rows][pitch], new_map->occ_bits [rows][bits_pitch])
+ * is written in one pass -- the old map's cell (r, c) at (r + d_row, c + d_col) (d_row / d_col: rows / columns the sequence
+ * inserted on the low sides, :70-71; the high sides are appended, :81-82), SLAM2D_INIT_CELL elsewhere, pitch padding included --
+ * together with the new map's occupancy bits.  Both maps in the same cell format (`wide`). */
+int slam2d_map_grow(const Slam2dMap* old_map, const Slam2dMap* new_map, int32_t d_row, int32_t d_col, void* stream);
 
 /* Fill a map with SLAM2D_INIT_CELL (np.ones / 2*np.ones, Utils/OccupancyGrid.py:13-14). */
 int slam2d_map_fill(uint32_t* d_cells, int64_t n, uint32_t value, void* stream);

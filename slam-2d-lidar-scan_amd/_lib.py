@@ -40,7 +40,7 @@ MAX_BLUR_RADIUS = 16
 MAX_BEAMS = 2048
 SPOKE_BAND = 16
 SYNC_WORDS = 4
-ABI_VERSION = 12
+ABI_VERSION = 13
 MATCH_PRUNE_BY_PRIOR = 1
 PRUNE_MARGIN = 40.0
 BNB_MARGIN = 30.0
@@ -161,6 +161,7 @@ SIGNATURES = {
     "slam2d_gather_maps": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int64, _vp]),
     "slam2d_map_image": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     "slam2d_map_fill": (C.c_int, [_vp, C.c_int64, C.c_uint32, _vp]),
+    "slam2d_map_grow": (C.c_int, [C.POINTER(Slam2dMap), C.POINTER(Slam2dMap), C.c_int32, C.c_int32, _vp]),
     "slam2d_map_refresh_bits": (C.c_int, [_vp, _vp, C.c_int32, _vp]),
     "slam2d_device_sincos": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp]),
     "slam2d_prof_enable": (C.c_int, [C.c_uint32, C.c_int32]),

@@ -3132,6 +3132,12 @@ __global__ __launch_bounds__(256, UPDB_MIN_WAVES) void k_grid_update(Slam2dLidar
         if (__syncthreads_or(bad)) {
             if (blockIdx.x == 0 && wj.flag_snapshot)
                 for (int i = threadIdx.x; i < wj.N; i += blockDim.x) wj.flag_snapshot[i] = flags[i];
+            // ... except that the report receives the COARSE matched poses: the host grows the maps for the fine windows round
+            // them (Utils/ScanMatcher_OGBased.py:27 at the fine level) before it issues the scan again
+            if (blockIdx.x == 0 && wj.report && wj.coarse)
+                for (int i = threadIdx.x; i < wj.N; i += blockDim.x) {
+                    wj.report[5 * i] = wj.coarse[i].x; wj.report[5 * i + 1] = wj.coarse[i].y; wj.report[5 * i + 2] = wj.coarse[i].theta;
+                }
             return;
         }
     }
@@ -4091,6 +4097,48 @@ int slam2d_map_fill(uint32_t* d_cells, int64_t n, uint32_t value, void* stream) 
     long long blocks = (n + 256 * 8 - 1) / (256 * 8);
     if (blocks > 65535) blocks = 65535;
     k_fill<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(d_cells, (long long)n, value);
+    return launch_status();
+}
+
+// expandOccupancyGrid (Utils/OccupancyGrid.py:59-100) on the device, once per growth SEQUENCE: the new count array in one pass --
+// old content at its shifted place (np.insert / np.append of fresh columns / rows: :70-71, :81-82), SLAM2D_INIT_CELL everywhere
+// else, the pitch padding included -- and the new occupancy bits from the cells as they are written (k_refresh_bits' test).
+// One wave = 64 consecutive cells of a row: a 256-byte read where the old map covers them, a 256-byte write, one ballot.
+__global__ __launch_bounds__(256) void k_map_grow(const Slam2dMap o, const Slam2dMap n, const int d_row, const int d_col) {
+    const int lane = threadIdx.x & 63;
+    const int groups_per_row = (n.pitch + 63) >> 6;
+    const long long ngroups = (long long)n.rows * groups_per_row;
+    for (long long g = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); g < ngroups; g += (long long)gridDim.x * 4) {
+        const int row = (int)(g / groups_per_row), c0 = (int)(g - (long long)row * groups_per_row) << 6;
+        const int col = c0 + lane;
+        const int orow = row - d_row, ocol = col - d_col;
+        const bool inside = orow >= 0 && orow < o.rows && ocol >= 0 && ocol < o.cols && col < n.cols;
+        bool occ = false;
+        if (n.wide) {
+            unsigned long long v = ((unsigned long long)(SLAM2D_INIT_CELL >> 16) << 32) | (SLAM2D_INIT_CELL & 0xffffu);
+            if (inside) v = reinterpret_cast<const unsigned long long*>(o.cells)[(size_t)orow * o.pitch + ocol];
+            if (col < n.pitch) reinterpret_cast<unsigned long long*>(n.cells)[(size_t)row * n.pitch + col] = v;
+            occ = col < n.cols && 2ull * (v >> 32) > (v & 0xffffffffull);
+        } else {
+            uint32_t v = SLAM2D_INIT_CELL;
+            if (inside) v = o.cells[(size_t)orow * o.pitch + ocol];
+            if (col < n.pitch) n.cells[(size_t)row * n.pitch + col] = v;
+            occ = col < n.cols && 2u * (v >> 16) > (v & 0xffffu);                   // :29-31
+        }
+        const unsigned long long mask = __ballot(occ);
+        if (lane < 2 && (c0 >> 5) + lane < n.bits_pitch)
+            n.occ_bits[(size_t)row * n.bits_pitch + (c0 >> 5) + lane] = (uint32_t)(mask >> (32 * lane));
+    }
+}
+
+int slam2d_map_grow(const Slam2dMap* old_map, const Slam2dMap* new_map, int32_t d_row, int32_t d_col, void* stream) {
+    if (!old_map || !new_map || !old_map->cells || !new_map->cells || !new_map->occ_bits || d_row < 0 || d_col < 0) return SLAM2D_E_BADARG;
+    if (old_map->wide != new_map->wide || new_map->rows < old_map->rows + d_row || new_map->cols < old_map->cols + d_col ||
+        new_map->pitch < new_map->cols || new_map->bits_pitch * 32 < new_map->cols) return SLAM2D_E_BADARG;
+    const long long ngroups = (long long)new_map->rows * ((new_map->pitch + 63) >> 6);
+    long long blocks = (ngroups + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    k_map_grow<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(*old_map, *new_map, d_row, d_col);
     return launch_status();
 }
 

@@ -362,8 +362,8 @@ class MapState:
     def _sync_coords(self):
         self.lim_x = [self.X[0], self.X[-1]]           # mapXLim (:19, :86-87)
         self.lim_y = [self.Y[0], self.Y[-1]]           # mapYLim (:20, :88-89)
-        self.dX = _dev(self.X, self.device)
-        self.dY = _dev(self.Y, self.device)
+        xy = _dev(np.concatenate((self.X, self.Y)), self.device)          # (one upload)
+        self.dX, self.dY = xy[:len(self.X)], xy[len(self.X):]
 
     def desc(self):
         self._materialise()
@@ -440,13 +440,19 @@ class MapState:
             return
         old, rows, cols, dc, dr = self._pending
         self._pending = None
+        old_desc = Slam2dMap(cells=old.data_ptr(), rows=rows, cols=cols, pitch=self.pitch, wide=1 if self.wide else 0)
         self.pitch = -(-self.cols // self.PITCH_ALIGN) * self.PITCH_ALIGN
         with _on_launch_stream():
-            cells = torch.full((self.rows, self.pitch), _lib.INIT_CELL_WIDE if self.wide else _lib.INIT_CELL, dtype=old.dtype, device=self.device)
-            cells[dr:dr + rows, dc:dc + cols] = old[:, :cols]
-            self.cells = cells
-            self._alloc_bits()
+            # one pass on the device writes the new counts (old content shifted, fresh cells elsewhere) AND the new occupancy bits
+            # (slam2d_map_grow; round 3: fill + strided copy + zeroed bits + a refresh pass over the whole map, ~100 us per map)
+            self.cells = torch.empty((self.rows, self.pitch), dtype=old.dtype, device=self.device)
+            self.bits_pitch = -(-self.cols // 32)
+            self.bits = torch.empty((self.rows, self.bits_pitch), dtype=torch.int32, device=self.device)
             self._sync_coords()
+            new_desc = Slam2dMap(cells=self.cells.data_ptr(), occ_bits=self.bits.data_ptr(), rows=self.rows, cols=self.cols,
+                                 pitch=self.pitch, bits_pitch=self.bits_pitch, wide=1 if self.wide else 0)
+            _lib.check(_lib.lib().slam2d_map_grow(C.byref(old_desc), C.byref(new_desc), dr, dc, _stream()), "slam2d_map_grow")
+            self.bits_valid = True
         self.layout_version += 1
 
     def _grow(self, side, unit):

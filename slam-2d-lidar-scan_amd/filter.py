@@ -186,7 +186,7 @@ class ParticleFilter:
         self.n_groups = g if (g > 1 and P % g == 0 and not self.sharded) else 1
         self._grp = None                                 # streams, events, level views: built by the first grouped run()
         # run(): scans redone step by step (discarded speculative match); resample(): all / those that moved any state
-        self.stats = {"redo": 0, "aborted": 0, "resamples": 0, "state_moving_resamples": 0}
+        self.stats = {"redo": 0, "aborted": 0, "reissued": 0, "step_by_step": 0, "resamples": 0, "state_moving_resamples": 0}
 
     # ---- odometry prior (Algorithm/FastSlam.py:77-106) ----
     def _raw_odometry(self, raw, prev_raw=None, prev_raw_heading="same"):
@@ -344,6 +344,7 @@ class ParticleFilter:
 
         def plain(count, reading):
             """One scan through the unpipelined calls."""
+            self.stats["step_by_step"] += 1
             self._quiesce_groups()
             self.updateParticles(reading, count)
             unb = self.weightUnbalanced()
@@ -371,7 +372,23 @@ class ParticleFilter:
             discard_speculation(p[4])
             plain(p[0], p[1])
 
-        for count, reading in enumerate(readings, start=first_count):
+        # A voided scan is re-issued THROUGH THE PIPELINE once the maps have grown for it, as the step-by-step path grows them
+        # (Utils/ScanMatcher_OGBased.py:27, once per level): first for the coarse windows, from the poses the host holds; if
+        # those were inside already, for the fine windows, from the coarse matched poses the voided commit leaves in the scan's
+        # report (its coarse match was the one the step-by-step path would compute: same maps, same inputs, same uniforms).
+        # The re-issued coarse match then runs on the grown maps, the reference's on the maps before the growth: the same cells
+        # -- growth pads a map with unobserved cells and shifts its low limit by a whole number of cells, and a window's first
+        # map column rint((x_lo - lim) / unit) sits an integer away from rounding ties for poses that move in multiples of the
+        # match step.  A scan voided three times goes through the step-by-step calls.  (Round 3 ran every voided scan AND its
+        # successor step by step: 44 of the Intel log's 910 scans at 0.85 ms each.)  SLAM2D_FILTER_REISSUE=0 restores that.
+        reissue = os.environ.get("SLAM2D_FILTER_REISSUE", "1") != "0"
+        retried = (None, 0)                                  # (count of the scan last re-issued, how often)
+        if not isinstance(readings, (list, tuple)):
+            readings = list(readings)
+        i = 0
+        while i < len(readings):
+            count, reading = first_count + i, readings[i]
+            i += 1
             if count == 1 or (pending is None and self.prev_raw is None) or not self.lazy_field:
                 assert pending is None
                 plain(count, reading)
@@ -410,9 +427,24 @@ class ParticleFilter:
                 if was_aborted(pending):
                     # scan count-1 did not happen on the device: redo it (with the growth it needs), then this scan, whose
                     # speculative match started from a state that never was
-                    redo_aborted(pending)
-                    pending = None
+                    p, pending = pending, None
                     self.stats["redo"] += 1
+                    tries = retried[1] if retried[0] == p[0] else 0
+                    if reissue and tries < 2:
+                        self.stats["aborted"] = self.stats.get("aborted", 0) + 1
+                        coarse_xy = self._h_pack.numpy()[:5 * P].reshape(P, 5)[:, :2].copy()     # (a voided commit reports the coarse poses)
+                        discard_speculation(p[4])
+                        grew = self._grow_for_windows(self.prev_matched[:, 0], self.prev_matched[:, 1], self.coarse.reach)
+                        if not grew:
+                            grew = self._grow_for_windows(coarse_xy[:, 0], coarse_xy[:, 1], self.fine.reach)
+                        if grew:
+                            retried = (p[0], tries + 1)
+                            self.stats["reissued"] += 1
+                            i -= 2                              # both scans again, speculatively
+                            continue
+                        plain(p[0], p[1])
+                    else:
+                        redo_aborted(p)
                     plain(count, reading)
                     continue
                 if finish(pending):
