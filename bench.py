@@ -892,12 +892,14 @@ def config3_closed_loop(P, device):
         m = pf.engine.maps[int(np.argmax(pf.weights))]
         return dict(value=P * len(readings) / el, unit="particle-scans/s", scans=len(readings), particles=P, seconds=el,
                     scans_per_sec=len(readings) / el, resamples=len(resamples), state_moving_resamples=pf.stats["state_moving_resamples"],
-                    scans_voided_and_repeated=pf.stats.get("aborted", 0), scans_redone=pf.stats["redo"], particle_groups=pf.n_groups,
+                    scans_voided_and_repeated=pf.stats.get("aborted", 0), scans_redone=pf.stats["redo"], scans_reissued_in_pipeline=pf.stats["reissued"],
+                    scans_step_by_step=pf.stats["step_by_step"], particle_groups=pf.n_groups,
                     final_map=[m.rows, m.cols])
     leg()                                              # (first leg: allocator warm-up, 1.6 GB of maps)
     out = leg()
     out["note"] = ("closed loop through ParticleFilter.run(): host decisions (growth, resampling), per-scan H2D staging, one packed D2H per "
-                   "scan; scan s is enqueued before scan s-1's results are read")
+                   "scan; scan s is enqueued before scan s-1's results are read; a scan voided on the device (a search window left its map) is issued "
+                   "again through the pipeline once the maps have grown (slam2d_map_grow: one device pass per map)")
     out["two_groups"] = {k: v for k, v in leg(groups=2).items() if k in ("value", "seconds", "scans_per_sec", "particle_groups")}
     out["two_groups"]["note"] = "the particles in two groups on two streams (slam2d_groups_match / slam2d_groups_commit): no gain in the closed loop"
     # the same log with a resample forced every 100 scans (64 particles never degenerate by themselves on this log): the gather

@@ -61,6 +61,9 @@ def test_device_count_never_raises(L):
 
 def test_argument_errors_without_gpu(L):
     assert L.slam2d_map_fill(None, 0, 0, None) == -1
+    assert L.slam2d_map_grow(None, None, 0, 0, None) == -1
+    empty = _lib.Slam2dMap()
+    assert L.slam2d_map_grow(ctypes.byref(empty), ctypes.byref(empty), 0, 0, None) == -1          # (no arrays: refused before any launch)
     assert L.slam2d_weights_normalize(None, None, 1, 0, None, None, None) == -1
 
 

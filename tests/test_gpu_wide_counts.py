@@ -115,3 +115,41 @@ def test_promotion_behind_an_attached_engine(pkg, intel_readings):
     got, _ = sm.matchScan(dict(intel_readings[3]), 0.1, None, 5)
     want, _ = smo.matchScan(dict(intel_readings[3]), 0.1, None, 5)
     assert (got["x"], got["y"], got["theta"]) == (want["x"], want["y"], want["theta"])
+
+
+@pytest.mark.parametrize("wide", [False, True])
+def test_growth_sequence_in_one_device_pass_matches_the_oracle(pkg, wide):
+    """expandOccupancyGrid for a whole growth sequence at once (slam2d_map_grow behind MapState._materialise: new counts and
+    new occupancy bits in ONE pass): a map with seeded counts grows on all four sides -- twice on the low x side, so the content
+    moves by more than one step -- against the oracle's np.insert / np.append (Utils/OccupancyGrid.py:59-100): counts, limits,
+    coordinate vectors, and the occupancy bits the matcher reads (2 visited > total), in both cell formats."""
+    import torch
+    E = importlib.import_module("slam-2d-lidar-scan_amd.engine")
+    init = {"x": 0.3, "y": -0.2}
+    og = pkg.OccupancyGrid(6, 6, init, 0.05, np.pi, 90, 4, 0.1)
+    ogo = so.GridOracle(6, 6, init, 0.05, np.pi, 90, 4, 0.1)
+    hi = 70000 if wide else 900
+    v, t = _seeded_counts(ogo.visited.shape, 11, hi)
+    og.set_counts(v, t)
+    ogo.visited[:], ogo.total[:] = v, t
+    assert og.map.wide == wide
+    m = og.map
+    with m.deferred_growth():
+        for side in (1, 4, 1, 3, 2):
+            m._grow(side, 0.05)
+    for side in (1, 4, 1, 3, 2):
+        ogo._grow(side)
+    assert m.bits_valid                                   # (written by the growth pass itself: no refresh pass follows)
+    got_v, got_t = m.download()
+    assert got_v.shape == ogo.visited.shape
+    assert np.array_equal(got_v, ogo.visited) and np.array_equal(got_t, ogo.total)
+    assert np.array_equal(m.X, ogo.X) and np.array_equal(m.Y, ogo.Y)
+    assert (m.lim_x, m.lim_y) == (list(ogo.mapXLim), list(ogo.mapYLim))
+    assert np.array_equal(m.dX.cpu().numpy(), m.X) and np.array_equal(m.dY.cpu().numpy(), m.Y)
+    bits = m.bits.cpu().numpy().view(np.uint32)
+    occ = np.unpackbits(bits.view(np.uint8), axis=1, bitorder="little")[:, :m.cols].astype(bool)
+    assert np.array_equal(occ, 2 * ogo.visited > ogo.total)
+    assert not np.unpackbits(bits.view(np.uint8), axis=1, bitorder="little")[:, m.cols:].any()
+    # the pitch padding holds fresh cells
+    pad = m.cells.cpu().numpy()[:, m.cols:]
+    assert (pad == (E._lib.INIT_CELL_WIDE if wide else E._lib.INIT_CELL)).all()
