@@ -63,8 +63,9 @@ def test_level_geometry_bounds():
 
 
 def test_map_growth_emulation_equals_oracle():
-    """MapState growth (device re-allocation + coordinate vectors) follows the same sequence,
-    block sizes, coordinates (high-side compression included) and content placement."""
+    """MapState growth, the HOST side (the device pass -- slam2d_map_grow: new counts and occupancy bits -- is compared with the
+    oracle on the GPU, tests/test_gpu_wide_counts.py): the same sequence, block sizes, coordinates (high-side compression
+    included), limits, index conversion, and where the old content is to sit in the new array."""
     init = {"x": 0.698, "y": -0.015}
     m = eng.MapState.create(10, 10, init, 0.02, CPU)
     og = so.GridOracle(10, 10, init, 0.02, np.pi, 180, 10, 0.1, lut=so.SpokeLUT(0.5, 4, np.pi, 180))
@@ -73,20 +74,25 @@ def test_map_growth_emulation_equals_oracle():
     t = v + rs.randint(1, 9, og.visited.shape)
     og.visited[:], og.total[:] = v, t
     m.upload(v, t)
+    c = m.clone()
+    c.cells += 1
+    assert not torch.equal(c.cells, m.cells)
+    rows0, cols0 = m.rows, m.cols
+    m._defer = True                                   # plan only: nothing is materialised without the HIP library
     for (x, y) in [([-12.4, 12.4], [-12.4, 12.4]), ([-20, 3], [1, 2]), ([0, 1], [-30, 22]), ([31, 32], [0, 1])]:
         og.checkAndExapndOG(x, y)
         m.ensure_contains(x, y, 0.02)
         assert m.growth_log == og.growth_log
         assert np.array_equal(m.X, og.X) and np.array_equal(m.Y, og.Y)
         assert m.lim_x == og.mapXLim and m.lim_y == og.mapYLim
-        mv, mt = m.download()
-        assert np.array_equal(mv, og.visited) and np.array_equal(mt, og.total)
+        assert (m.rows, m.cols) == og.visited.shape
+        dc = sum(n for side, n in m.growth_log if side == 1)
+        dr = sum(n for side, n in m.growth_log if side == 3)
+        assert m._pending[1:] == [rows0, cols0, dc, dr]
+        assert np.array_equal(og.visited[dr:dr + rows0, dc:dc + cols0], v) and np.array_equal(og.total[dr:dr + rows0, dc:dc + cols0], t)
         xi, yi = m.to_map_idx(x, y, 0.02)
         xo, yo = og.convertRealXYToMapIdx(x, y)
         assert np.array_equal(xi, xo) and np.array_equal(yi, yo)
-    c = m.clone()
-    c.cells += 1
-    assert not torch.equal(c.cells, m.cells)
 
 
 def test_map_upload_download_roundtrip_and_validation():
