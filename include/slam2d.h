@@ -293,6 +293,7 @@ int slam2d_sweep(const Slam2dLidar* lidar, const Slam2dLevel* level, int32_t P,
  * prior outside the ring) is swept in full by the same call: d_out never differs in arg-max from the
  * unpruned result. */
 #define SLAM2D_MATCH_PRUNE_BY_PRIOR 1u
+#define SLAM2D_MATCH_PRIOR_READY    2u   /* slam2d_scan_match only: d_est / d_psi_cs already hold this scan's prior (slam2d_scan_commit_next) */
 #define SLAM2D_PRUNE_MARGIN 40.0
 #define SLAM2D_BNB_MARGIN 30.0
 /* Branch and bound (Slam2dLevel.bnb != 0; every level whose cube has 2*ncell+1 in [9, 64] may use it).
@@ -411,6 +412,17 @@ int slam2d_scan_commit(const Slam2dLidar* lidar, const Slam2dMap* d_maps, int32_
                        const Slam2dMatch* d_coarse, double* d_prev_pose, double* d_heading, double* d_logw, double* d_report,
                        const double* d_ranges, uint32_t* d_flags, double* d_w, double* d_stats, uint32_t* d_flag_snapshot,
                        uint32_t abort_mask, void* stream);
+
+/* slam2d_scan_commit that ALSO writes the next scan's pose prior (slam2d_prior's work: Algorithm/FastSlam.py:77-106 needs only
+ * this scan's matched poses and headings and the next reading's odometry, which a driver replaying a log -- or one scan behind a
+ * live sensor -- holds when it commits): the bookkeeping block computes d_next_est[P][3] / d_next_psi_cs[P][2] behind each
+ * particle's bookkeeping, and the next slam2d_scan_match is called with SLAM2D_MATCH_PRIOR_READY -- one launch less per scan.
+ * A voided scan (abort_mask) writes no prior; the driver re-issues it without the option.  d_next_est NULL: slam2d_scan_commit. */
+int slam2d_scan_commit_next(const Slam2dLidar* lidar, const Slam2dMap* d_maps, int32_t P, const Slam2dMatch* d_fine,
+                            const Slam2dMatch* d_coarse, double* d_prev_pose, double* d_heading, double* d_logw, double* d_report,
+                            const double* d_ranges, uint32_t* d_flags, double* d_w, double* d_stats, uint32_t* d_flag_snapshot,
+                            uint32_t abort_mask, double next_raw_theta, double next_prev_raw_theta, int32_t next_has_turn,
+                            double next_raw_turn, double* d_next_est, double* d_next_psi_cs, void* stream);
 
 /* The same normaliser for particles sharded over several processes (one per GPU).  Rank-local
  * half: d_logw[i] += d_logconf[i * logconf_stride], then d_part[3] = [max log w, sum exp(lw - max),

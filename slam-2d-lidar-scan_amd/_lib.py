@@ -42,6 +42,7 @@ SPOKE_BAND = 16
 SYNC_WORDS = 4
 ABI_VERSION = 13
 MATCH_PRUNE_BY_PRIOR = 1
+MATCH_PRIOR_READY = 2
 PRUNE_MARGIN = 40.0
 BNB_MARGIN = 30.0
 
@@ -153,6 +154,8 @@ SIGNATURES = {
                                     _vp, C.c_uint32, _vp]),
     "slam2d_scan_commit": (C.c_int, [C.POINTER(Slam2dLidar), _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _vp, C.c_uint32, _vp]),
+    "slam2d_scan_commit_next": (C.c_int, [C.POINTER(Slam2dLidar), _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                          _vp, C.c_uint32, C.c_double, C.c_double, C.c_int32, C.c_double, _vp, _vp, _vp]),
     "slam2d_groups_match": (C.c_int, [C.POINTER(Slam2dLidar), C.POINTER(Slam2dGroup), C.c_int32, C.POINTER(Slam2dScan)]),
     "slam2d_groups_commit": (C.c_int, [C.POINTER(Slam2dLidar), C.POINTER(Slam2dGroup), C.c_int32, C.POINTER(Slam2dScan)]),
     "slam2d_groups_step": (C.c_int, [C.POINTER(Slam2dLidar), C.POINTER(Slam2dGroup), C.c_int32, C.POINTER(Slam2dScan)]),

@@ -2647,6 +2647,9 @@ __global__ __launch_bounds__(XS_THREADS) void k_exact_select(Slam2dLevel lv, con
     const int ntot = lv.ntheta * nt;
     const double thr = unorder_bits(lv.bnb_best[p]) - SLAM2D_BNB_MARGIN;
     const double* __restrict__ bnd = lv.bounds + (size_t)p * ntot;
+    // (what the selection tail needs from global memory is fetched now: a load there is a microsecond of one wave's serial chain)
+    const double u_pre = uniform != nullptr ? uniform[p] : 0.0;
+    const double ex = est[(size_t)p * estride], ey = est[(size_t)p * estride + 1], eth = est[(size_t)p * estride + 2];
     DBG_CLOCK(8, p == 0);
     // ---- scan ----
     const int per = (ntot + XS_THREADS - 1) / XS_THREADS;          // <= XS_MAX_PER (checked by the host)
@@ -2878,7 +2881,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_exact_select(Slam2dLevel lv, con
     if (uniform != nullptr && !isnan(total)) {
         // np.random.choice(n, 1, p): first index whose normalised cdf exceeds u (:137-138); the poses that were not
         // scored carry < 1e-8 of the mass
-        const double target = uniform[p] * total;
+        const double target = u_pre * total;
         const unsigned long long ahead = __ballot(cinc > target);
         const int lsel = ahead ? __ffsll((long long)ahead) - 1 : WAVE - 1;
         double run = readlane_f64(cinc - mine, lsel);
@@ -2954,7 +2957,6 @@ __global__ __launch_bounds__(XS_THREADS) void k_exact_select(Slam2dLevel lv, con
         Slam2dMatch m;
         const int it = pick / npose, rem = pick - it * npose;
         const int iy = rem / nx, ix = rem - iy * nx;
-        const double ex = est[(size_t)p * estride], ey = est[(size_t)p * estride + 1], eth = est[(size_t)p * estride + 2];
         m.x = ex + (double)(ix - lv.ncell) * lv.step;                               // :142-143
         m.y = ey + (double)(iy - lv.ncell) * lv.step;
         m.theta = eth + lv.thetas[it];
@@ -2974,6 +2976,21 @@ __global__ __launch_bounds__(XS_THREADS) void k_exact_select(Slam2dLevel lv, con
 // One 256-thread block.  `exchange`: the block runs beside the update blocks of the same launch (slam2d_scan_commit,
 // slam2d_grid_update_weights), which may still raise bits: they are taken with an atomic exchange, so a bit raised
 // after it stays in flags and is reported with the next scan instead of being lost.
+// updateEstimatedPose of one particle (Algorithm/FastSlam.py:77-106): estimate = previous matched pose turned by the raw odometry's
+// rotation; cos / sin of the expected moving direction (NaN: no direction known)
+__device__ __forceinline__ void prior_one(const double* prev, const double* heading, const int p, const double raw_theta,
+                                          const double prev_raw_theta, const int has_turn, const double raw_turn, double* est, double* psi_cs) {
+    est[3 * p + 0] = prev[3 * p + 0];                                               // :79
+    est[3 * p + 1] = prev[3 * p + 1];
+    est[3 * p + 2] = prev[3 * p + 2] + raw_theta - prev_raw_theta;                  // :78
+    double c = NAN, s = NAN;
+    const double h = heading[p];
+    if (has_turn && !isnan(h)) {                                                    // :89-95
+        const double psi = h + raw_turn;
+        c = cos(psi); s = sin(psi);
+    }
+    psi_cs[2 * p] = c; psi_cs[2 * p + 1] = s;
+}
 struct WeightsJob {
     double* logw; const double* logconf; int cstride; int N; double* w; double* stats; uint32_t* flags; uint32_t* flag_snapshot;
     // slam2d_scan_commit: the same block first does the scan's bookkeeping (k_post_match's work) for all particles
@@ -2981,6 +2998,8 @@ struct WeightsJob {
     double* part;            // sharded filters: only the rank-local half (k_weights_local's work), the collective follows
     uint32_t abort_mask;     // slam2d_scan_commit: fault bits of the match that make the WHOLE launch a no-op (see there)
     const uint32_t* abort_flags; int abort_n;   // slam2d_groups_commit: the abort is decided over the fault bits of ALL groups (NULL: flags[0 .. N))
+    // slam2d_scan_commit_next: the NEXT scan's pose prior (k_prior's work) behind this scan's bookkeeping, same thread per particle
+    double* next_est; double* next_psi; double next_raw_theta, next_prev_raw_theta, next_raw_turn; int next_has_turn;
 };
 // pose / heading / log-weight bookkeeping of one particle after its match (Algorithm/FastSlam.py:110-117,134-135)
 __device__ __forceinline__ void post_match_one(const Slam2dMatch* __restrict__ fine, const Slam2dMatch* __restrict__ coarse, const int p,
@@ -3145,8 +3164,12 @@ __global__ __launch_bounds__(256, UPDB_MIN_WAVES) void k_grid_update(Slam2dLidar
     if (wj.logw && blockIdx.x == 0) {                      // one extra block: the normaliser, beside the update (one launch less;
         //                                                    block 0, so that it starts with the launch and not as its tail)
         if (wj.fine) {                                     // ... after the scan's bookkeeping (the update blocks take their
-            for (int i = threadIdx.x; i < wj.N; i += blockDim.x)          // poses from the match buffer themselves)
+            for (int i = threadIdx.x; i < wj.N; i += blockDim.x) {        // poses from the match buffer themselves)
                 post_match_one(wj.fine, wj.coarse, i, wj.prev, wj.heading, wj.logw, wj.report);
+                if (wj.next_est)                                            // (reads what this very thread has just written)
+                    prior_one(wj.prev, wj.heading, i, wj.next_raw_theta, wj.next_prev_raw_theta, wj.next_has_turn, wj.next_raw_turn,
+                              wj.next_est, wj.next_psi);
+            }
             __syncthreads();
         }
         if (wj.part) {
@@ -3368,16 +3391,7 @@ __global__ void k_prior(const double* __restrict__ prev, double raw_theta, doubl
                         double raw_turn, const double* __restrict__ heading, int P, double* est, double* psi_cs) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
-    est[3 * p + 0] = prev[3 * p + 0];                                               // :79
-    est[3 * p + 1] = prev[3 * p + 1];
-    est[3 * p + 2] = prev[3 * p + 2] + raw_theta - prev_raw_theta;                  // :78
-    double c = NAN, s = NAN;
-    const double h = heading[p];
-    if (has_turn && !isnan(h)) {                                                    // :89-95
-        const double psi = h + raw_turn;
-        c = cos(psi); s = sin(psi);
-    }
-    psi_cs[2 * p] = c; psi_cs[2 * p + 1] = s;
+    prior_one(prev, heading, p, raw_theta, prev_raw_theta, has_turn, raw_turn, est, psi_cs);
 }
 
 __global__ void k_post_match(const Slam2dMatch* __restrict__ fine, const Slam2dMatch* __restrict__ coarse, int P,
@@ -3859,10 +3873,12 @@ int slam2d_scan_match(const Slam2dLidar* lidar, const Slam2dLevel* coarse, const
                       double raw_turn, const double* d_heading, const double* d_ranges, double est_moving_dist,
                       const double* d_uniform, double* d_est, double* d_psi_cs, Slam2dMatch* d_coarse, Slam2dMatch* d_fine,
                       uint32_t* d_flags, uint32_t options, void* stream) {
-    int rc = slam2d_prior(d_prev_pose, raw_theta, prev_raw_theta, has_turn, raw_turn, d_heading, P, d_est, d_psi_cs, stream);
+    // (SLAM2D_MATCH_PRIOR_READY: d_est / d_psi_cs were written by the previous scan's slam2d_scan_commit_next)
+    int rc = (options & SLAM2D_MATCH_PRIOR_READY) ? 0
+             : slam2d_prior(d_prev_pose, raw_theta, prev_raw_theta, has_turn, raw_turn, d_heading, P, d_est, d_psi_cs, stream);
     if (rc) return rc;
     rc = slam2d_match(lidar, coarse, d_maps, P, d_est, 3, d_ranges, est_moving_dist, d_psi_cs, d_uniform, d_coarse, d_flags,
-                      options, stream);
+                      options & ~SLAM2D_MATCH_PRIOR_READY, stream);
     if (rc) return rc;
     // the fine level is centred on the coarse result and takes its arg-max (matchMax=True), priors off (:65-73)
     return slam2d_match(lidar, fine, d_maps, P, reinterpret_cast<const double*>(d_coarse), (int32_t)(sizeof(Slam2dMatch) / sizeof(double)),
@@ -3873,6 +3889,16 @@ int slam2d_scan_commit(const Slam2dLidar* lidar, const Slam2dMap* d_maps, int32_
                        const Slam2dMatch* d_coarse, double* d_prev_pose, double* d_heading, double* d_logw, double* d_report,
                        const double* d_ranges, uint32_t* d_flags, double* d_w, double* d_stats, uint32_t* d_flag_snapshot,
                        uint32_t abort_mask, void* stream) {
+    return slam2d_scan_commit_next(lidar, d_maps, P, d_fine, d_coarse, d_prev_pose, d_heading, d_logw, d_report, d_ranges, d_flags, d_w,
+                                   d_stats, d_flag_snapshot, abort_mask, 0.0, 0.0, 0, 0.0, nullptr, nullptr, stream);
+}
+
+int slam2d_scan_commit_next(const Slam2dLidar* lidar, const Slam2dMap* d_maps, int32_t P, const Slam2dMatch* d_fine,
+                            const Slam2dMatch* d_coarse, double* d_prev_pose, double* d_heading, double* d_logw, double* d_report,
+                            const double* d_ranges, uint32_t* d_flags, double* d_w, double* d_stats, uint32_t* d_flag_snapshot,
+                            uint32_t abort_mask, double next_raw_theta, double next_prev_raw_theta, int32_t next_has_turn,
+                            double next_raw_turn, double* d_next_est, double* d_next_psi_cs, void* stream) {
+    if ((d_next_est != nullptr) != (d_next_psi_cs != nullptr) || (d_next_est && !d_w)) return SLAM2D_E_BADARG;
     if (!d_w) {                                        // sharded filters run their own normaliser (a collective sits in it)
         const int rc = slam2d_post_match(d_fine, d_coarse, P, d_prev_pose, d_heading, d_logw, d_report, stream);
         if (rc) return rc;
@@ -3885,7 +3911,8 @@ int slam2d_scan_commit(const Slam2dLidar* lidar, const Slam2dMap* d_maps, int32_
     return launch_update(lidar, d_maps, P, reinterpret_cast<const double*>(d_fine), (int)(sizeof(Slam2dMatch) / sizeof(double)), d_ranges,
                          nullptr, d_flags,
                          WeightsJob{d_logw, nullptr, 1, P, d_w, d_stats, d_flags, d_flag_snapshot, d_fine, d_coarse, d_prev_pose, d_heading,
-                                    d_report, nullptr, abort_mask}, stream);
+                                    d_report, nullptr, abort_mask, nullptr, 0, d_next_est, d_next_psi_cs, next_raw_theta,
+                                    next_prev_raw_theta, next_raw_turn, next_has_turn}, stream);
 }
 
 // ---- particle groups on several streams, one host call per scan (include/slam2d.h, "one scan for several particle GROUPS") ----

@@ -342,8 +342,14 @@ class ParticleFilter:
                 on_scan(count, self, unb)
             return unb or count in force_resample
 
+        # the next scan's pose prior rides in this scan's commit (slam2d_scan_commit_next) when the next reading is at hand:
+        # prior_ready = count of the scan whose prior the last commit wrote (its match then skips the prior's launch)
+        fold_prior = not grouped and not self.sharded and os.environ.get("SLAM2D_FILTER_FOLD_PRIOR", "1") != "0"
+        prior_ready = [None]
+
         def plain(count, reading):
             """One scan through the unpipelined calls."""
+            prior_ready[0] = None
             self.stats["step_by_step"] += 1
             self._quiesce_groups()
             self.updateParticles(reading, count)
@@ -355,6 +361,7 @@ class ParticleFilter:
 
         def discard_speculation(rng_state):
             """Throw away what is in flight: its fault flags and its draws from the random stream."""
+            prior_ready[0] = None
             if grouped:
                 torch.cuda.synchronize(self.device)
                 self._grp.flags2.zero_()
@@ -420,7 +427,7 @@ class ParticleFilter:
                 self._enqueue_match_groups(reading, prev_raw, dist, has_turn, turn, parity)
             else:
                 self._stage_inputs(parity, np.asarray(reading['range'], dtype=np.float64), None if self.match_max else self._draw_uniforms())
-                self._enqueue_match(reading, prev_raw, dist, has_turn, turn)          # speculative: scan count-1 not seen yet
+                self._enqueue_match(reading, prev_raw, dist, has_turn, turn, prior_ready[0] == count)   # speculative: scan count-1 not seen yet
             redo = False
             if pending is not None:
                 prev_count = pending[0]
@@ -473,7 +480,12 @@ class ParticleFilter:
             if grouped:
                 ev = self._enqueue_commit_groups(abort_mask, parity)
             else:
-                self._enqueue_commit(abort_mask)
+                nxt = None
+                if fold_prior and i < len(readings):
+                    _, _, n_has_turn, n_turn = self._raw_odometry(readings[i], reading, raw_heading)
+                    nxt = (float(readings[i]['theta']), float(reading['theta']), int(n_has_turn), float(n_turn))
+                    prior_ready[0] = count + 1
+                self._enqueue_commit(abort_mask, nxt)
                 ev = events[parity]
                 ev.record()
             pending = (count, reading, raw_heading, ev, state_before)
@@ -611,9 +623,9 @@ class ParticleFilter:
             grp.ready[parity].record()
         return grp.ready[parity]
 
-    def _enqueue_match(self, reading, prev_raw, dist, has_turn, turn):
+    def _enqueue_match(self, reading, prev_raw, dist, has_turn, turn, prior_ready=False):
         """prior + coarse + fine match of one scan for all particles (slam2d_scan_match: one library call); reads the
-        maps, changes no filter state."""
+        maps, changes no filter state.  prior_ready: the previous commit wrote this scan's prior already (_enqueue_commit)."""
         eng, P = self.engine, self.numParticles
         eng.refresh_bits()
         self.coarse.next_generation()
@@ -623,19 +635,26 @@ class ParticleFilter:
             float(reading['theta']), float(prev_raw['theta']), has_turn, float(turn), _ptr(self.d_head), _ptr(self.d_ranges),
             float(dist), None if self.match_max else _ptr(self.d_uniform), _ptr(self.d_est), _ptr(self.d_psi), _ptr(self.m_coarse),
             _ptr(self.m_fine),
-            _ptr(eng.flags), _lib.MATCH_PRUNE_BY_PRIOR if self.prune_by_prior else 0, _stream()), "slam2d_scan_match")
+            _ptr(eng.flags), (_lib.MATCH_PRUNE_BY_PRIOR if self.prune_by_prior else 0) | (_lib.MATCH_PRIOR_READY if prior_ready else 0),
+            _stream()), "slam2d_scan_match")
 
-    def _enqueue_commit(self, abort_mask=0):
+    def _enqueue_commit(self, abort_mask=0, next_prior=None):
         """Bookkeeping, map update, normaliser and the (asynchronous) download of everything the host reads.  abort_mask: fault
-        bits of the match that turn the whole commit into a device-side no-op (slam2d_scan_commit)."""
+        bits of the match that turn the whole commit into a device-side no-op (slam2d_scan_commit).  next_prior = (theta of the
+        next raw reading, theta of this one, has_turn, raw turn): the next scan's pose prior is written in the same launch
+        (slam2d_scan_commit_next; Algorithm/FastSlam.py:77-106 needs nothing else that is not on the device then)."""
         eng, P = self.engine, self.numParticles
         own_norm = not self.sharded
         eng._before_update()
-        _lib.check(_lib.lib().slam2d_scan_commit(
-            C.byref(eng.lidar_c), _ptr(eng.d_maps), P, _ptr(self.m_fine), _ptr(self.m_coarse), _ptr(self.d_pose),
-            _ptr(self.d_head), _ptr(self.d_logw), _ptr(self.d_report), _ptr(self.d_ranges), _ptr(eng.flags),
-            _ptr(self.d_w) if own_norm else None, _ptr(self.d_stats) if own_norm else None,
-            _ptr(self._d_flagsnap) if own_norm else None, abort_mask if own_norm else 0, _stream()), "slam2d_scan_commit")
+        args = (C.byref(eng.lidar_c), _ptr(eng.d_maps), P, _ptr(self.m_fine), _ptr(self.m_coarse), _ptr(self.d_pose),
+                _ptr(self.d_head), _ptr(self.d_logw), _ptr(self.d_report), _ptr(self.d_ranges), _ptr(eng.flags),
+                _ptr(self.d_w) if own_norm else None, _ptr(self.d_stats) if own_norm else None,
+                _ptr(self._d_flagsnap) if own_norm else None, abort_mask if own_norm else 0)
+        if next_prior is not None and own_norm:
+            _lib.check(_lib.lib().slam2d_scan_commit_next(*args, *next_prior, _ptr(self.d_est), _ptr(self.d_psi), _stream()),
+                       "slam2d_scan_commit_next")
+        else:
+            _lib.check(_lib.lib().slam2d_scan_commit(*args, _stream()), "slam2d_scan_commit")
         if not own_norm:
             self._normalize_on_device()                 # two launches around the one all-gather of the scan
             self._d_flagsnap.copy_(eng.flags)
