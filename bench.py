@@ -63,7 +63,7 @@ WORKLOADS = {
 WORKLOAD_PARTICLES = {"config5": 128}
 PROF_EVERY_MAX = int(os.environ.get("SLAM2D_BENCH_PROF_EVERY", "41"))  # (round 4: 7 -> 41: measured 0.1312 ms per step with a pair round every 7th launch, 0.1280 with every 51st, 0.1419 with every launch)
 # the dominant kernel keeps a HIP event pair around every n-th of its launches inside the timed region (n <= 41, chosen so
-# that at least ~20 launches are timed: an event pair holds the stream for ~6 us on each side of the kernel)
+# that at least 13 launches are timed: an event pair holds the stream for ~6 us on each side of the kernel)
 KERNEL_SOURCE = os.path.join(REPO, "slam-2d-lidar-scan_amd", "csrc", "slam2d.hip")
 
 
@@ -1231,7 +1231,7 @@ def main():
     # and only around every n-th of its launches (an event pair holds the stream for ~6 us on each side of the kernel; odd n: a
     # stage with one launch per level alternates between the levels)
     dom_lps = launches_per_step_of.get(E._lib.STAGE_NAMES[dom_stage], 1.0)
-    every = int(max(1, min(PROF_EVERY_MAX, (R * K * dom_lps) // 24)))
+    every = int(max(1, min(PROF_EVERY_MAX, (R * K * dom_lps) // 13)))       # (>= 13 timed launches: the driver's 5 x 20 steps bracket every 15th)
     if every > 1 and every % 2 == 0:
         every -= 1
     E._lib.check(lib.slam2d_prof_every(every), "prof_every")
