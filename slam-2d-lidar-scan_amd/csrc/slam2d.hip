@@ -1574,8 +1574,10 @@ __device__ __forceinline__ void select_argmax_from_partials(const Slam2dLevel& l
 }
 
 template <int RQ, int mode, bool SKIP>
-__global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks, int bpp, const double* __restrict__ sel_est = nullptr,
-                                               int sel_estride = 0, Slam2dMatch* sel_out = nullptr) {
+// (RQ = 1, whole cube, no skip test: 8 waves per SIMD -- 64 VGPRs instead of 66 -- hold the reference's fine level, 30 blocks per
+// particle x 64 particles = 1 920 blocks of 4 waves, in ONE round of blocks instead of a full one and a sliver)
+__global__ __launch_bounds__(256, (RQ == 1 && mode == 0 && !SKIP) ? 8 : 1) void k_sweep(Slam2dLevel lv, int P, int chunks, int bpp, const double* __restrict__ sel_est = nullptr,
+                                               int sel_estride = 0, Slam2dMatch* sel_out = nullptr, int deep = 0) {
     // mode 0: the whole cube.  mode 1 (RQ = 1): only the slots of the prior's ring (lv.ring).  mode 2: the
     // whole cube, for the particles the ring pass could not settle (lv.prune_state[p] != 0) -- see write_priors.
     // SKIP (RQ = 1): a wave-load whose whole patch (its 6-7 pose rows x all dx, at the cell) lies in tiles that
@@ -1613,7 +1615,9 @@ __global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks
     // the loop, and out-of-range offsets read 0 instead of faulting.
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)F, (short)0, (int)((size_t)lv.fmax * lv.fpitch * sizeof(uint32_t)), 0x00020000);
+    const int dbg0 = lv.fine ? 44 : 32;
     auto sweep_chunk = [&](const int ch) {
+    DBG_CLOCK(dbg0, p == 0 && it == 0 && ch == 0);
     const int u0 = ch * (WAVE * RQ) + lane;
     int off[RQ], q0[RQ], nv[RQ];          // byte offset, first pose index, valid poses (0..4) of each slot
     unsigned lo[RQ][4], hi[RQ][4];        // exact 64-bit integer sums as 32-bit halves
@@ -1679,6 +1683,32 @@ __global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks
                     }
             }
         }
+    } else if (RQ == 1 && deep) {
+        // Round 4: a level whose launch is ONE round of blocks (the reference's 11 x 11 fine cube: 30 blocks per particle) is
+        // bound by the latency of this loop, not by the gathers' throughput -- with two loads in flight a wave's ~40 cells were
+        // ~20 round trips.  The wave's cells come in one vector load (a lane each), v_readlane hands them to the loop as scalar
+        // offsets, SWEEP_DEPTH loads are in flight (the skip loop's structure without its patch test).
+        for (int base = wave; base < K; base += 4 * WAVE) {
+            const int kk = base + 4 * lane;
+            const int boff = kk < K ? cl[kk] * 4 : 0x7ffffff0;                     // beyond the buffer: reads zeros
+            const int n = min(WAVE, (K - base + 3) >> 2);                           // this wave's cells in this batch (wave-uniform)
+            for (int j0 = 0; j0 < n; j0 += SWEEP_DEPTH) {
+                int c[SWEEP_DEPTH];
+#pragma unroll
+                for (int i = 0; i < SWEEP_DEPTH; ++i) c[i] = __builtin_amdgcn_readlane(boff, min(j0 + i, WAVE - 1));
+                u32x4 v[SWEEP_DEPTH];
+#pragma unroll
+                for (int i = 0; i < SWEEP_DEPTH; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[0], j0 + i < n ? c[i] : 0x7ffffff0, 0);
+#pragma unroll
+                for (int i = 0; i < SWEEP_DEPTH; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned s2 = lo[0][e] + v[i][e];
+                        hi[0][e] += s2 < v[i][e] ? 1u : 0u;
+                        lo[0][e] = s2;
+                    }
+            }
+        }
     } else {
 #pragma unroll 2
     for (int k = wave; k < K; k += 4) {
@@ -1707,6 +1737,7 @@ __global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks
                 hi[r][e] = (unsigned)(t >> 32); lo[r][e] = (unsigned)t;
             }
     }
+    DBG_CLOCK(dbg0 + 1, p == 0 && it == 0 && ch == 0);
     if (wave > 0) {
 #pragma unroll
         for (int r = 0; r < RQ; ++r)
@@ -1714,6 +1745,7 @@ __global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks
             for (int e = 0; e < 4; ++e) part_s[wave - 1][(r * 4 + e) * WAVE + lane] = ((unsigned long long)hi[r][e] << 32) | lo[r][e];
     }
     __syncthreads();
+    DBG_CLOCK(dbg0 + 2, p == 0 && it == 0 && ch == 0);
     if (wave > 0) return;
     {
 #pragma unroll
@@ -1776,6 +1808,7 @@ __global__ __launch_bounds__(256) void k_sweep(Slam2dLevel lv, int P, int chunks
             *dst = pt;
         }
     }
+    DBG_CLOCK(dbg0 + 3, p == 0 && it == 0 && ch == 0);
     }
     };
     if constexpr (CPB > 1) {
@@ -3460,8 +3493,12 @@ static void launch_sweep(const Slam2dLevel& lv, int P, int chunks, hipStream_t s
             return;
         }
     }
-    if (mode == 0) k_sweep<R, 0, false><<<grid, 256, 0, s>>>(lv, P, chunks, bpp, sel_est, sel_estride, sel_out);
-    else if (mode == 2) k_sweep<R, 2, false><<<grid, 256, 0, s>>>(lv, P, chunks, bpp);
+    // deep (R == 1): SWEEP_DEPTH gathers in flight per wave; SLAM2D_SWEEP_DEEP = 0 never, 1 (default) where a particle has at most
+    // 64 blocks (the launch is about one round of blocks: latency-bound), 2 always
+    static const int deep_env = [] { const char* e = getenv("SLAM2D_SWEEP_DEEP"); return e ? atoi(e) : 1; }();
+    const int deep = R == 1 && (deep_env == 2 || (deep_env == 1 && bpp <= 64)) ? 1 : 0;
+    if (mode == 0) k_sweep<R, 0, false><<<grid, 256, 0, s>>>(lv, P, chunks, bpp, sel_est, sel_estride, sel_out, deep);
+    else if (mode == 2) k_sweep<R, 2, false><<<grid, 256, 0, s>>>(lv, P, chunks, bpp, nullptr, 0, nullptr, deep);
 }
 
 extern "C" {

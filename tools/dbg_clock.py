@@ -29,6 +29,10 @@ print("k_endpoints (theta 0, particle 0): cells %.2f us, hash + tile marking %.2
 print("k_bound: prologue->loop end %.2f us, bounds+argmax %.2f, seed tile %.2f, atomic %.2f" % (us(0, 1), us(1, 2), us(2, 3), us(3, 4)))
 print("k_exact_select: scan %.2f us, list %.2f, tiles %.2f, max %.2f, exp %.2f, theta sums %.2f, select %.2f; total %.2f" % (
     us(8, 9), us(9, 10), us(10, 11), us(11, 29), us(29, 30), us(30, 12), us(12, 13), us(8, 13)))
+for name, a in (("coarse", 32), ("fine", 44)):
+    if t[a + 3] > t[a] > 0:
+        print("k_sweep %s (particle 0, theta 0, chunk 0, wave 0): gather loop %.2f us, partial sums to LDS + barrier %.2f, scores + reduction + partial %.2f; total %.2f" % (
+            name, us(a, a + 1), us(a + 1, a + 2), us(a + 2, a + 3), us(a, a + 3)))
 print("k_grid_update (block of particle 0, beams 0-3): whole walk %.2f us; normaliser block %.2f us; update block start relative to the normaliser block's %.2f" % (us(60, 62), us(58, 59), us(58, 60)))
 b = hot.coarse.t["bounds"].cpu().numpy(); best = hot.coarse.t["bnb_best"].cpu().numpy().view(np.uint64)
 bits = np.where(best >> np.uint64(63), best & np.uint64(0x7FFFFFFFFFFFFFFF), ~best).astype(np.uint64); m0 = bits.view(np.float64)

@@ -7,7 +7,10 @@ ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"
 skip = int(len(ev) * (float(sys.argv[2]) if len(sys.argv) > 2 else 0.5))
 ev = ev[skip:]
 dur, gap, prevname = collections.defaultdict(list), collections.defaultdict(list), collections.defaultdict(collections.Counter)
+split = len(sys.argv) > 3 and sys.argv[3] == "split"          # "split": a kernel's launches told apart by the kernel in front of them
 for (s0, e0, n0), (s1, e1, n1) in zip(ev, ev[1:]):
+    if split:
+        n1 = n1 + " <- " + n0[:22]
     dur[n1].append(e1 - s1); gap[n1].append(s1 - e0); prevname[n1][n0] += 1
 wall = ev[-1][1] - ev[0][0]
 busy = sum(e - s for s, e, _ in ev)
