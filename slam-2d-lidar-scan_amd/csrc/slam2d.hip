@@ -2631,6 +2631,9 @@ __global__ __launch_bounds__(64) void k_bound2(Slam2dLevel lv, int P) {
 #define XS_MAX_PER 32
 #define XS_CELLS 8192                // cell-list entries staged in LDS (ntheta * kmax: config 2 6480, reference 5400)
 #define XS_SPLIT_MAX 8
+#ifndef XS_SPLIT_STAGE_CELLS
+#define XS_SPLIT_STAGE_CELLS 1       // split blocks stage all cell lists in LDS behind the scan (0: each tile's list from global memory)
+#endif
 #define XS_SPLIT_LIGHT 4             // blocks per particle that work when one list pass holds all surviving tiles
 #define SLAM2D_BNB_MAX_THETA 256
 // SPLIT: nsplit blocks per particle (all of them on the particle's XCD, for the field's sake).  Every block scans the
@@ -2682,6 +2685,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_exact_select(Slam2dLevel lv, con
     const double* __restrict__ bnd = lv.bounds + (size_t)p * ntot;
     // (what the selection tail needs from global memory is fetched now: a load there is a microsecond of one wave's serial chain)
     const double u_pre = uniform != nullptr ? uniform[p] : 0.0;
+    const double th_pre = (tid & 63) < lv.ntheta ? lv.thetas[tid & 63] : 0.0;       // (lane i keeps angle i: the chosen one comes by v_readlane)
     const double ex = est[(size_t)p * estride], ey = est[(size_t)p * estride + 1], eth = est[(size_t)p * estride + 2];
     DBG_CLOCK(8, p == 0);
     // ---- scan ----
@@ -2693,7 +2697,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_exact_select(Slam2dLevel lv, con
         if (g < ntot && bnd[g] >= thr) keepbits |= 1u << i;        // (padding tiles hold -inf)
     }
     // (a block that scores a quarter of the tiles reads the few lists it needs from global memory instead of staging them all)
-    const bool cells_in_lds = !SPLIT && lv.ntheta * lv.kmax <= XS_CELLS;
+    const bool cells_in_lds = (!SPLIT || XS_SPLIT_STAGE_CELLS) && lv.ntheta * lv.kmax <= XS_CELLS;
     if (cells_in_lds) {
         const int* __restrict__ call = lv.cells + (size_t)p * lv.ntheta * lv.kmax;
         for (int i = tid; i < lv.ntheta * lv.kmax; i += XS_THREADS) cells_s[i] = call[i];
@@ -2986,13 +2990,15 @@ __global__ __launch_bounds__(XS_THREADS) void k_exact_select(Slam2dLevel lv, con
             pick = __builtin_amdgcn_readlane(found, l2);
         }
     }
+    const int it_sel = __builtin_amdgcn_readfirstlane(pick / npose);
+    const double th_sel = lv.ntheta <= WAVE ? readlane_f64(th_pre, it_sel) : lv.thetas[it_sel];
     if (lane == 0) {
         Slam2dMatch m;
         const int it = pick / npose, rem = pick - it * npose;
         const int iy = rem / nx, ix = rem - iy * nx;
         m.x = ex + (double)(ix - lv.ncell) * lv.step;                               // :142-143
         m.y = ey + (double)(iy - lv.ncell) * lv.step;
-        m.theta = eth + lv.thetas[it];
+        m.theta = eth + th_sel;
         m.confidence = exp(M) * total;                                              // :141
         m.log_confidence = M + log(total);
         m.best_score = M;
