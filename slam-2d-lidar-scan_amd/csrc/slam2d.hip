@@ -328,17 +328,22 @@ __global__ __launch_bounds__(256) void k_occ_scatter(Slam2dLevel lv, const Slam2
     uint32_t edge = ~0u;
     if (col_base < fr.mx0) edge &= ~0u << (fr.mx0 - col_base);                    // window edges
     if (col_base + 32 > fr.mx1) edge &= ~0u >> (col_base + 32 - fr.mx1);
-    uint8_t* occ = lv.occ + (size_t)p * lv.fmax * lv.fpitch;
-    uint8_t* tiles = lv.tilemask + (size_t)p * flag_bytes(lv);                // flags of 8 x 8-cell blocks, [2 tmax][flag_pitch]
     const int fpad = flag_pitch(lv);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(lv.occ + (size_t)p * lv.fmax * lv.fpitch), (short)0, (int)((size_t)lv.fmax * lv.fpitch), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(lv.tilemask + (size_t)p * flag_bytes(lv)), (short)0, (int)flag_bytes(lv), 0x00020000);   // flags of 8 x 8-cell blocks, [2 tmax][flag_pitch]
     const uint8_t stamp = occ_stamp(lv);
     const int half = lane >> 5, bit = lane & 31;
+    const int lbase = (w0 << 5) + bit - fr.mx0;            // the lane's column of word w0, relative to the window
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
         const uint32_t word = words[k] & edge;
         unsigned long long nz = __ballot(word != 0u);
         if (!nz) continue;
-        const int fy = fyk[k];
+        const int fy = __builtin_amdgcn_readfirstlane(fyk[k]);                     // (the wave's row: uniform)
+        if (fy < 0) continue;                                                      // :36-37
+        const int so = fy * lv.fpitch, st = (fy >> FLAG_SHIFT) * fpad;
         while (nz) {
             const int sa = __ffsll((long long)nz) - 1;
             nz &= nz - 1;
@@ -349,11 +354,10 @@ __global__ __launch_bounds__(256) void k_occ_scatter(Slam2dLevel lv, const Slam2
             const uint32_t wsel = half ? wb : wa;
             const int src = half ? sb : sa;
             if ((wsel >> bit) & 1u) {
-                const int col = ((w0 + src) << 5) + bit;
-                const int fx = ax_s[col - fr.mx0];
-                if (fx >= 0 && fy >= 0) {                                          // :36-37
-                    occ[(size_t)fy * lv.fpitch + fx] = stamp;
-                    tiles[(fy >> FLAG_SHIFT) * fpad + (fx >> FLAG_SHIFT)] = stamp;
+                const int fx = ax_s[lbase + (src << 5)];
+                if (fx >= 0) {                                                     // (buffer stores: see scatter_role)
+                    __builtin_amdgcn_raw_buffer_store_b8(stamp, ro, fx, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b8(stamp, rt, fx >> FLAG_SHIFT, st, 0);
                 }
             }
         }
@@ -418,17 +422,24 @@ __device__ __forceinline__ void scatter_role(const Slam2dLidar& lid, const Slam2
     uint32_t edge = ~0u;
     if (col_base < fr.mx0) edge &= ~0u << (fr.mx0 - col_base);                    // window edges
     if (col_base + 32 > fr.mx1) edge &= ~0u >> (col_base + 32 - fr.mx1);
-    uint8_t* occ = lv.occ + (size_t)p * lv.fmax * lv.fpitch;
-    uint8_t* tiles = lv.tilemask + (size_t)p * flag_bytes(lv);                // flags of 8 x 8-cell blocks, [2 tmax][flag_pitch]
+    // (buffer stores: the row's byte offset rides in the scalar offset, the column in the lane's -- no 64-bit address
+    // arithmetic per set bit; the kernel's launch is bound by its vector instructions)
     const int fpad = flag_pitch(lv);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(lv.occ + (size_t)p * lv.fmax * lv.fpitch), (short)0, (int)((size_t)lv.fmax * lv.fpitch), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(lv.tilemask + (size_t)p * flag_bytes(lv)), (short)0, (int)flag_bytes(lv), 0x00020000);   // flags of 8 x 8-cell blocks, [2 tmax][flag_pitch]
     const uint8_t stamp = occ_stamp(lv);
     const int half = lane >> 5, bit = lane & 31;
+    const int lbase = (w0 << 5) + bit - fr.mx0;            // the lane's column of word w0, relative to the window
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
         const uint32_t word = words[k] & edge;
         unsigned long long nz = __ballot(word != 0u);
         if (!nz) continue;
         const int fy = fyk[k];
+        if (fy < 0) continue;                                                      // :36-37
+        const int so = fy * lv.fpitch, st = (fy >> FLAG_SHIFT) * fpad;             // (wave-uniform)
         while (nz) {
             const int sa = __ffsll((long long)nz) - 1;
             nz &= nz - 1;
@@ -438,11 +449,10 @@ __device__ __forceinline__ void scatter_role(const Slam2dLidar& lid, const Slam2
             const uint32_t wsel = half ? wb : wa;
             const int src = half ? sb : sa;
             if ((wsel >> bit) & 1u) {
-                const int col = ((w0 + src) << 5) + bit;
-                const int fx = ax_s[col - fr.mx0];
-                if (fx >= 0 && fy >= 0) {                                          // :36-37
-                    occ[(size_t)fy * lv.fpitch + fx] = stamp;
-                    tiles[(fy >> FLAG_SHIFT) * fpad + (fx >> FLAG_SHIFT)] = stamp;
+                const int fx = ax_s[lbase + (src << 5)];
+                if (fx >= 0) {
+                    __builtin_amdgcn_raw_buffer_store_b8(stamp, ro, fx, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b8(stamp, rt, fx >> FLAG_SHIFT, st, 0);
                 }
             }
         }
