@@ -209,6 +209,21 @@ __device__ __forceinline__ int wave_scan_incl_i32(int v) {
     return v;
 }
 
+// (int)(v / step) -- truncation, as astype(int) -- and rint(v / unit) without the fp64 division (~35 issue slots each): v * (1 / d)
+// differs from v / d by < 4e-16 relative, so the two agree unless the quotient is within 1e-6 of an integer (a half-integer for
+// rint), where the exact division decides.
+__device__ __forceinline__ int trunc_div(const double v, const double step, const double inv_step) {
+    const double t = v * inv_step;
+    if (fabs(t - rint(t)) < 1e-6 || !(fabs(t) < 1e9)) return (int)(v / step);
+    return (int)t;
+}
+__device__ __forceinline__ int rint_div(const double v, const double unit, const double inv_unit) {
+    const double t = v * inv_unit;
+    double rt = rint(t);
+    if (fabs(fabs(t - rt) - 0.5) < 1e-6 || !(fabs(t) < 1e9)) rt = rint(v / unit);
+    return (int)rt;
+}
+
 // ------------------------------------------------------------------------------------
 // K2a  frame geometry                      (Utils/ScanMatcher_OGBased.py:21-28)
 // ------------------------------------------------------------------------------------
@@ -364,14 +379,6 @@ __global__ __launch_bounds__(256) void k_occ_scatter(Slam2dLevel lv, const Slam2
     }
 }
 
-// (int)(v / step) -- truncation, as astype(int) -- without the fp64 division (~70 issue slots): v * (1/step) differs from
-// v / step by < 4e-16 relative, so the two truncate alike unless the quotient is within 1e-6 of an integer, where the exact
-// division decides.
-__device__ __forceinline__ int trunc_div(const double v, const double step, const double inv_step) {
-    const double t = v * inv_step;
-    if (fabs(t - rint(t)) < 1e-6 || !(fabs(t) < 1e9)) return (int)(v / step);
-    return (int)t;
-}
 // k_occ_scatter's work as a block role of k_endpoints' launch (slam2d_match below 512 beams, where no k_frame_axis
 // precedes it): the block derives the frame itself and evaluates the field index of its columns / rows inline (:32-37)
 // instead of reading the axis tables the frame block of the same launch is still writing.  Block (sbx, sby) of NW waves:
@@ -395,28 +402,32 @@ __device__ __forceinline__ void scatter_role(const Slam2dLidar& lid, const Slam2
     if (sby * (NW * NR) >= nrow) return;
     const int ncol = fr.mx1 - fr.mx0;
     const double inv_step = 1.0 / lv.step;
+    // (the rows' words and coordinates are requested FIRST: they need the frame only, and their round trip then runs under the
+    // column table's)
+    uint32_t words[NR];
+    int fyk[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int i = i0 + NW * k;
+        words[k] = (i < nrow && w <= wlast) ? m.occ_bits[(size_t)(fr.my0 + i) * m.bits_pitch + w] : 0u;
+    }
+    const double ycoord = (lane < NR && i0 + NW * lane < nrow) ? m.Y[fr.my0 + i0 + NW * lane] : 0.0;
     for (int j = threadIdx.x; j < ncol; j += NW * 64) {
         int idx = trunc_div(m.X[fr.mx0 + j] - fr.xlo, lv.step, inv_step);
         if (idx < 0) idx += fr.fw;                         // Python negative-index wrap (:37)
         ax_s[j] = (idx < 0 || idx >= fr.fw) ? -1 : idx;
     }
-    uint32_t words[NR];
-    int fyk[NR];
     int fy_lane = -1;                                      // lane k < NR evaluates the field row of the wave's k-th map row
     if (lane < NR) {
         const int i = i0 + NW * lane;
         if (i < nrow) {
-            int idx = trunc_div(m.Y[fr.my0 + i] - fr.ylo, lv.step, inv_step);
+            int idx = trunc_div(ycoord - fr.ylo, lv.step, inv_step);
             if (idx < 0) idx += fr.fh;
             fy_lane = (idx < 0 || idx >= fr.fh) ? -1 : idx;
         }
     }
 #pragma unroll
-    for (int k = 0; k < NR; ++k) {
-        const int i = i0 + NW * k;
-        words[k] = (i < nrow && w <= wlast) ? m.occ_bits[(size_t)(fr.my0 + i) * m.bits_pitch + w] : 0u;
-        fyk[k] = __builtin_amdgcn_readlane(fy_lane, k);
-    }
+    for (int k = 0; k < NR; ++k) fyk[k] = __builtin_amdgcn_readlane(fy_lane, k);
     __syncthreads();
     const int col_base = w << 5;
     uint32_t edge = ~0u;
@@ -3166,13 +3177,6 @@ __global__ __launch_bounds__(256) void k_weights(double* logw, const double* __r
 // (int)rint(v / unit) without the fp64 division (~70 issue slots on gfx950, and the update needs two per
 // cell): v * (1/unit) differs from v / unit by < 4e-16 relative, so the two round to the same integer
 // unless the quotient is within 1e-6 of a half-integer -- there the exact division decides.
-__device__ __forceinline__ int rint_div(const double v, const double unit, const double inv_unit) {
-    const double t = v * inv_unit;
-    double rt = rint(t);
-    if (fabs(fabs(t - rt) - 0.5) < 1e-6 || !(fabs(t) < 1e9)) rt = rint(v / unit);
-    return (int)rt;
-}
-
 #define UPDB_BEAMS 4                 // = waves per block
 #ifndef UPDB_UNROLL
 #define UPDB_UNROLL 4
