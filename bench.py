@@ -882,7 +882,7 @@ def config3_closed_loop(P, device):
     for count, raw in enumerate(readings[:5], start=1):          # warm-up: first scans
         pf.updateParticles(raw, count)
         pf.weightUnbalanced()
-    def leg(force=(), groups=None):
+    def leg(force=(), groups=None, P=P):
         pf = pkg.ParticleFilter(P, ogP, smP, device=device, rng=np.random.RandomState(0), groups=groups)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -907,6 +907,12 @@ def config3_closed_loop(P, device):
     forced = leg(force=range(100, len(readings), 100))
     out["forced_resample_every_100"] = {k: v for k, v in forced.items() if k in ("value", "seconds", "scans_per_sec", "resamples",
                                                                                 "state_moving_resamples", "scans_redone")}
+    # the closed loop at other particle counts (one leg each after a warm-up leg: 16 / 256 particles x 910 scans)
+    out["p_sweep"] = {}
+    for PP in (16, 256):
+        leg(P=PP)
+        r = leg(P=PP)
+        out["p_sweep"][str(PP)] = {k: r[k] for k in ("value", "seconds", "scans_per_sec", "scans_voided_and_repeated")}
     return out
 
 
