@@ -50,14 +50,25 @@ def timed_mat(self):
 
 
 engine.MapState._materialise = timed_mat
+refr = [0.0, 0]
+_refresh = engine.ParticleEngine.refresh_maps
+
+
+def timed_refresh(self):
+    t0 = time.perf_counter()
+    _refresh(self)
+    refr[0] += time.perf_counter() - t0; refr[1] += 1
+
+
+engine.ParticleEngine.refresh_maps = timed_refresh
 for G in [int(a) for a in sys.argv[1:]] or [1, 2]:
     for rep in range(3):
         pf = pkg.ParticleFilter(64, ogP, smP, rng=np.random.RandomState(0), groups=G)
-        waited[:] = [0.0, 0]; slow[:] = [0.0, 0]; grow[:] = [0.0, 0]
+        waited[:] = [0.0, 0]; slow[:] = [0.0, 0]; grow[:] = [0.0, 0]; refr[:] = [0.0, 0]
         torch.cuda.synchronize(); t0 = time.perf_counter()
         pf.run(readings)
         torch.cuda.synchronize(); el = time.perf_counter() - t0
         print(f"groups {pf.n_groups}: {el:.4f} s = {910 / el:.0f} scans/s; host waited {waited[0]:.4f} s in {waited[1]} report waits "
               f"({1e3 * waited[0] / max(1, waited[1]):.3f} ms each), issued for {1e3 * (el - waited[0]) / 910:.3f} ms per scan "
               f"(aborted {pf.stats.get('aborted', 0)}, redo {pf.stats['redo']}, step by step {pf.stats['step_by_step']}); step-by-step scans: {slow[1]} in {slow[0]:.4f} s, "
-              f"of which {grow[1]} map re-allocations {grow[0]:.4f} s (host)", flush=True)
+              f"of which {grow[1]} map re-allocations {grow[0]:.4f} s (host); {refr[1]} descriptor refreshes {refr[0]:.4f} s", flush=True)
