@@ -433,6 +433,8 @@ class HotPathGroups:
                 eng = sub.eng
                 eng._before_update()
                 eng.refresh_bits()
+                for lv in sub.levels():
+                    lv.next_generation()
                 cg = self.cgroups[g]
                 if self._maps_seen[g] != eng.maps_version:
                     cg.d_maps, self._maps_seen[g] = eng.d_maps.data_ptr(), eng.maps_version
@@ -671,10 +673,9 @@ def level_stats(hot):
             need = np.bitwise_or.reduce(need, axis=1)
             st["needed_tiles"] = float(np.unpackbits(need.view(np.uint8), axis=1).sum(axis=1).mean())
             st["kbar"] = float(lv.t["kcount"].double().mean().item())
-            frs = lv.frames()                                                   # (the bits of the frame's rows; words beyond are stale)
-            ob = lv.t["occ"].cpu().numpy().view(np.uint32)
-            st["occupied_field_cells"] = float(np.mean([np.unpackbits(ob[q, :frs[q]["fh"], :(frs[q]["fw"] + 31) // 32].copy().view(np.uint8)).sum()
-                                                        for q in range(lv.P)]))
+            P, f = lv.P, lv.fmax * lv.fpitch
+            occ = lv.t["occ"][:P * f].view(P, f)
+            st["occupied_field_cells"] = float((occ == lv.c.occ_gen).sum(dim=1).double().mean().item())
             for a, v in st.items():
                 acc[a] = (max(acc.get(a, 0.0), v) if a == "kept_max_per_theta" else acc.get(a, 0.0) + v * lv.P)
             wsum += lv.P

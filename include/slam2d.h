@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define SLAM2D_ABI_VERSION 14
+#define SLAM2D_ABI_VERSION 13
 #define SLAM2D_SPOKE_BAND 16         /* radial band width of the beam-major spoke table, in cells */
 
 /* library error codes (negative; positive values are hipError_t) */
@@ -167,10 +167,9 @@ typedef struct {
     double max_move_dev;     /* maxMoveDeviation            (:103) */
     /* ---- workspaces, all device, sized for P particles ---- */
     Slam2dFrame* frames;     /* [P] */
-    uint32_t* occ;           /* [P][fmax][op] occupied field cells as BITS, op = (fpitch + 31) / 32 + 1 words per row: bit (x & 31) of
-                                word x >> 5 of row y = field cell (y, x) holds an occupied map cell (:29-37).  Every build rewrites
-                                every word of the frame's rows; zero the buffer once after allocation (the padding word of a row is
-                                read, never written) */
+    int32_t* axis_x;         /* [P][wmax] field column of every window map column */
+    int32_t* axis_y;         /* [P][wmax] */
+    uint8_t* occ;            /* [P][fmax][fpitch] occupied field cells; then [P][2 tmax][fp] block flags (8 x 8 cells), fp = (2 tmax + 17) & ~15 */
     uint32_t* field;         /* [P][fmax][fpitch]  fixed-point cost of probSP (see above) */
     int32_t* cells;          /* [P][ntheta][kmax] unique endpoint cells (patch-corner offsets) */
     int32_t* kcount;         /* [P][ntheta] */
@@ -179,9 +178,8 @@ typedef struct {
     Slam2dPartial* partials; /* [P][npartial] per-wave reductions of the cube (sweep -> select) */
     int32_t npartial;        /* capacity per particle: ntheta * ceil(ny*nx / 64) */
     int32_t tmax;            /* ceil(fmax / 16): 16x16-cell tiles per field edge */
-    uint16_t* tilemask;      /* [P][2 tmax][fq], fq = ((2 tmax + 17) & ~15) / 16 words per row: bit (X & 15) of word X >> 4 of row Y = the
-                                8 x 8-cell block (Y, X) of the field holds an occupied cell.  Written with occ (rows below
-                                ceil(fh / 8) whole at every build); zero once after allocation.  Four flags per blur tile: at a blur
+    uint8_t* tilemask;       /* [P][2 tmax][fp], fp = (2 tmax + 17) & ~15 (the bytes beyond 2 tmax of a row are never written): the 8 x 8-cell block holds an occupied field cell (stamped like occ; must follow
+                                occ contiguously: one memset clears both when occ_gen == 0).  Four flags per blur tile: at a blur
                                 radius of 8 a tile's halo is exactly its 4 x 4 blocks, so the triage lists exactly the tiles whose
                                 halo holds a wall */
     uint8_t* tilestate;      /* [P][tmax][tmax] PERSISTENT across calls: 0 = the field tile already holds
@@ -227,6 +225,10 @@ typedef struct {
     int32_t bnb;             /* 1: slam2d_match scores this level by branch and bound; 2: with two-level bounds; 3: angle bounds
                                 (cubes of <= 5 x 5 poses per angle: needs gmin, gmin2, pcells, bounds [P][ntheta], bnb_best, seed_key) */
     int32_t ep_group;        /* angles per k_endpoints block (>= 1; 0 = 1): tileneed holds ceil(ntheta / ep_group) slices per particle */
+    int32_t occ_gen;         /* 0: occ + tilemask are cleared at every build.  1..255: generation stamp -- an
+                                occ / tilemask byte means "occupied" only when it equals occ_gen, so nothing is
+                                cleared; the caller passes a value unused since the buffers were last zeroed
+                                (count 1, 2, ... 254, zero the buffers, start again at 1) */
 } Slam2dLevel;
 
 /* Result of one level for one particle. */
@@ -441,7 +443,8 @@ int slam2d_weights_merge(double* d_logw, int32_t N, const double* d_parts, int32
  * scan (slam2d_groups_step) or two (match / commit: the pipelined closed loop reads the previous scan's report in between).
  *
  * A group is described by HOST pointers to its level descriptors -- either levels of its own or offset views of a larger
- * level (every per-particle pointer advanced by the group's first particle) -- and by device pointers to its slices of the
+ * level (every per-particle pointer advanced by the group's first particle; `tilemask` then no longer follows `occ`
+ * contiguously, which is accepted whenever occ_gen != 0: nothing is cleared) -- and by device pointers to its slices of the
  * per-particle arrays. */
 typedef struct {
     const Slam2dLevel* coarse;   /* HOST pointer */
@@ -546,7 +549,7 @@ int slam2d_device_sincos(const double* d_angles, int32_t n, double* d_cos, doubl
  * events, returns their summed duration and launch count, and resets the stage. */
 #define SLAM2D_STAGE_SWEEP     0   /* k_sweep: pose-cube scoring */
 #define SLAM2D_STAGE_BLUR      1   /* k_blur_clamp: separable blur + clamp */
-#define SLAM2D_STAGE_SCATTER   2   /* k_occ_field as its own launch: map window -> occupied field cells (bits) */
+#define SLAM2D_STAGE_SCATTER   2   /* k_occ_scatter: map window -> occupied field cells */
 #define SLAM2D_STAGE_UPDATE    3   /* k_grid_update: occupancy-grid update */
 #define SLAM2D_STAGE_SELECT    4   /* k_select: argmax / soft-max draw / confidence */
 #define SLAM2D_STAGE_ENDPOINTS 5   /* k_endpoints: unique endpoint cells */

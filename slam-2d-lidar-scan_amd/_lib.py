@@ -40,7 +40,7 @@ MAX_BLUR_RADIUS = 16
 MAX_BEAMS = 2048
 SPOKE_BAND = 16
 SYNC_WORDS = 4
-ABI_VERSION = 14
+ABI_VERSION = 13
 MATCH_PRUNE_BY_PRIOR = 1
 MATCH_PRIOR_READY = 2
 PRUNE_MARGIN = 40.0
@@ -89,7 +89,7 @@ class Slam2dLevel(C.Structure):
                 ("ncell", C.c_int32), ("ntheta", C.c_int32), ("fine", C.c_int32), ("kmax", C.c_int32),
                 ("thetas", _vp), ("theta_cos", _vp), ("theta_sin", _vp),
                 ("rv_coef", C.c_double), ("tw_coef", C.c_double), ("max_move_dev", C.c_double),
-                ("frames", _vp), ("occ", _vp), ("field", _vp),
+                ("frames", _vp), ("axis_x", _vp), ("axis_y", _vp), ("occ", _vp), ("field", _vp),
                 ("cells", _vp), ("kcount", _vp), ("prior", _vp), ("cube", _vp),
                 ("partials", _vp), ("npartial", C.c_int32), ("tmax", C.c_int32), ("tilemask", _vp),
                 ("tilestate", _vp), ("tilemin", _vp), ("tilemax", _vp),
@@ -97,7 +97,7 @@ class Slam2dLevel(C.Structure):
                 ("ring", _vp), ("prune_state", _vp), ("ring_cap", C.c_int32),
                 ("gmin", _vp), ("gmin2", _vp), ("pcells", _vp), ("bounds", _vp), ("tile_pmax", _vp), ("bnb_best", _vp),
                 ("gmin3d", _vp), ("p3cells", _vp), ("bounds1", _vp), ("seed_key", _vp),
-                ("beam_xy", _vp), ("sync", _vp), ("bnb", C.c_int32), ("ep_group", C.c_int32)]
+                ("beam_xy", _vp), ("sync", _vp), ("bnb", C.c_int32), ("ep_group", C.c_int32), ("occ_gen", C.c_int32)]
 
 
 class Slam2dMatch(C.Structure):

@@ -88,15 +88,14 @@ __device__ __forceinline__ double unorder_bits(unsigned long long k) {
     unsigned long long b = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
     return __longlong_as_double((long long)b);
 }
-// Field-space occupancy bits of one particle (Slam2dLevel.occ): [fmax][occ_pitch] 32-bit words, bit (x & 31) of word x >> 5 of row y set
-// = field cell (y, x) holds an occupied map cell.  Every build rewrites every word of the frame's rows (occ_field_role), so nothing is
-// ever cleared.  One word of padding per row: the blur reads a row's halo as two adjacent words.
-__host__ __device__ __forceinline__ int occ_pitch(const Slam2dLevel& lv) { return ((lv.fpitch + 31) >> 5) + 1; }
-// Block flags of one particle (Slam2dLevel.tilemask): [2 tmax][flag_words] 16-bit words, bit (X & 15) of word X >> 4 of row Y set = the
-// 8 x 8-cell block (Y, X) of the field holds an occupied cell.  Rows below ceil(fh / 8) are rewritten whole at every build; rows
-// beyond are stale and masked by the reader.
-__host__ __device__ __forceinline__ int flag_words(const Slam2dLevel& lv) { return (((lv.tmax << 1) + 17) & ~15) >> 4; }
-__host__ __device__ __forceinline__ size_t flag_count(const Slam2dLevel& lv) { return (size_t)(lv.tmax << 1) * flag_words(lv); }
+// Block flags of one particle: [2 tmax][flag_pitch] bytes, the pitch a multiple of 16 with at least two unused (never
+// written, hence never "set") bytes at the end of every row: the triage copies rows with 16-byte loads and reads the byte left
+// of a row's first flag from the padding of the row above.
+__host__ __device__ __forceinline__ int flag_pitch(const Slam2dLevel& lv) { return ((lv.tmax << 1) + 17) & ~15; }
+__host__ __device__ __forceinline__ size_t flag_bytes(const Slam2dLevel& lv) { return (size_t)(lv.tmax << 1) * flag_pitch(lv); }
+// The occupied-field image and the tile flags are not cleared between builds: a cell / tile is
+// occupied when its byte equals the build's generation stamp (Slam2dLevel.occ_gen, 1..255).
+__device__ __forceinline__ uint8_t occ_stamp(const Slam2dLevel& lv) { return (uint8_t)(lv.occ_gen ? lv.occ_gen : 1); }
 // The needed-tile bitmap of slam2d_match: one slice per (particle, group of ep_group angles), written whole by that group's k_endpoints block
 // with plain stores (every call overwrites every word: nothing to clear) and OR-ed over theta by the triage.  One shared
 // bitmap per particle cost k_endpoints half of its time at 139 angles: every block's atomics met on the same few lines.
@@ -107,6 +106,12 @@ __device__ __forceinline__ int need_slices(const Slam2dLevel& lv) {
 __device__ __forceinline__ uint32_t* need_slice(const Slam2dLevel& lv, const int p, const int grp, const int nneed) {
     return lv.tileneed + ((size_t)p * need_slices(lv) + grp) * nneed;
 }
+// 0x01 in every byte of v that equals the stamp byte (exact per byte), 0x00 elsewhere
+__device__ __forceinline__ uint32_t bytes_equal(const uint32_t v, const uint8_t stamp) {
+    const uint32_t t = v ^ (0x01010101u * stamp);
+    return (~(((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t | 0x7f7f7f7fu)) >> 7;
+}
+
 // The sweep skips loads whose patch holds only the free-space constant when the cell lists are long enough to
 // pay for it (k_sweep) and the tile grid fits 64-bit row masks; k_blur_check_redo then builds those masks.
 __host__ __device__ __forceinline__ bool sweep_skips(const Slam2dLevel& lv) {
@@ -219,10 +224,28 @@ __device__ __forceinline__ int rint_div(const double v, const double unit, const
     return (int)rt;
 }
 
+// trunc_div for non-negative quotients below 2^31 WITHOUT the division when the quotient sits on an integer n -- which is the rule,
+// not the exception: the reference's poses stay on the map's lattice, so (coordinate - window edge) / step is an
+// integer give or take an ulp for every column of the window, rounds either way, and trunc_div's guard sends every one of them
+// through the fp64 division (~35 issue slots).  (int)(v / step) is n iff the correctly rounded quotient reaches n.  r = v - n * step
+// is exact as one fma (v and n * step agree in all but their last bits).  r >= 0: the real quotient is >= n, so is its rounding.
+// r < 0: the quotient rounds UP to n iff it lies within half a spacing g of the doubles just below n (g = ulp(n), half that when n is
+// a power of two; the tie goes to n, whose mantissa is even): r >= -(g / 2) * step, a product with a power of two, exact.
+// tests/test_host_logic.py restates it in Python and checks it against the division on quotients within a few ulp of an integer.
+__device__ __forceinline__ int trunc_div_fast(const double v, const double step, const double inv_step) {
+    const double t = v * inv_step, n = rint(t);
+    if (!(fabs(t - n) < 1e-6) && fabs(t) < 1e9) return (int)t;
+    if (!(n >= 1.0 && n < 2147483648.0)) return (int)(v / step);
+    const double r = __builtin_fma(-n, step, v);
+    const int ni = (int)n, e = 31 - __clz(ni), pow2 = (ni & (ni - 1)) == 0 ? 1 : 0;
+    const double ghalf = __longlong_as_double((long long)(1023 + e - 53 - pow2) << 52);
+    return r >= -ghalf * step ? ni : ni - 1;
+}
+
 // ------------------------------------------------------------------------------------
 // K2a  frame geometry                      (Utils/ScanMatcher_OGBased.py:21-28)
 // ------------------------------------------------------------------------------------
-// Frame geometry of one particle (every thread of k_frames evaluates it redundantly: a few fp64
+// Frame geometry of one particle (every thread of k_frame_axis evaluates it redundantly: a few fp64
 // operations are cheaper than a kernel boundary).
 __device__ __forceinline__ Slam2dFrame make_frame(const Slam2dLidar& lid, const Slam2dLevel& lv, const Slam2dMap& m,
                                                   const double ex, const double ey, uint32_t& f) {
@@ -252,15 +275,14 @@ __device__ __forceinline__ Slam2dFrame make_frame(const Slam2dLidar& lid, const 
 }
 
 // ------------------------------------------------------------------------------------
-// K2a'  frame geometry (:21-28) of every particle as its own launch (slam2d_field_build; slam2d_match from
-//       SLAM2D_BEAM_TABLE_MIN beams, where it also tabulates the beam endpoints of the estimate)
+// K2a+b  frame geometry (:21-28) and the field index of every window column / row (:32-36,173-176)
 // ------------------------------------------------------------------------------------
-__global__ void k_frames(Slam2dLidar lid, Slam2dLevel lv, const Slam2dMap* __restrict__ maps,
-                         const double* __restrict__ centre, int cstride, uint32_t* flags,
-                         const double* __restrict__ ranges) {
-    const int p = blockIdx.y;
+__global__ void k_frame_axis(Slam2dLidar lid, Slam2dLevel lv, const Slam2dMap* __restrict__ maps,
+                             const double* __restrict__ centre, int cstride, uint32_t* flags,
+                             const double* __restrict__ ranges) {
+    const int p = blockIdx.y, axis = blockIdx.z;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ranges) {
+    if (ranges && axis == 0) {
         // covertMeasureToXY (Utils/ScanMatcher_OGBased.py:81-89) once per particle: k_endpoints' ntheta blocks of the
         // particle would otherwise each evaluate the same cos / sin (a third of its time at 1081 beams x 139 angles)
         const double ex = centre[(size_t)p * cstride], ey = centre[(size_t)p * cstride + 1], eth = centre[(size_t)p * cstride + 2];
@@ -274,274 +296,199 @@ __global__ void k_frames(Slam2dLidar lid, Slam2dLevel lv, const Slam2dMap* __res
             lv.beam_xy[((size_t)p * B + b) * 2 + 1] = ey + sin(a) * rg;                          // :88
         }
     }
-    if (j != 0) return;
+    const Slam2dMap m = maps[p];
     uint32_t f;
-    const Slam2dFrame fr = make_frame(lid, lv, maps[p], centre[(size_t)p * cstride], centre[(size_t)p * cstride + 1], f);
-    lv.frames[p] = fr;
-    lv.tilecount[2 * p] = 0; lv.tilecount[2 * p + 1] = 0;
-    if (lv.bnb) lv.bnb_best[p] = order_bits(-INFINITY);
-    if (lv.bnb >= 2) lv.seed_key[p] = 0ull;
-    if (f) atomicOr(&flags[p], f);
+    const Slam2dFrame fr = make_frame(lid, lv, m, centre[(size_t)p * cstride], centre[(size_t)p * cstride + 1], f);
+    if (j == 0 && axis == 0) {
+        lv.frames[p] = fr;
+        lv.tilecount[2 * p] = 0; lv.tilecount[2 * p + 1] = 0;
+        if (lv.bnb) lv.bnb_best[p] = order_bits(-INFINITY);
+        if (lv.bnb >= 2) lv.seed_key[p] = 0ull;
+        if (f) atomicOr(&flags[p], f);
+    }
+    const int n = axis == 0 ? fr.mx1 - fr.mx0 : fr.my1 - fr.my0;
+    if (j >= n) return;
+    const double coord = axis == 0 ? m.X[fr.mx0 + j] : m.Y[fr.my0 + j];
+    const double lo = axis == 0 ? fr.xlo : fr.ylo;
+    const int dim = axis == 0 ? fr.fw : fr.fh;
+    int idx = (int)((coord - lo) / lv.step);       // astype(int): truncation toward zero
+    if (idx < 0) idx += dim;                       // Python negative-index wrap (:37)
+    if (idx < 0 || idx >= dim) { idx = -1; atomicOr(&flags[p], SLAM2D_F_FIELD_INDEX); }
+    (axis == 0 ? lv.axis_x : lv.axis_y)[(size_t)p * lv.wmax + j] = idx;
 }
 
 // ------------------------------------------------------------------------------------
 // K2c  occupied map cells -> occupied field cells  (Utils/ScanMatcher_OGBased.py:29-37)
+//      HBM-bound: streams the map window once (4 B / map cell), byte scatter into occ.
 // ------------------------------------------------------------------------------------
-// The reference takes the coordinates of every occupied map cell of the window, truncates them to field indices (:32-36, negative
-// indices wrap, :37) and writes 0 there.  Rounds 1-4 did the same: a scatter of stamped bytes, one store per occupied map cell
-// (two thirds of the vector instructions of the endpoint launch it rode in, for an image whose readers look at 10-20 %).  Round 5
-// GATHERS instead, in bits: the coordinates ascend, so the map columns that land in one field column are a contiguous run
-// [clo, chi) -- and where the field's step is the map's unit (every fine level; config 2) a whole 32-column word of the field is
-// 32 CONSECUTIVE map columns, i.e. a funnel shift of two words of the map's bit image.  A field row is the OR of the map rows
-// that land in it.  One wave streams the map rows of its field rows (8 loads in flight), ORs them per field row, and turns the
-// ORed row into field words: a funnel shift per word where the word is "pure" (32 runs of length 1 at consecutive columns),
-// a ballot over 32 lanes (lane = field column: its run's bits of the row, masked) elsewhere -- a coarse level (5 map cells per
-// field cell), the seams of a grown map's compressed coordinates (Utils/OccupancyGrid.py:59-100), the +-1 jitter of a truncation
-// that sits on a lattice point.  Columns / rows whose index wrapped round the low edge (:37) are kept in short lists and ORed in.
-// By-products: the flags of the 8 x 8-cell blocks (k_tile_triage), as bits.  Every word of the frame's rows is written at every
-// build: no clearing, no generation stamps, and the readers (the blur's halo, the triage) take 1/8 of the bytes.
-//
-// Every block derives the frame and BOTH forward tables itself (one fp64 multiply-truncate per window column and row: cheaper
-// than a kernel boundary or a hand-off from another block of the same launch), then owns NW * rpw field rows.
-#define OCCF_MAX_WRAP 32
-#define OCCF_ROWBUF 68                 // one zero word, 64 words of the ORed window row, zero words behind
-#define OCCF_BATCH 16
-#define OCCF_HI 0x7FFF               // forward index of a window column / row beyond the field's high edge (flagged)
-struct OccFieldLds { int fwd_c, fwd_r, clo, chi, src, mask, misc, rowbuf, total; };     // byte offsets into the dynamic LDS
-__host__ __device__ __forceinline__ OccFieldLds occ_field_lds(const Slam2dLevel& lv, const int nwaves) {
-    OccFieldLds o;
-    const int wpad = (lv.wmax + 7) & ~7, fpad = (lv.fmax + 7) & ~7;
-    int b = 0;
-    o.fwd_c = b; b += 2 * wpad;
-    o.fwd_r = b; b += 2 * wpad;
-    o.clo = b; b += 2 * fpad;
-    o.chi = b; b += 2 * fpad;
-    o.src = b; b += 2 * ((occ_pitch(lv) + 7) & ~7);
-    o.mask = b; b += 8 * ((occ_pitch(lv) + 1) & ~1);
-    o.misc = b; b += 4 * (16 + 4 * OCCF_MAX_WRAP);
-    o.rowbuf = b; b += 4 * nwaves * OCCF_ROWBUF;
-    o.total = b;
-    return o;
-}
-// field rows per wave (a multiple of 8: a wave owns whole rows of block flags): about 16 map rows -- one batch of loads -- where
-// the level's step allows, 8 field rows otherwise.  SLAM2D_OCCF_RPW overrides.
-__host__ __forceinline__ int occ_field_rpw(const Slam2dLidar& lid, const Slam2dLevel& lv) {
-    static const int forced = [] { const char* e = getenv("SLAM2D_OCCF_RPW"); return e ? atoi(e) & ~7 : 0; }();
-    if (forced >= 8 && forced <= 64) return forced;
-    const double ratio = lv.step / lid.unit;
-    int r = ratio > 0.0 ? (int)(16.0 / ratio) : 8;
-    r &= ~7;
-    return r < 8 ? 8 : r > 64 ? 64 : r;
+// The occupied / free state of every map cell is kept as one bit (Slam2dMap.occ_bits, maintained by
+// the update kernel), so the field build reads 1/32 of the bytes the count map holds.
+// One thread = one 32-cell word of the map window.
+#define SCATTER_ROWS 32
+__global__ __launch_bounds__(256) void k_occ_scatter(Slam2dLevel lv, const Slam2dMap* __restrict__ maps) {
+    // wave = threadIdx.y walks 8 rows of the map window; lane = one 32-cell word of the row.  The bits
+    // of a non-zero word are handled by 32 lanes at once (two words per step), so a horizontal wall --
+    // words with up to 32 bits set -- costs one step, not 32 serial iterations of one lane.
+    const int p = blockIdx.z;
+    const Slam2dFrame fr = lv.frames[p];
+    const int nrow = fr.my1 - fr.my0;
+    if (fr.mx1 <= fr.mx0 || nrow <= 0) return;
+    const int lane = threadIdx.x, wave = threadIdx.y;
+    const int w0 = (fr.mx0 >> 5) + blockIdx.x * 64, wlast = (fr.mx1 - 1) >> 5;
+    if (w0 > wlast) return;
+    const int w = w0 + lane;
+    const Slam2dMap m = maps[p];
+    constexpr int NR = SCATTER_ROWS / 4;
+    const int i0 = blockIdx.y * SCATTER_ROWS + wave;
+    // the field column of every window column is staged in LDS and the rows' field indices are loaded with
+    // the words: the expansion loop below then has no global load in its dependency chain
+    extern __shared__ int32_t ax_s[];
+    const int ncol = fr.mx1 - fr.mx0;
+    {
+        const int32_t* __restrict__ ax = lv.axis_x + (size_t)p * lv.wmax;
+        for (int j = wave * 64 + lane; j < ncol; j += 256) ax_s[j] = ax[j];
+    }
+    uint32_t words[NR];
+    int fyk[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int i = i0 + 4 * k;
+        words[k] = (i < nrow && w <= wlast) ? m.occ_bits[(size_t)(fr.my0 + i) * m.bits_pitch + w] : 0u;
+        fyk[k] = i < nrow ? lv.axis_y[(size_t)p * lv.wmax + i] : -1;
+    }
+    __syncthreads();
+    const int col_base = w << 5;
+    uint32_t edge = ~0u;
+    if (col_base < fr.mx0) edge &= ~0u << (fr.mx0 - col_base);                    // window edges
+    if (col_base + 32 > fr.mx1) edge &= ~0u >> (col_base + 32 - fr.mx1);
+    const int fpad = flag_pitch(lv);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(lv.occ + (size_t)p * lv.fmax * lv.fpitch), (short)0, (int)((size_t)lv.fmax * lv.fpitch), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(lv.tilemask + (size_t)p * flag_bytes(lv)), (short)0, (int)flag_bytes(lv), 0x00020000);   // flags of 8 x 8-cell blocks, [2 tmax][flag_pitch]
+    const uint8_t stamp = occ_stamp(lv);
+    const int half = lane >> 5, bit = lane & 31;
+    const int lbase = (w0 << 5) + bit - fr.mx0;            // the lane's column of word w0, relative to the window
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const uint32_t word = words[k] & edge;
+        unsigned long long nz = __ballot(word != 0u);
+        if (!nz) continue;
+        const int fy = __builtin_amdgcn_readfirstlane(fyk[k]);                     // (the wave's row: uniform)
+        if (fy < 0) continue;                                                      // :36-37
+        const int so = fy * lv.fpitch, st = (fy >> FLAG_SHIFT) * fpad;
+        while (nz) {
+            const int sa = __ffsll((long long)nz) - 1;
+            nz &= nz - 1;
+            int sb = -1;
+            if (nz) { sb = __ffsll((long long)nz) - 1; nz &= nz - 1; }
+            // (sa, sb are wave-uniform: v_readlane, not a ds_bpermute round trip per step)
+            const uint32_t wa = (uint32_t)__builtin_amdgcn_readlane((int)word, sa), wb = sb >= 0 ? (uint32_t)__builtin_amdgcn_readlane((int)word, sb) : 0u;
+            const uint32_t wsel = half ? wb : wa;
+            const int src = half ? sb : sa;
+            if ((wsel >> bit) & 1u) {
+                const int fx = ax_s[lbase + (src << 5)];
+                if (fx >= 0) {                                                     // (buffer stores: see scatter_role)
+                    __builtin_amdgcn_raw_buffer_store_b8(stamp, ro, fx, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b8(stamp, rt, fx >> FLAG_SHIFT, st, 0);
+                }
+            }
+        }
+    }
 }
 
+// k_occ_scatter's work as a block role of k_endpoints' launch (slam2d_match below 512 beams, where no k_frame_axis
+// precedes it): the block derives the frame itself and evaluates the field index of its columns / rows inline (:32-37)
+// instead of reading the axis tables the frame block of the same launch is still writing.  Block (sbx, sby) of NW waves:
+// wave = 8 rows of the map window, lane = one 32-cell word.  Out-of-range indices are skipped here and flagged by the
+// frame block.
+#ifndef SCATTER_ROLE_NR
+#define SCATTER_ROLE_NR 8           // map rows per wave of the scatter role (every block derives the field index of ALL window columns first)
+#endif
 template <int NW>
-__device__ __forceinline__ void occ_field_role(const Slam2dLidar& lid, const Slam2dLevel& lv, const Slam2dMap* __restrict__ maps,
-                                               const double* __restrict__ centre, const int cstride, uint32_t* flags, const int p,
-                                               const int sb, const int rpw, uint8_t* lds) {
-    constexpr int NT = NW * 64;
+__device__ __forceinline__ void scatter_role(const Slam2dLidar& lid, const Slam2dLevel& lv, const Slam2dMap* __restrict__ maps,
+                                             const double* __restrict__ centre, const int cstride, const int p,
+                                             const int sbx, const int sby, int32_t* ax_s) {
     const Slam2dMap m = maps[p];
     uint32_t fignore;
     const Slam2dFrame fr = make_frame(lid, lv, m, centre[(size_t)p * cstride], centre[(size_t)p * cstride + 1], fignore);
-    const int fh = fr.fh, fw = fr.fw;
-    const int fyb0 = sb * (NW * rpw);
-    if (fyb0 >= fh) return;                                // (block-uniform)
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nrow = max(fr.my1 - fr.my0, 0), ncol = max(fr.mx1 - fr.mx0, 0);
-    const OccFieldLds Lo = occ_field_lds(lv, NW);
-    int16_t* fwd_c = reinterpret_cast<int16_t*>(lds + Lo.fwd_c);          // [ncol] field column of window column j; -1: wrapped / below, OCCF_HI: beyond
-    int16_t* fwd_r = reinterpret_cast<int16_t*>(lds + Lo.fwd_r);          // [nrow]
-    uint16_t* clo = reinterpret_cast<uint16_t*>(lds + Lo.clo);            // [fw] the run of window columns of field column f: [clo, chi)
-    uint16_t* chi = reinterpret_cast<uint16_t*>(lds + Lo.chi);
-    int16_t* src = reinterpret_cast<int16_t*>(lds + Lo.src);              // [nwo] shifted word: bit index of its first column's source in the row buffer; -1: not shifted
-    uint32_t* mska = reinterpret_cast<uint32_t*>(lds + Lo.mask);          // [nwo] its columns fed from distance D / D + 1
-    uint32_t* mskb = mska + ((occ_pitch(lv) + 1) & ~1);
-    int* misc = reinterpret_cast<int*>(lds + Lo.misc);                    // [0] wrapped columns, [1] wrapped rows, [4 + k] first map row of wave k
-    int* wave_i = misc + 4;
-    int* wc_j = misc + 16, *wc_f = wc_j + OCCF_MAX_WRAP, *wr_i = wc_f + OCCF_MAX_WRAP, *wr_f = wr_i + OCCF_MAX_WRAP;
-    uint32_t* rowbuf = reinterpret_cast<uint32_t*>(lds + Lo.rowbuf) + wave * OCCF_ROWBUF;
-    const bool dbg = p == 0 && sb == 1;
-    DBG_CLOCK(14, dbg);
-    if (tid < 2) misc[tid] = 0;
-    if (tid < NW + 1) wave_i[tid] = nrow;
-    for (int f = tid; f < fw; f += NT) { clo[f] = 0; chi[f] = 0; }
-    // (:32-36) astype(int) truncates; (:37) a negative index counts from the field's high edge
+    const int nrow = fr.my1 - fr.my0;
+    if (fr.mx1 <= fr.mx0 || nrow <= 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int w0 = (fr.mx0 >> 5) + sbx * 64, wlast = (fr.mx1 - 1) >> 5;
+    if (w0 > wlast) return;
+    const int w = w0 + lane;
+    constexpr int NR = SCATTER_ROLE_NR;
+    const int i0 = sby * (NW * NR) + wave;
+    if (sby * (NW * NR) >= nrow) return;
+    const int ncol = fr.mx1 - fr.mx0;
     const double inv_step = 1.0 / lv.step;
-    bool bad = false;
-    for (int j = tid; j < ncol; j += NT) {
-        int idx = trunc_div(m.X[fr.mx0 + j] - fr.xlo, lv.step, inv_step), v;
-        if (idx >= fw) { v = OCCF_HI; bad = true; }
-        else if (idx >= 0) v = idx;
-        else {
-            v = -1; idx += fw;
-            if (idx < 0) bad = true;
-            else { const int k = atomicAdd(&misc[0], 1); if (k < OCCF_MAX_WRAP) { wc_j[k] = j; wc_f[k] = idx; } else bad = true; }
-        }
-        fwd_c[j] = (int16_t)v;
-    }
-    for (int i = tid; i < nrow; i += NT) {
-        int idx = trunc_div(m.Y[fr.my0 + i] - fr.ylo, lv.step, inv_step), v;
-        if (idx >= fh) { v = OCCF_HI; bad = true; }
-        else if (idx >= 0) v = idx;
-        else {
-            v = -1; idx += fh;
-            if (idx < 0) bad = true;
-            else { const int k = atomicAdd(&misc[1], 1); if (k < OCCF_MAX_WRAP) { wr_i[k] = i; wr_f[k] = idx; } else bad = true; }
-        }
-        fwd_r[i] = (int16_t)v;
-    }
-    __syncthreads();
-    DBG_CLOCK(15, dbg);
-    // the runs of the field columns; the first map row of every wave's field rows (the forward tables ascend)
-    for (int j = tid; j < ncol; j += NT) {
-        const int v = fwd_c[j];
-        if (v < 0 || v == OCCF_HI) continue;
-        const int prev = j ? fwd_c[j - 1] : -1, next = j + 1 < ncol ? fwd_c[j + 1] : OCCF_HI;
-        if (prev > v) bad = true;                          // (descending coordinates: not a map this library wrote)
-        if (prev != v) clo[v] = (uint16_t)j;
-        if (next != v) chi[v] = (uint16_t)(j + 1);
-    }
-    for (int i = tid; i < nrow; i += NT) {
-        const int v = fwd_r[i], prev = i ? fwd_r[i - 1] : -1;
-        if (v < 0) continue;
-        if (prev > v) bad = true;
+    // (the rows' words and coordinates are requested FIRST: they need the frame only, and their round trip then runs under the
+    // column table's)
+    uint32_t words[NR];
+    int fyk[NR];
 #pragma unroll
-        for (int k = 0; k <= NW; ++k) { const int fs = min(fyb0 + k * rpw, fh); if (v >= fs && prev < fs) wave_i[k] = i; }
+    for (int k = 0; k < NR; ++k) {
+        const int i = i0 + NW * k;
+        words[k] = (i < nrow && w <= wlast) ? m.occ_bits[(size_t)(fr.my0 + i) * m.bits_pitch + w] : 0u;
     }
-    if (bad) atomicOr(&flags[p], SLAM2D_F_FIELD_INDEX);
-    __syncthreads();
-    DBG_CLOCK(16, dbg);
-    // shifted words: every window column that lands in the word sits D or D + 1 columns right of its field column (D = the word's
-    // smallest such distance) -- a field at the map's resolution: D alone off the lattice; both where the truncation sits ON a
-    // lattice point and falls either way from column to column (a pose estimate on the map's lattice: the reference's own case,
-    // SURVEY.md H1) or across a seam of compressed coordinates.  The word is then two funnel shifts of the row under two masks.
-    const int nwo = (fw + 31) >> 5, boff = fr.mx0 & 31;
-    for (int wb = 0; wb < nwo; wb += NT / 32) {            // (uniform trip count: ballots and shuffles inside)
-        const int wo = wb + (tid >> 5), b = tid & 31, fx = (wo << 5) + b;
-        int dlo = INT_MAX, dhi = INT_MIN;
-        if (wo < nwo && fx < fw && chi[fx] > clo[fx]) { dlo = (int)clo[fx] - fx; dhi = (int)chi[fx] - 1 - fx; }
-        int D = dlo, Dh = dhi;
-#pragma unroll
-        for (int o = 1; o < 32; o <<= 1) { D = min(D, __shfl_xor(D, o)); Dh = max(Dh, __shfl_xor(Dh, o)); }
-        const int D1 = D == INT_MAX ? D : D + 1;
-        const bool shifted = Dh <= D1;                                     // (an empty word: masks of zeros)
-        const unsigned long long ba = __ballot(dlo != INT_MAX && dlo <= D && D <= dhi);
-        const unsigned long long bb = __ballot(dlo != INT_MAX && dlo <= D1 && D1 <= dhi);
-        if (wo < nwo && b == 0) {
-            const int sh = (lane >> 5) << 5;
-            // bit index of the word's first column's source in the row buffer (one zero word in front: D may point left of it)
-            src[wo] = shifted ? (int16_t)(D == INT_MAX ? 32 : (wo << 5) + D + boff + 32) : (int16_t)-1;
-            mska[wo] = (uint32_t)(ba >> sh); mskb[wo] = (uint32_t)(bb >> sh);
+    const double ycoord = (lane < NR && i0 + NW * lane < nrow) ? m.Y[fr.my0 + i0 + NW * lane] : 0.0;
+    for (int j = threadIdx.x; j < ncol; j += NW * 64) {
+        int idx = trunc_div_fast(m.X[fr.mx0 + j] - fr.xlo, lv.step, inv_step);
+        if (idx < 0) idx += fr.fw;                         // Python negative-index wrap (:37)
+        ax_s[j] = (idx < 0 || idx >= fr.fw) ? -1 : idx;
+    }
+    int fy_lane = -1;                                      // lane k < NR evaluates the field row of the wave's k-th map row
+    if (lane < NR) {
+        const int i = i0 + NW * lane;
+        if (i < nrow) {
+            int idx = trunc_div_fast(ycoord - fr.ylo, lv.step, inv_step);
+            if (idx < 0) idx += fr.fh;
+            fy_lane = (idx < 0 || idx >= fr.fh) ? -1 : idx;
         }
     }
+#pragma unroll
+    for (int k = 0; k < NR; ++k) fyk[k] = __builtin_amdgcn_readlane(fy_lane, k);
     __syncthreads();
-    DBG_CLOCK(17, dbg);
-    const int fya = min(fyb0 + wave * rpw, fh), fyb = min(fya + rpw, fh);
-    if (fya >= fyb) return;                                // (whole waves; no barrier follows)
-    const int w0 = fr.mx0 >> 5;
-    const int nww = ncol > 0 ? ((fr.mx1 - 1) >> 5) - w0 + 1 : 0;            // words of a window row (<= 64: check_field_args)
-    const bool wl = lane < nww;
-    const uint32_t* __restrict__ bits = m.occ_bits + (size_t)fr.my0 * m.bits_pitch + w0 + lane;
-    // the lane's word: where its source bits lie in the ORed row (lane qa holds the low word), how far they are shifted, and the
-    // two masks -- kept in registers: a field row then costs two cross-lane reads and a handful of vector instructions
-    const int s_l = lane < nwo ? (int)src[lane] : -1;
-    const unsigned long long genmask = __ballot(lane < nwo && s_l < 0);
-    const uint32_t ma = s_l >= 0 ? mska[lane] : 0u, mb = s_l >= 0 ? mskb[lane] : 0u;
-    const int qa = (max(s_l, 0) >> 5) - 1, sh = max(s_l, 0) & 31;           // (the row buffer's word q is lane q - 1)
-    const uint32_t vlo = (qa >= 0 && qa < 64) ? ~0u : 0u, vhi = (qa + 1 >= 0 && qa + 1 < 64) ? ~0u : 0u;
-    const int nwc = __builtin_amdgcn_readfirstlane(min(misc[0], OCCF_MAX_WRAP)), nwr = __builtin_amdgcn_readfirstlane(min(misc[1], OCCF_MAX_WRAP));
-    const bool slow = genmask != 0ull || nwc > 0;          // (wave-uniform) words or columns that need the row in LDS
-    if (lane < 4) rowbuf[lane ? 64 + lane : 0] = 0u;
-    const int op = occ_pitch(lv), qpr = flag_words(lv);
-    uint32_t* fb = lv.occ + (size_t)p * lv.fmax * op;
-    uint16_t* fl = lv.tilemask + (size_t)p * flag_count(lv);
-    uint32_t flagacc = 0u;
-    // field row fy from the OR of its map rows
-    auto emit = [&](const int fy, uint32_t acc) {
-        for (int e = 0; e < nwr; ++e)                       // map rows wrapped round the low edge (:37) -- rare
-            if (wr_f[e] == fy && wl) acc |= bits[(size_t)wr_i[e] * m.bits_pitch];
-        uint32_t out = 0u;
-        if (__ballot(acc != 0u)) {
-            {
-                const uint32_t lo = (uint32_t)__shfl((int)acc, qa & 63) & vlo, hi = (uint32_t)__shfl((int)acc, (qa + 1) & 63) & vhi;
-                const unsigned long long t = ((((unsigned long long)hi) << 32) | lo) >> sh;
-                out = ((uint32_t)t & ma) | ((uint32_t)(t >> 1) & mb);
-            }
-          if (slow) {
-            rowbuf[1 + lane] = acc;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            unsigned long long gm = genmask;
-            while (gm) {                                    // two words per step: lane = field column
-                const int wa = __ffsll((long long)gm) - 1; gm &= gm - 1;
-                int wb = -1;
-                if (gm) { wb = __ffsll((long long)gm) - 1; gm &= gm - 1; }
-                const int wsel = lane < 32 ? wa : wb;
-                const int fx = (wsel << 5) + (lane & 31);
-                uint32_t hit = 0u;
-                if (wsel >= 0 && fx < fw) {
-                    const int a = clo[fx] + boff + 32, b = chi[fx] + boff + 32;   // the run as bits [a, b) of the row buffer
-                    if (b > a) {
-                        for (int wd = a >> 5; wd <= (b - 1) >> 5; ++wd) {
-                            uint32_t mk = ~0u;
-                            if (wd == a >> 5) mk &= ~0u << (a & 31);
-                            if (wd == (b - 1) >> 5) mk &= ~0u >> (31 - ((b - 1) & 31));
-                            hit |= rowbuf[wd] & mk;
-                        }
-                    }
+    const int col_base = w << 5;
+    uint32_t edge = ~0u;
+    if (col_base < fr.mx0) edge &= ~0u << (fr.mx0 - col_base);                    // window edges
+    if (col_base + 32 > fr.mx1) edge &= ~0u >> (col_base + 32 - fr.mx1);
+    // (buffer stores: the row's byte offset rides in the scalar offset, the column in the lane's -- no 64-bit address
+    // arithmetic per set bit; the kernel's launch is bound by its vector instructions)
+    const int fpad = flag_pitch(lv);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(lv.occ + (size_t)p * lv.fmax * lv.fpitch), (short)0, (int)((size_t)lv.fmax * lv.fpitch), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(lv.tilemask + (size_t)p * flag_bytes(lv)), (short)0, (int)flag_bytes(lv), 0x00020000);   // flags of 8 x 8-cell blocks, [2 tmax][flag_pitch]
+    const uint8_t stamp = occ_stamp(lv);
+    const int half = lane >> 5, bit = lane & 31;
+    const int lbase = (w0 << 5) + bit - fr.mx0;            // the lane's column of word w0, relative to the window
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const uint32_t word = words[k] & edge;
+        unsigned long long nz = __ballot(word != 0u);
+        if (!nz) continue;
+        const int fy = fyk[k];
+        if (fy < 0) continue;                                                      // :36-37
+        const int so = fy * lv.fpitch, st = (fy >> FLAG_SHIFT) * fpad;             // (wave-uniform)
+        while (nz) {
+            const int sa = __ffsll((long long)nz) - 1;
+            nz &= nz - 1;
+            int sb = -1;
+            if (nz) { sb = __ffsll((long long)nz) - 1; nz &= nz - 1; }
+            const uint32_t wa = (uint32_t)__builtin_amdgcn_readlane((int)word, sa), wb = sb >= 0 ? (uint32_t)__builtin_amdgcn_readlane((int)word, sb) : 0u;
+            const uint32_t wsel = half ? wb : wa;
+            const int src = half ? sb : sa;
+            if ((wsel >> bit) & 1u) {
+                const int fx = ax_s[lbase + (src << 5)];
+                if (fx >= 0) {
+                    __builtin_amdgcn_raw_buffer_store_b8(stamp, ro, fx, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b8(stamp, rt, fx >> FLAG_SHIFT, st, 0);
                 }
-                const unsigned long long bal = __ballot(hit != 0u);
-                if (lane == wa) out = (uint32_t)bal;
-                if (lane == wb) out = (uint32_t)(bal >> 32);
             }
-            for (int e = 0; e < nwc; ++e) {                 // map columns wrapped round the low edge (:37) -- rare
-                const int rel = wc_j[e] + boff + 32, f = wc_f[e];
-                const uint32_t bit = (rowbuf[rel >> 5] >> (rel & 31)) & 1u;
-                if (lane == (f >> 5)) out |= bit << (f & 31);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-          }
-        }
-        if (lane < nwo) fb[(size_t)fy * op + lane] = out;
-        flagacc |= out;
-        if ((fy & 7) == 7 || fy == fh - 1) {               // the flags of block row fy >> 3: four per lane, sixteen per stored word
-            const uint32_t nib = ((flagacc & 0xFFu) ? 1u : 0u) | ((flagacc & 0xFF00u) ? 2u : 0u) | ((flagacc & 0xFF0000u) ? 4u : 0u) | ((flagacc & 0xFF000000u) ? 8u : 0u);
-            uint32_t t = nib << ((lane & 3) << 2);
-            t |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0xB1, 0xF, 0xF, true);    // quad_perm [1, 0, 3, 2]
-            t |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x4E, 0xF, 0xF, true);    // quad_perm [2, 3, 0, 1]
-            if ((lane & 3) == 0 && (lane >> 2) < qpr) fl[(size_t)(fy >> 3) * qpr + (lane >> 2)] = (uint16_t)t;
-            flagacc = 0u;
-        }
-    };
-    int fy_next = fya, cur = -1;
-    uint32_t acc = 0u;
-    auto flush_upto = [&](const int upto) {                 // rows fy_next .. upto - 1 (row `cur`, if among them, with the ORed bits)
-        for (; fy_next < upto; ++fy_next) emit(fy_next, fy_next == cur ? acc : 0u);
-    };
-    const int ia = __builtin_amdgcn_readfirstlane(wave_i[wave]), ib = __builtin_amdgcn_readfirstlane(wave_i[wave + 1]);
-    for (int i = ia; i < ib; i += OCCF_BATCH) {
-        uint32_t w[OCCF_BATCH];
-#pragma unroll
-        for (int k = 0; k < OCCF_BATCH; ++k) w[k] = (wl && i + k < ib) ? bits[(size_t)(i + k) * m.bits_pitch] : 0u;
-        DBG_CLOCK(18, dbg && i == ia && w[0] != 0xdeadbeefu);
-#pragma unroll
-        for (int k = 0; k < OCCF_BATCH; ++k) {
-            if (i + k >= ib) break;
-            const int fy = __builtin_amdgcn_readfirstlane((int)fwd_r[i + k]);
-            if (fy < fya || fy >= fyb) continue;            // (only behind a flagged table)
-            if (fy != cur) { flush_upto(fy); cur = fy; acc = 0u; }
-            acc |= w[k];
         }
     }
-    flush_upto(fyb);
-    DBG_CLOCK(19, dbg);
-}
-
-__global__ __launch_bounds__(256) void k_occ_field(Slam2dLidar lid, Slam2dLevel lv, const Slam2dMap* __restrict__ maps,
-                                                   const double* __restrict__ centre, int cstride, uint32_t* flags, int rpw) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t occf_lds[];
-    occ_field_role<4>(lid, lv, maps, centre, cstride, flags, blockIdx.y, blockIdx.x, rpw, occf_lds);
 }
 
 __global__ __launch_bounds__(256) void k_refresh_bits(const Slam2dMap* __restrict__ maps, const int32_t* __restrict__ index) {
@@ -611,78 +558,82 @@ __device__ __forceinline__ void blur_tile(const Slam2dLevel& lv, BlurLds<RAD>& s
     const int tid = threadIdx.x;
     const bool dbg = p == 0 && blockIdx.x == 0 && mode == 0;
     DBG_CLOCK(50, dbg);
-    const int op = occ_pitch(lv);
-    const uint32_t* __restrict__ occ = lv.occ + (size_t)p * lv.fmax * op;          // field-space occupancy bits (occ_field_role)
+    const uint8_t* occ = lv.occ + (size_t)p * lv.fmax * lv.fpitch;
+    const uint8_t stamp = occ_stamp(lv);
     uint8_t* state = lv.tilestate + ((size_t)p * lv.tmax + tby) * lv.tmax + tbx;
     // activity: an occupied cell within the halo lies in one of the 8 x 8-cell blocks within ceil(r / 8) blocks of the tile's four
     int any = 1;
     if (use_flags) {
         any = 0;
-        const uint16_t* tiles = lv.tilemask + (size_t)p * flag_count(lv);
+        const uint8_t* tiles = lv.tilemask + (size_t)p * flag_bytes(lv);
         const int nsy = (fh + 7) >> FLAG_SHIFT, nsx = (fw + 7) >> FLAG_SHIFT, k = (r + 7) >> FLAG_SHIFT, e = 2 + 2 * k;
         if (tid < e * e) {
             const int yy = 2 * tby - k + tid / e, xx = 2 * tbx - k + tid % e;
-            if (yy >= 0 && yy < nsy && xx >= 0 && xx < nsx) any = (tiles[yy * flag_words(lv) + (xx >> 4)] >> (xx & 15)) & 1;
+            if (yy >= 0 && yy < nsy && xx >= 0 && xx < nsx) any = tiles[yy * flag_pitch(lv) + xx] == stamp;
         }
         any = __syncthreads_or(any);
     }
     if (any) {
-        // an interior halo is `ext` (<= 32 where RAD > 0) bits of two adjacent words per row; bits + reflect otherwise
+        // word loads when the halo is interior and 4-byte aligned (r % 4 == 0), bytes + reflect otherwise
         const bool interior = ty0 - r >= 0 && ty0 + BLUR_TILE + r <= fh && tx0 - r >= 0 && tx0 + BLUR_TILE + r <= fw;
         int exact = 0;                 // the tile flags are conservative: re-test on the halo itself
-        if constexpr (RAD > 0) {
-            constexpr int EXT_C = BLUR_TILE + 2 * RAD;
-            static_assert(EXT_C <= 32, "a halo row is one 32-bit word only for RAD <= 8");
-            if (interior) {
-                // lane = (row ly, half): both halves load the row's two words (the same addresses), each expands four of the row's
-                // eight nibbles into bytes (1 = free) -- 1/8 of the byte image's loads
-                const int ly = tid & 31, half = tid >> 5;
-                uint32_t hw = 0u;
-                if (ly < EXT_C) {
-                    const int c0 = tx0 - r;
-                    const uint32_t* rowp = occ + (size_t)(ty0 - r + ly) * op + (c0 >> 5);
-                    const unsigned long long two = ((unsigned long long)rowp[1] << 32) | rowp[0];
-                    hw = (uint32_t)(two >> (c0 & 31));
-                    if (EXT_C < 32) hw &= (1u << (EXT_C & 31)) - 1u;
-                }
-                if (ly < EXT_C) {
+        // every load of the halo is issued before the first use: the image is not cache-resident (one
+        // HBM latency instead of one per 64-lane slice)
+        if ((r & 3) == 0 && interior) {
+            const int wpr = ext >> 2;
+            constexpr int NW = RAD > 0 ? ((BLUR_TILE + 2 * RAD) * ((BLUR_TILE + 2 * RAD) / 4) + BLUR_THREADS - 1) / BLUR_THREADS : 1;
+            if constexpr (RAD > 0) {
+                uint32_t v[NW];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int wq = half * 4 + q;
-                        if (4 * wq < EXT_C) {
-                            // nibble -> four 0 / 1 bytes: the multiplier moves bit k to bit 8 k (no two partial products meet)
-                            const uint32_t e4 = (((hw >> (4 * wq)) & 15u) * 0x00204081u) & 0x01010101u;
-                            *reinterpret_cast<uint32_t*>(&sm.occ[ly][4 * wq]) = e4 ^ 0x01010101u;          // (RAD > 0: the LDS image holds 1 = free)
-                        }
-                    }
-                }
-                exact = hw != 0u;
-            } else {
-                constexpr int NB = (EXT_C * EXT_C + BLUR_THREADS - 1) / BLUR_THREADS;
-                uint32_t v[NB];
-                // every load of the halo is issued before the first use (one latency instead of one per 64-lane slice)
-#pragma unroll
-                for (int i = 0; i < NB; ++i) {
-                    const int idx = min(tid + i * BLUR_THREADS, EXT_C * EXT_C - 1);
-                    const int ly = idx / EXT_C, lx = idx - ly * EXT_C;
-                    const int gy = reflect_index(ty0 - r + ly, fh), gx = reflect_index(tx0 - r + lx, fw);
-                    v[i] = (occ[(size_t)gy * op + (gx >> 5)] >> (gx & 31)) & 1u;
+                for (int i = 0; i < NW; ++i) {
+                    const int idx = min(tid + i * BLUR_THREADS, ext * wpr - 1);
+                    const int ly = idx / wpr, lw = idx - ly * wpr;
+                    v[i] = *reinterpret_cast<const uint32_t*>(occ + (size_t)(ty0 - r + ly) * lv.fpitch + (tx0 - r) + 4 * lw);
                 }
 #pragma unroll
-                for (int i = 0; i < NB; ++i) {
+                for (int i = 0; i < NW; ++i) {
                     const int idx = tid + i * BLUR_THREADS;
-                    if (idx < EXT_C * EXT_C) {
-                        const int ly = idx / EXT_C, lx = idx - ly * EXT_C;
-                        sm.occ[ly][lx] = (uint8_t)(v[i] ^ 1u);
-                        exact |= (int)v[i];
+                    if (idx < ext * wpr) {
+                        const int ly = idx / wpr, lw = idx - ly * wpr;
+                        const uint32_t e = bytes_equal(v[i], stamp);
+                        *reinterpret_cast<uint32_t*>(&sm.occ[ly][4 * lw]) = e ^ 0x01010101u;                 // (RAD > 0: the LDS image holds 1 = free)
+                        exact |= (e != 0u);
                     }
+                }
+            } else {
+                for (int idx = tid; idx < ext * wpr; idx += BLUR_THREADS) {
+                    const int ly = idx / wpr, lw = idx - ly * wpr;
+                    const uint32_t v = bytes_equal(*reinterpret_cast<const uint32_t*>(occ + (size_t)(ty0 - r + ly) * lv.fpitch + (tx0 - r) + 4 * lw), stamp);
+                    *reinterpret_cast<uint32_t*>(&sm.occ[ly][4 * lw]) = v;
+                    exact |= (v != 0u);
+                }
+            }
+        } else if constexpr (RAD > 0) {
+            constexpr int EXT_C = BLUR_TILE + 2 * RAD;
+            constexpr int NB = (EXT_C * EXT_C + BLUR_THREADS - 1) / BLUR_THREADS;
+            uint8_t v[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int idx = min(tid + i * BLUR_THREADS, EXT_C * EXT_C - 1);
+                const int ly = idx / EXT_C, lx = idx - ly * EXT_C;
+                const int gy = reflect_index(ty0 - r + ly, fh), gx = reflect_index(tx0 - r + lx, fw);
+                v[i] = occ[(size_t)gy * lv.fpitch + gx];
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int idx = tid + i * BLUR_THREADS;
+                if (idx < EXT_C * EXT_C) {
+                    const int ly = idx / EXT_C, lx = idx - ly * EXT_C;
+                    const uint8_t o = v[i] == stamp;
+                    sm.occ[ly][lx] = o ^ 1;
+                    exact |= o;
                 }
             }
         } else {
             for (int idx = tid; idx < ext * ext; idx += BLUR_THREADS) {
                 const int ly = idx / ext, lx = idx - ly * ext;
                 const int gy = reflect_index(ty0 - r + ly, fh), gx = reflect_index(tx0 - r + lx, fw);
-                const uint8_t o = (uint8_t)((occ[(size_t)gy * op + (gx >> 5)] >> (gx & 31)) & 1u);
+                const uint8_t o = occ[(size_t)gy * lv.fpitch + gx] == stamp;
                 sm.occ[ly][lx] = o;
                 exact |= o;
             }
@@ -866,14 +817,15 @@ __global__ __launch_bounds__(TRIAGE_THREADS) void k_tile_triage(Slam2dLevel lv, 
     // rows above and below -- and, per tile row, the OR of the 2 + 2 kb flag rows its halo spans: a tile's test is one shift of
     // two words of its row (byte flags and a 4 x 4 window of LDS reads per tile cost three times the kernel's compute)
     const int kb = (lv.blur_radius + 7) >> FLAG_SHIFT;     // blocks the blur radius reaches beyond a tile (<= 2)
-    const int qpr = flag_words(lv), frows = lv.tmax << 1;
-    const int rw = qpr + 1, rw1 = rw + 1;
+    const int fp = flag_pitch(lv), frows = lv.tmax << 1;
+    const int rw = (fp >> 4) + 1, rw1 = rw + 1;
     uint16_t* bits_s = reinterpret_cast<uint16_t*>(tri_lds);                     // [kb + frows + kb][rw]
     uint16_t* rows_s = bits_s + (((frows + 2 * kb) * rw + 1) & ~1);              // [tmax][rw + 1] (a zero word at the end)
     const int fbytes = (2 * ((((frows + 2 * kb) * rw + 1) & ~1) + lv.tmax * rw1) + 15) & ~15;
     uint8_t* state_s = tri_lds + fbytes;
     uint32_t* need_s = reinterpret_cast<uint32_t*>(tri_lds + fbytes + ntile4);
     uint16_t* fill_s = reinterpret_cast<uint16_t*>(need_s + nneed);             // [ntile] the fill list
+    const uint8_t stamp = occ_stamp(lv);
     uint8_t* state = lv.tilestate + (size_t)p * ntile;
     // every global load of the kernel's first half is issued before the first barrier -- flags, states AND the first words of
     // the needed-tile slices: the kernel is a chain of round trips, this makes it one instead of two
@@ -884,12 +836,15 @@ __global__ __launch_bounds__(TRIAGE_THREADS) void k_tile_triage(Slam2dLevel lv, 
 #pragma unroll
     for (int u = 0; u < PRE; ++u) { const int i = tid + u * TRIAGE_THREADS; pre[u] = i < nsl ? sl[i] : 0u; }
     {
-        // the block flags are bits already (occ_field_role: sixteen blocks per word); rows below the frame are stale
-        const uint16_t* __restrict__ tq = lv.tilemask + (size_t)p * flag_count(lv);
-        const int nq = frows * qpr, nsy = (fr.fh + 7) >> FLAG_SHIFT;
+        const uint4* tq = reinterpret_cast<const uint4*>(lv.tilemask + (size_t)p * flag_bytes(lv));     // (rows of fp bytes, fp % 16 == 0)
+        const int qpr = fp >> 4, nq = frows * qpr;
         for (int i = tid; i < nq; i += TRIAGE_THREADS) {
+            const uint4 v = tq[i];
+            // bytes 0 / 1 -> one bit each: the multiplier moves byte k's bit 0 to bit 24 + k (no two partial products meet)
+            const uint32_t m = ((bytes_equal(v.x, stamp) * 0x01020408u) >> 24) | (((bytes_equal(v.y, stamp) * 0x01020408u) >> 24) << 4) |
+                               (((bytes_equal(v.z, stamp) * 0x01020408u) >> 24) << 8) | (((bytes_equal(v.w, stamp) * 0x01020408u) >> 24) << 12);
             const int row = i / qpr;
-            bits_s[(kb + row) * rw + 1 + (i - row * qpr)] = row < nsy ? tq[i] : (uint16_t)0;
+            bits_s[(kb + row) * rw + 1 + (i - row * qpr)] = (uint16_t)m;
         }
         for (int i = tid; i < frows; i += TRIAGE_THREADS) bits_s[(kb + i) * rw] = 0;
         for (int i = tid; i < kb * rw; i += TRIAGE_THREADS) { bits_s[i] = 0; bits_s[(kb + frows) * rw + i] = 0; }
@@ -1244,18 +1199,34 @@ __device__ __forceinline__ void write_priors(const Slam2dLevel& lv, const int p,
     if (threadIdx.x == 0) lv.ring[0] = ring_base <= lv.ring_cap ? ring_base : -1;     // -1: does not fit, sweep in full
 }
 
-// k_frames' per-particle work, done by one thread of the priors-side extra block of k_endpoints when that kernel is not launched:
-// frame, counters, flags (:21-28).  (The field index of the window's columns / rows, :32-37, is the business of occ_field_role.)
+// k_frame_axis's per-particle work, done by one 256-thread block (the priors block of k_endpoints) when that
+// kernel is not launched: frame, flags, axis tables (:21-37,173-176).
 __device__ __forceinline__ void frame_duties(const Slam2dLidar& lid, const Slam2dLevel& lv, const Slam2dMap* __restrict__ maps,
                                              const double* __restrict__ centre, const int cstride, uint32_t* flags, const int p) {
-    if (threadIdx.x != 0) return;
+    const Slam2dMap m = maps[p];
     uint32_t f;
-    const Slam2dFrame fr = make_frame(lid, lv, maps[p], centre[(size_t)p * cstride], centre[(size_t)p * cstride + 1], f);
-    lv.frames[p] = fr;
-    lv.tilecount[2 * p] = 0; lv.tilecount[2 * p + 1] = 0;
-    if (lv.bnb) lv.bnb_best[p] = order_bits(-INFINITY);
-    if (lv.bnb >= 2) lv.seed_key[p] = 0ull;
-    if (f) atomicOr(&flags[p], f);
+    const Slam2dFrame fr = make_frame(lid, lv, m, centre[(size_t)p * cstride], centre[(size_t)p * cstride + 1], f);
+    if (threadIdx.x == 0) {
+        lv.frames[p] = fr;
+        lv.tilecount[2 * p] = 0; lv.tilecount[2 * p + 1] = 0;
+        if (lv.bnb) lv.bnb_best[p] = order_bits(-INFINITY);
+        if (lv.bnb >= 2) lv.seed_key[p] = 0ull;
+        if (f) atomicOr(&flags[p], f);
+    }
+    bool bad = false;
+    for (int axis = 0; axis < 2; ++axis) {
+        const int n = axis == 0 ? fr.mx1 - fr.mx0 : fr.my1 - fr.my0;
+        const double lo = axis == 0 ? fr.xlo : fr.ylo;
+        const int dim = axis == 0 ? fr.fw : fr.fh;
+        for (int j = threadIdx.x; j < n; j += blockDim.x) {
+            const double coord = axis == 0 ? m.X[fr.mx0 + j] : m.Y[fr.my0 + j];
+            int idx = (int)((coord - lo) / lv.step);       // astype(int): truncation toward zero
+            if (idx < 0) idx += dim;                       // Python negative-index wrap (:37)
+            if (idx < 0 || idx >= dim) { idx = -1; bad = true; }
+            (axis == 0 ? lv.axis_x : lv.axis_y)[(size_t)p * lv.wmax + j] = idx;
+        }
+    }
+    if (bad) atomicOr(&flags[p], SLAM2D_F_FIELD_INDEX);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1271,9 +1242,9 @@ template <int NT>
 __global__ __launch_bounds__(NT) void k_endpoints(Slam2dLidar lid, Slam2dLevel lv, const double* __restrict__ est,
                                                    int estride, const double* __restrict__ ranges, uint32_t* flags,
                                                    double est_dist, const double* __restrict__ psi_cs, int mark, int prune,
-                                                   int beam_table, const Slam2dMap* __restrict__ maps, int occf_rpw) {
-    // maps != NULL: this launch is not preceded by k_frames (slam2d_match below 512 beams): the theta blocks derive
-    // the frame fields they need themselves, the priors block also writes frames[p] and the flags.
+                                                   int beam_table, const Slam2dMap* __restrict__ maps, int scatter_bx) {
+    // maps != NULL: this launch is not preceded by k_frame_axis (slam2d_match below 512 beams): the theta blocks derive
+    // the frame fields they need themselves, the priors block also writes frames[p], the axis tables and the flags.
     // np.unique (:120) through an LDS hash set: every beam inserts its cell; of the beams that hit one
     // cell the lowest beam index owns it (atomicMin), so the list keeps beam order -- which is spatially
     // coherent (neighbouring beams hit neighbouring cells) and deterministic.  Scores are exact
@@ -1286,19 +1257,23 @@ __global__ __launch_bounds__(NT) void k_endpoints(Slam2dLidar lid, Slam2dLevel l
     const int grp = blockIdx.x, p = blockIdx.y, tid = threadIdx.x;
     const int G = max(lv.ep_group, 1), ngrp = (lv.ntheta + G - 1) / G;
     if (grp == ngrp) {                                     // the extra block of every particle: motion priors (+ ring)
-        if (maps) frame_duties(lid, lv, maps, est, estride, flags, p);      // (+ what k_frames would have done, by its thread 0)
         write_priors(lv, p, est_dist, psi_cs, prune);
         return;
     }
-    if (grp > ngrp) {                                      // (occf_rpw > 0) the occupied field cells, beside the angle blocks
-        occ_field_role<NT / 64>(lid, lv, maps, est, estride, flags, p, grp - (ngrp + 1), occf_rpw, reinterpret_cast<uint8_t*>(ep_lds));
+    if (grp == ngrp + 1) {                                 // a second one (only when maps != NULL): what k_frame_axis would have done
+        frame_duties(lid, lv, maps, est, estride, flags, p);
+        return;
+    }
+    if (grp > ngrp + 1) {                                  // (scatter_bx > 0) the occupied-cell scatter, beside the angle blocks
+        const int sb = grp - (ngrp + 2);
+        scatter_role<NT / 64>(lid, lv, maps, est, estride, p, sb % scatter_bx, sb / scatter_bx, ep_lds);
         return;
     }
     const int it0 = grp * G, it1 = min(it0 + G, lv.ntheta);
     const double ex = est[(size_t)p * estride], ey = est[(size_t)p * estride + 1];
     Slam2dFrame fr;
     if (maps) {
-        // no k_frames ahead of this launch: the four frame fields used here, in make_frame's very expressions (:22-25)
+        // no k_frame_axis ahead of this launch: the four frame fields used here, in make_frame's very expressions (:22-25)
         fr.xlo = ex - lv.reach; fr.ylo = ey - lv.reach;
         fr.fw = min((int)(((ex + lv.reach) - fr.xlo) / lv.step) + 1, lv.fmax);
         fr.fh = min((int)(((ey + lv.reach) - fr.ylo) / lv.step) + 1, lv.fmax);
@@ -1360,7 +1335,7 @@ __global__ __launch_bounds__(NT) void k_endpoints(Slam2dLidar lid, Slam2dLevel l
             const double rg = ranges[b];
             if (rg < lid.max_range) {                                               // :84
                 double px, py;
-                if (beam_table) {                           // k_frames evaluated :87-88 once for the particle
+                if (beam_table) {                           // k_frame_axis evaluated :87-88 once for the particle
                     px = lv.beam_xy[((size_t)p * B + b) * 2]; py = lv.beam_xy[((size_t)p * B + b) * 2 + 1];
                 } else {
                     const double a = (b == B - 1) ? a1 : (double)b * astep + a0;
@@ -2244,7 +2219,7 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
 // the 4 poses (4 by + r, 4 bx .. 4 bx + 3) against cells k0 + s, k0 + s + kstep, ...; on return every lane of a
 // row group holds the row's 4 sums over ALL the cells this wave walked (reduced over the 16 slices).
 #define EXACT_DEPTH 8
-#define SLAM2D_BEAM_TABLE_MIN 512   // beams from which k_frames (with its per-particle beam-endpoint table) is worth its launch
+#define SLAM2D_BEAM_TABLE_MIN 512   // beams from which k_frame_axis (with its per-particle beam-endpoint table) is worth its launch
 // byte offsets of the first NPRE cells of lane slice s (cells s, s + 16, ...), beyond-the-buffer where the list ends
 template <int NPRE>
 __device__ __forceinline__ void tile_prefetch(const int* __restrict__ cl, const int K, int (&pre)[NPRE]) {
@@ -3602,10 +3577,10 @@ static int check_level(const Slam2dLidar* lidar, const Slam2dLevel* lv, int P) {
 
 // ---- launch sequences shared by slam2d_field_build / slam2d_sweep / slam2d_match ----
 static int check_field_args(const Slam2dLevel& lv, int P, bool lazy) {
-    if (!lv.occ || !lv.tilemask || !lv.tilestate || !lv.tilemin || !lv.tilemax || !lv.tilelist || !lv.tilecount)
+    // (occ and tilemask are cleared by ONE memset when occ_gen == 0; with generation stamps nothing is cleared and a level may
+    // be an offset view of a larger one -- slam2d_groups_* -- whose flags do not follow its image)
+    if (!lv.occ || !lv.tilemask || (lv.occ_gen == 0 && lv.tilemask != lv.occ + (size_t)P * lv.fmax * lv.fpitch) || !lv.tilestate || !lv.tilemin || !lv.tilemax || !lv.tilelist || !lv.tilecount)
         return SLAM2D_E_BADARG;
-    // occ_field_role: a window row and a field row are at most 64 words (one per lane), indices fit 16 bits
-    if (lv.wmax > 1984 || lv.fpitch > 2048) return SLAM2D_E_TOOLARGE;
     if (lazy && !lv.tileneed) return SLAM2D_E_BADARG;
     if (lv.tmax * lv.tmax > 28000) return SLAM2D_E_TOOLARGE;        // k_tile_triage: 32 passes, 5 bytes of LDS per tile (144 KB)
     if (lv.bnb == 3) {                                 // angle bounds: small cubes only, windows of <= 5 x 5 cells
@@ -3624,23 +3599,23 @@ static int check_field_args(const Slam2dLevel& lv, int P, bool lazy) {
     return 0;
 }
 
-// frame geometry of every particle (+ the beam endpoints of the estimate)
+// frame geometry, axis index vectors, cleared occupancy image / tile flags (/ needed-tile bitmap)
 static int launch_frames(const Slam2dLidar& lid, const Slam2dLevel& lv, const Slam2dMap* d_maps, int P,
                          const double* d_centre, int centre_stride, uint32_t* d_flags, bool lazy, hipStream_t s,
                          const double* d_ranges = nullptr) {
     if (d_ranges && (!lv.beam_xy || centre_stride < 3)) d_ranges = nullptr;
-    k_frames<<<dim3(d_ranges ? cdiv(lid.beams, 256) : 1, P), d_ranges ? 256 : 64, 0, s>>>(lid, lv, d_maps, d_centre, centre_stride, d_flags, d_ranges);
-    return 0;
+    k_frame_axis<<<dim3(cdiv(lv.wmax, 256), P, 2), 256, 0, s>>>(lid, lv, d_maps, d_centre, centre_stride, d_flags, d_ranges);
+    if (lv.occ_gen < 0 || lv.occ_gen > 255) return SLAM2D_E_BADARG;
+    if (lv.occ_gen != 0) return 0;                     // generation stamps: nothing to clear
+    return (int)hipMemsetAsync(lv.occ, 0, (size_t)P * lv.fmax * lv.fpitch + (size_t)P * flag_bytes(lv), s);
 }
 
-// occupied map cells -> field bits + block flags, tile triage (+ fill), blur + clamp, minimum check
-static int launch_field(const Slam2dLidar& lid, const Slam2dLevel& lv, const Slam2dMap* d_maps, int P, const double* d_centre,
-                        int centre_stride, uint32_t* d_flags, bool lazy, hipStream_t s, bool occ_done = false,
-                        bool field_max_needed = true) {
-    if (!occ_done) {
+// occupied cells -> field image, tile triage (+ fill), blur + clamp, minimum check
+static int launch_field(const Slam2dLevel& lv, const Slam2dMap* d_maps, int P, uint32_t* d_flags, bool lazy, hipStream_t s,
+                        bool scattered = false, bool field_max_needed = true) {
+    if (!scattered) {
         StageScope prof(SLAM2D_STAGE_SCATTER, s);
-        const int rpw = occ_field_rpw(lid, lv);
-        k_occ_field<<<dim3(cdiv(lv.fmax, 4 * rpw), P), 256, (size_t)occ_field_lds(lv, 4).total, s>>>(lid, lv, d_maps, d_centre, centre_stride, d_flags, rpw);
+        k_occ_scatter<<<dim3(cdiv(cdiv(lv.wmax, 32) + 1, 64), cdiv(lv.wmax, SCATTER_ROWS), P), dim3(64, 4), (size_t)lv.wmax * sizeof(int32_t), s>>>(lv, d_maps);
     }
     const int ntile = lv.tmax * lv.tmax;
     // Without bounds (no gmin2 to derive), without the sweep's free-tile masks and without the prior pruning (which reads the
@@ -3651,7 +3626,7 @@ static int launch_field(const Slam2dLidar& lid, const Slam2dLevel& lv, const Sla
     const bool folded = fold && lazy && !lv.bnb && !sweep_skips(lv) && !field_max_needed && lv.sync != nullptr;
     {
         const int kb = (lv.blur_radius + 7) >> FLAG_SHIFT;
-        const int rw = flag_words(lv) + 1;
+        const int rw = (flag_pitch(lv) >> 4) + 1;
         const size_t lds = (size_t)((2 * ((((2 * lv.tmax + 2 * kb) * rw + 1) & ~1) + lv.tmax * (rw + 1)) + 15) & ~15) + ((ntile + 3) & ~3) + 4 * ((ntile + 31) / 32) + 2 * (size_t)ntile;
         // more than the default dynamic LDS limit: ask once per device (160 KB per CU on gfx950); a device that does not grant it
         // gets a clean error instead of a failed launch
@@ -3703,7 +3678,7 @@ static int launch_field(const Slam2dLidar& lid, const Slam2dLevel& lv, const Sla
 static void launch_endpoints(const Slam2dLidar& lid, const Slam2dLevel& lv, int P, const double* d_est, int est_stride,
                              const double* d_ranges, double est_moving_dist, const double* d_psi_cs, uint32_t* d_flags,
                              bool mark, bool prune, hipStream_t s, bool beam_table = false,
-                             const Slam2dMap* own_frame_maps = nullptr, bool with_occ = false) {
+                             const Slam2dMap* own_frame_maps = nullptr, bool with_scatter = false) {
     StageScope prof(SLAM2D_STAGE_ENDPOINTS, s);
     int n = 256;
     while (n < lid.beams) n <<= 1;
@@ -3716,17 +3691,16 @@ static void launch_endpoints(const Slam2dLidar& lid, const Slam2dLevel& lv, int 
     // k_endpoints, mark == 2: 13 % fewer needed tiles, 6 % fewer blurred ones at config 2, the same surviving pose tiles;
     // SLAM2D_TIGHT_NEED=0 restores the wide marking)
     static const int markv = [] { const char* e = getenv("SLAM2D_TIGHT_NEED"); return e && atoi(e) == 0 ? 1 : 2; }();
-    // with_occ (needs own_frame_maps): the occupied field cells (occ_field_role) as further blocks of this launch
-    const int rpw = with_occ ? occ_field_rpw(lid, lv) : 0;
-    const int oblocks = with_occ ? cdiv(lv.fmax, (nt / 64) * rpw) : 0;
-    if (with_occ) ep_lds = ep_lds > (size_t)occ_field_lds(lv, nt / 64).total ? ep_lds : (size_t)occ_field_lds(lv, nt / 64).total;
-    const dim3 grid(cdiv(lv.ntheta, G) + 1 + oblocks, P);
+    // with_scatter (needs own_frame_maps): the occupied-cell scatter as further blocks of this launch
+    const int sbx = with_scatter ? cdiv(cdiv(lv.wmax, 32) + 1, 64) : 0, sby = with_scatter ? cdiv(lv.wmax, (nt / 64) * SCATTER_ROLE_NR) : 0;
+    if (with_scatter) ep_lds = ep_lds > (size_t)lv.wmax * sizeof(int32_t) ? ep_lds : (size_t)lv.wmax * sizeof(int32_t);
+    const dim3 grid(cdiv(lv.ntheta, G) + (own_frame_maps ? 2 : 1) + sbx * sby, P);
     if (nt == 192)
         k_endpoints<192><<<grid, 192, ep_lds, s>>>(lid, lv, d_est, est_stride, d_ranges, d_flags, est_moving_dist, lv.fine ? nullptr : d_psi_cs,
-                                                   mark ? markv : 0, prune ? 1 : 0, beam_table && lv.beam_xy ? 1 : 0, own_frame_maps, rpw);
+                                                   mark ? markv : 0, prune ? 1 : 0, beam_table && lv.beam_xy ? 1 : 0, own_frame_maps, sbx);
     else
         k_endpoints<256><<<grid, 256, ep_lds, s>>>(lid, lv, d_est, est_stride, d_ranges, d_flags, est_moving_dist, lv.fine ? nullptr : d_psi_cs,
-                                                   mark ? markv : 0, prune ? 1 : 0, beam_table && lv.beam_xy ? 1 : 0, own_frame_maps, rpw);
+                                                   mark ? markv : 0, prune ? 1 : 0, beam_table && lv.beam_xy ? 1 : 0, own_frame_maps, sbx);
 }
 
 // cube sweep + selection
@@ -3836,7 +3810,7 @@ int slam2d_field_build(const Slam2dLidar* lidar, const Slam2dLevel* level, const
     Slam2dLevel lv = *level;
     lv.bnb = 0;                                        // the full build has no pooled image
     if ((rc = launch_frames(*lidar, lv, d_maps, P, d_centre, centre_stride, d_flags, false, s))) return rc;
-    if ((rc = launch_field(*lidar, lv, d_maps, P, d_centre, centre_stride, d_flags, false, s))) return rc;
+    if ((rc = launch_field(lv, d_maps, P, d_flags, false, s))) return rc;
     return launch_status();
 }
 
@@ -3872,19 +3846,20 @@ int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2
         const int nx = 2 * lv.ncell + 1, nslot = nx * ((nx + 3) / 4);
         if (bound > 0 && 2 * bound <= nslot) ring_chunks = cdiv(bound, WAVE);     // worth it only for a thin ring
     }
-    // Below SLAM2D_BEAM_TABLE_MIN beams k_frames is not launched at all: the endpoint kernel's per-particle block does
-    // its work (one launch less per level); above, k_frames also tabulates the beam endpoints once per particle.
+    // Below SLAM2D_BEAM_TABLE_MIN beams k_frame_axis is not launched at all: the endpoint kernel's per-particle block does
+    // its work (one launch less per level); above, k_frame_axis also tabulates the beam endpoints once per particle.
     static const bool keep_frame_kernel = [] { const char* e = getenv("SLAM2D_FRAME_KERNEL"); return e && atoi(e) == 1; }();
-    const bool framed = lidar->beams >= SLAM2D_BEAM_TABLE_MIN || keep_frame_kernel;
+    const bool framed = lidar->beams >= SLAM2D_BEAM_TABLE_MIN || keep_frame_kernel || lv.occ_gen == 0;
     const Slam2dMap* own = framed ? nullptr : d_maps;
-    // ... and then the occupied field cells ride in the endpoint launch as well (SLAM2D_MERGE_SCATTER=0: their own launch)
+    // ... and then the occupied-cell scatter rides in the endpoint launch as well (SLAM2D_MERGE_SCATTER=0: its own launch)
     static const bool merge_scatter = [] { const char* e = getenv("SLAM2D_MERGE_SCATTER"); return !e || atoi(e) != 0; }();
     const bool merged = own && merge_scatter;
+    if (lv.occ_gen < 0 || lv.occ_gen > 255) return SLAM2D_E_BADARG;
     if (lv.bnb && lv.bnb != 3) {
         // branch and bound over 4x4 pose tiles: tile bounds + seed tiles, surviving tiles + selection
         if (framed && (rc = launch_frames(*lidar, lv, d_maps, P, d_est, est_stride, d_flags, true, s, d_ranges))) return rc;
         launch_endpoints(*lidar, lv, P, d_est, est_stride, d_ranges, est_moving_dist, d_psi_cs, d_flags, true, false, s, framed, own, merged);
-        if ((rc = launch_field(*lidar, lv, d_maps, P, d_est, est_stride, d_flags, true, s, merged))) return rc;
+        if ((rc = launch_field(lv, d_maps, P, d_flags, true, s, merged))) return rc;
         const unsigned grid = (unsigned)cdiv(P, 8) * 8 * lv.ntheta;
         if (lv.bnb == 2) {
             StageScope prof(SLAM2D_STAGE_BOUND, s);
@@ -3906,7 +3881,7 @@ int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2
     // the endpoints need only the frame, so they run first and tell the field build which tiles matter
     if (framed && (rc = launch_frames(*lidar, lv, d_maps, P, d_est, est_stride, d_flags, true, s, d_ranges))) return rc;
     launch_endpoints(*lidar, lv, P, d_est, est_stride, d_ranges, est_moving_dist, d_psi_cs, d_flags, true, ring_chunks > 0, s, framed, own, merged);
-    if ((rc = launch_field(*lidar, lv, d_maps, P, d_est, est_stride, d_flags, true, s, merged, ring_chunks > 0))) return rc;      // (the ring pass reads the field's maximum)
+    if ((rc = launch_field(lv, d_maps, P, d_flags, true, s, merged, ring_chunks > 0))) return rc;      // (the ring pass reads the field's maximum)
     if ((rc = launch_scores(lv, P, d_est, est_stride, d_uniform, d_out, s, ring_chunks))) return rc;
     return launch_status();
 }

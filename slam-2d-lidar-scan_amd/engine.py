@@ -626,10 +626,10 @@ class SearchLevel:
             cos=_dev(np.array([np.cos(a) for a in self.thetas]), device),
             sin=_dev(np.array([np.sin(a) for a in self.thetas]), device),
             frames=torch.zeros((P, C.sizeof(Slam2dFrame)), dtype=torch.uint8, device=device),
-            # occupied field cells of every particle as bits (include/slam2d.h: Slam2dLevel.occ) and the flags of its 8 x 8-cell
-            # blocks, sixteen per word (Slam2dLevel.tilemask); every build rewrites them, nothing is cleared
-            occ=torch.zeros((P, self.fmax, (self.fpitch + 31) // 32 + 1), dtype=i32, device=device),
-            tilemask=torch.zeros((P, 2 * self.tmax, ((2 * self.tmax + 17) & ~15) // 16), dtype=torch.int16, device=device),
+            axis_x=torch.zeros((P, self.wmax), dtype=i32, device=device),
+            axis_y=torch.zeros((P, self.wmax), dtype=i32, device=device),
+            # occupied-cell image of every particle, followed by the flags of its 8 x 8-cell blocks (generation-stamped bytes)
+            occ=torch.zeros(P * self.fmax * self.fpitch + P * 2 * self.tmax * ((2 * self.tmax + 17) & ~15), dtype=torch.uint8, device=device),
             field=torch.zeros((P, self.fmax, self.fpitch), dtype=i32, device=device),     # uint32 costs
             cells=torch.zeros((P, self.ntheta, self.kmax), dtype=i32, device=device),
             kcount=torch.zeros((P, self.ntheta), dtype=i32, device=device),
@@ -679,10 +679,11 @@ class SearchLevel:
             blur_w=t["blur_w"].data_ptr(), ncell=self.ncell, ntheta=self.ntheta, fine=int(self.fine),
             kmax=self.kmax, thetas=t["thetas"].data_ptr(), theta_cos=t["cos"].data_ptr(),
             theta_sin=t["sin"].data_ptr(), rv_coef=self.rv_coef, tw_coef=self.tw_coef,
-            max_move_dev=max_move_dev, frames=t["frames"].data_ptr(), occ=t["occ"].data_ptr(), field=t["field"].data_ptr(),
+            max_move_dev=max_move_dev, frames=t["frames"].data_ptr(), axis_x=t["axis_x"].data_ptr(),
+            axis_y=t["axis_y"].data_ptr(), occ=t["occ"].data_ptr(), field=t["field"].data_ptr(),
             cells=t["cells"].data_ptr(), kcount=t["kcount"].data_ptr(), prior=t["prior"].data_ptr(),
             cube=t["cube"].data_ptr(), partials=t["partials"].data_ptr(), npartial=self.npartial, tmax=self.tmax,
-            tilemask=t["tilemask"].data_ptr(), tilestate=t["tilestate"].data_ptr(),
+            tilemask=t["occ"].data_ptr() + P * self.fmax * self.fpitch, tilestate=t["tilestate"].data_ptr(),
             tilemin=t["tilemin"].data_ptr(), tilemax=t["tilemax"].data_ptr(), tilelist=t["tilelist"].data_ptr(),
             tilecount=t["tilecount"].data_ptr(),
             tileneed=t["tileneed"].data_ptr(), freerow=t["freerow"].data_ptr(), ring=t["ring"].data_ptr(), prune_state=t["prune_state"].data_ptr(),
@@ -692,23 +693,41 @@ class SearchLevel:
             **({k: t[k].data_ptr() for k in ("gmin", "gmin2", "pcells", "bounds", "bnb_best", "seed_key")} if self.abound else {}),
             **({k: t[k].data_ptr() for k in ("gmin", "gmin2", "pcells", "bounds", "tile_pmax", "bnb_best")} if self.bnb else {}))
 
-    _PER_PARTICLE = ("frames", "occ", "tilemask", "field", "cells", "kcount", "prior", "cube", "partials", "tilestate", "tilemin",
+    _PER_PARTICLE = ("frames", "axis_x", "axis_y", "field", "cells", "kcount", "prior", "cube", "partials", "tilestate", "tilemin",
                      "tilemax", "tilelist", "tilecount", "tileneed", "freerow", "prune_state", "beam_xy", "sync", "gmin", "gmin2",
                      "pcells", "bounds", "tile_pmax", "bnb_best", "gmin3d", "p3cells", "bounds1", "seed_key")
 
     def view(self, p0, p1):
         """A Slam2dLevel describing particles [p0, p1) of this level: the same parameters, every per-particle pointer advanced to
         particle p0 (the C ABI takes base pointers, so a group of particles is an offset view of every array; include/slam2d.h,
-        slam2d_groups_*).  The ring of the prior pruning is written per call and therefore the view's own."""
+        slam2d_groups_*).  The ring of the prior pruning is written per call and therefore the view's own.  The view's
+        generation stamp follows the parent's: call ``sync_view(view)`` after ``next_generation()``."""
         v = Slam2dLevel.from_buffer_copy(self.c)
         for k in self._PER_PARTICLE:
             tz = self.t.get(k)
             if tz is not None and getattr(self.c, k):
                 setattr(v, k, tz.data_ptr() + p0 * tz.stride(0) * tz.element_size())
+        img = self.fmax * self.fpitch
+        fb = 2 * self.tmax * ((2 * self.tmax + 17) & ~15)
+        v.occ = self.t["occ"].data_ptr() + p0 * img
+        v.tilemask = self.t["occ"].data_ptr() + self.P * img + p0 * fb
         ring = torch.zeros_like(self.t["ring"])
         self._view_rings = getattr(self, "_view_rings", []) + [ring]
         v.ring = ring.data_ptr()
         return v
+
+    def sync_view(self, v):
+        v.occ_gen = self.c.occ_gen
+
+    def next_generation(self):
+        """Advance the occupancy-image generation stamp (Slam2dLevel.occ_gen) for the next build: the
+        image is zeroed once per 254 builds instead of at every build."""
+        g = self.c.occ_gen + 1
+        if g > 254:
+            with _on_launch_stream():
+                self.t["occ"].zero_()
+            g = 1
+        self.c.occ_gen = g
 
     # -- results --
     def frames(self):
@@ -865,6 +884,7 @@ class ParticleEngine:
     # -- kernels --
     def field_build(self, level, d_centre, stride):
         self.refresh_bits()
+        level.next_generation()
         check(self.L.slam2d_field_build(C.byref(self.lidar_c), C.byref(level.c), _ptr(self.d_maps), self.P,
                                         _ptr(d_centre), stride, _ptr(self.flags), _stream()), "slam2d_field_build")
 
@@ -879,6 +899,7 @@ class ParticleEngine:
         inside the motion prior's ring first and skip the rest when they cannot matter
         (SLAM2D_MATCH_PRUNE_BY_PRIOR; coarse level only; level.cube() then holds only the ring)."""
         self.refresh_bits()
+        level.next_generation()
         check(self.L.slam2d_match(C.byref(self.lidar_c), C.byref(level.c), _ptr(self.d_maps), self.P, _ptr(d_est),
                                   stride, _ptr(d_ranges), float(est_moving_dist), _ptr(d_psi_cs), _ptr(d_uniform),
                                   _ptr(d_out), _ptr(self.flags), _lib.MATCH_PRUNE_BY_PRIOR if prune else 0, _stream()),

@@ -553,6 +553,9 @@ class ParticleFilter:
         d_in = grp.d_in[parity]
         flags = grp.flags2[parity]
         sm = C.sizeof(_lib.Slam2dMap)
+        for lv, views in ((self.coarse, grp.coarse), (self.fine, grp.fine)):
+            for v in views:
+                lv.sync_view(v)
         for g in range(self.n_groups):
             cg, p0 = grp.c[g], g * per
             cg.d_maps = eng.d_maps.data_ptr() + p0 * sm
@@ -588,6 +591,10 @@ class ParticleFilter:
     def _enqueue_match_groups(self, reading, prev_raw, dist, has_turn, turn, parity):
         eng, grp, L = self.engine, self._grp, _lib.lib()
         eng.refresh_bits()
+        for lv in (self.coarse, self.fine):
+            if lv.c.occ_gen >= 254:                      # the stamp wraps: the occupancy images are zeroed -- with every stream idle
+                torch.cuda.synchronize(self.device)
+            lv.next_generation()
         self._bind_groups(parity)
         L.slam2d_event_record(grp.ev_inputs, _stream())  # behind the staging copy (and a bit refresh) on the main stream
         sc = grp.scan
@@ -621,6 +628,8 @@ class ParticleFilter:
         maps, changes no filter state.  prior_ready: the previous commit wrote this scan's prior already (_enqueue_commit)."""
         eng, P = self.engine, self.numParticles
         eng.refresh_bits()
+        self.coarse.next_generation()
+        self.fine.next_generation()
         _lib.check(_lib.lib().slam2d_scan_match(
             C.byref(eng.lidar_c), C.byref(self.coarse.c), C.byref(self.fine.c), _ptr(eng.d_maps), P, _ptr(self.d_pose),
             float(reading['theta']), float(prev_raw['theta']), has_turn, float(turn), _ptr(self.d_head), _ptr(self.d_ranges),

@@ -300,3 +300,49 @@ def test_shared_workspace_guard():
         with matcher._Exclusive(a):
             raise RuntimeError("inside")
     assert not a._busy
+
+
+def test_division_free_truncation_matches_the_division():
+    """csrc/slam2d.hip `trunc_div_fast` (the scatter role's column / row index of a window cell,
+    Utils/ScanMatcher_OGBased.py:32-36): where the quotient sits on an integer n -- every column of a window whose pose lies
+    on the map's lattice -- (int)(v / step) is decided from the exact remainder r = v - n * step and the spacing of the
+    doubles below n instead of the fp64 division.  The same decision restated here (the remainder in exact rationals,
+    which is what the device's single fma returns) must equal NumPy's division on quotients a few ulp either side of an
+    integer, powers of two included."""
+    from fractions import Fraction
+
+    def fast(v, step):
+        t = v * (1.0 / step)
+        n = float(np.rint(t))
+        if abs(t - n) >= 1e-6 and abs(t) < 1e9:
+            return int(t)
+        if not (1.0 <= n < 2.0 ** 31):
+            return int(np.float64(v) / np.float64(step))
+        r_exact = Fraction(v) - Fraction(n) * Fraction(step)
+        r = float(r_exact)
+        assert Fraction(r) == r_exact                      # representable: one fma returns it unrounded
+        ni = int(n)
+        e, pow2 = ni.bit_length() - 1, (ni & (ni - 1)) == 0
+        ghalf = 2.0 ** (e - 53 - pow2)
+        return ni if r >= -ghalf * step else ni - 1
+
+    rs = np.random.RandomState(0)
+    steps = [0.02, 0.05, 0.1, 0.25, 0.02 * 5, 0.05 * 2, 0.3, 1 / 3, 0.07]
+    checked = 0
+    for _ in range(60000):
+        step = steps[rs.randint(len(steps))]
+        n = int([rs.randint(0, 4), rs.randint(1, 2100), 2 ** rs.randint(0, 12), 2 ** rs.randint(1, 12) + rs.randint(-1, 2)][rs.randint(4)])
+        v = np.float64(n * step)
+        k = rs.randint(-6, 7)
+        for _ in range(abs(k)):
+            v = np.nextafter(v, np.inf if k > 0 else -np.inf)
+        if rs.rand() < 0.2:
+            v = np.float64(n * step + rs.uniform(-1e-7, 1e-7) * step)
+        if rs.rand() < 0.1:
+            v = np.float64(rs.uniform(0, 200))
+        v = float(v)
+        if v < 0:
+            continue
+        assert fast(v, step) == int(np.float64(v) / np.float64(step)), (v, step, n)
+        checked += 1
+    assert checked > 50000

@@ -26,7 +26,6 @@ print("k_blur_clamp (one tile): halo -> LDS %.2f us, axis-0 pass %.2f, axis-1 pa
 print("k_tile_triage (particle 0): prologue + loads issued + LDS stores %.2f us, barrier %.2f, slices OR %.2f, classify %.2f, barrier-or %.2f, lists + fills %.2f, barrier + counts %.2f; total %.2f" % (
     us(20, 21), us(21, 22), us(22, 23), us(23, 24), us(24, 25), us(25, 26), us(26, 27), us(20, 27)))
 print("k_endpoints (theta 0, particle 0): cells %.2f us, hash + tile marking %.2f, global marks + compaction %.2f" % (us(40, 41), us(41, 42), us(42, 43)))
-print("occ_field_role (particle 0, block 1, wave 0): forward tables %.2f us, runs + wave bounds %.2f, shift tables %.2f, first batch of rows loaded %.2f, rows out %.2f; total %.2f" % (us(14, 15), us(15, 16), us(16, 17), us(17, 18), us(18, 19), us(14, 19)))
 print("k_bound: prologue->loop end %.2f us, bounds+argmax %.2f, seed tile %.2f, atomic %.2f" % (us(0, 1), us(1, 2), us(2, 3), us(3, 4)))
 print("k_exact_select: scan %.2f us, list %.2f, tiles %.2f, max %.2f, exp %.2f, theta sums %.2f, select %.2f; total %.2f" % (
     us(8, 9), us(9, 10), us(10, 11), us(11, 29), us(29, 30), us(30, 12), us(12, 13), us(8, 13)))
