@@ -1350,7 +1350,8 @@ def main():
                                       ("single GPU, two particle groups on two HIP streams + one for the normaliser's merge" if isinstance(hot, HotPathGroups) else "single GPU")},
             "scans_per_sec": K / elapsed,
             "timed_blocks": {"repeats": R, "steps_each": K, "ms_per_step_of_each": [round(1e3 * b / K, 5) for b in blocks], "reported": "median",
-                             "host_enqueue_ms_per_step": round(1e3 * statistics.median(enq) / K, 5)},
+                             "host_enqueue_ms_per_step": round(1e3 * statistics.median(enq) / K, 5),
+                             "host_issue": hot.E._lib.group_policy()},      # cores / local ranks -> worker threads or not (include/slam2d.h: slam2d_group_policy)
             "roofline": rf_main,
             "stages_probe": {k: {"avg_us": round(v["avg_us"], 2), "launches": v["launches"]} for k, v in probe_ms.items()},
             "algorithmic_bytes_per_particle_scan": hot.algorithmic_bytes(scen),
@@ -1364,6 +1365,18 @@ def main():
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
+    if os.environ.get("SLAM2D_BENCH_THREAD_CPU") == "1":      # which host threads of this rank burned CPU (a diagnosis aid for core quotas)
+        rows = []
+        for t in os.listdir("/proc/self/task"):
+            try:
+                f = open(f"/proc/self/task/{t}/stat").read()
+                name = f[f.index("(") + 1:f.rindex(")")]
+                rest = f[f.rindex(")") + 2:].split()
+                rows.append((int(rest[11]) + int(rest[12]), name, t))          # utime + stime, clock ticks
+            except (OSError, ValueError):
+                pass
+        rows.sort(reverse=True)
+        print(f"[rank {rank}] thread cpu ticks: " + ", ".join(f"{n}:{c}" for c, n, _ in rows[:8]), file=sys.stderr, flush=True)
     if getattr(main, "hung_probe", False):
         os._exit(0)                                    # (a stuck helper thread must not keep the process)
     if dist.is_initialized():

@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define SLAM2D_ABI_VERSION 13
+#define SLAM2D_ABI_VERSION 14
 #define SLAM2D_SPOKE_BAND 16         /* radial band width of the beam-major spoke table, in cells */
 
 /* library error codes (negative; positive values are hipError_t) */
@@ -509,6 +509,13 @@ int slam2d_groups_match(const Slam2dLidar* lidar, const Slam2dGroup* groups, int
 int slam2d_groups_commit(const Slam2dLidar* lidar, const Slam2dGroup* groups, int32_t G, const Slam2dScan* scan);
 /* both, group by group (a group's update is enqueued right behind its match): the open-loop step of bench.py */
 int slam2d_groups_step(const Slam2dLidar* lidar, const Slam2dGroup* groups, int32_t G, const Slam2dScan* scan);
+/* How these three calls issue their groups on this host (decided at the first call; one call runs at a time, a second caller
+ * waits).  out4[0] = host cores this process may use (scheduler affinity capped by the cgroup CPU quota), out4[1] = processes
+ * assumed to share them (SLAM2D_LOCAL_RANKS, else torchrun's LOCAL_WORLD_SIZE, else 1), out4[2] = 1: one worker thread per group
+ * beyond the first issues that group's launches (needs >= 3 cores per process: a worker and the waiting caller both poll;
+ * otherwise all groups are issued from the calling thread), out4[3] = 1: the threads poll briefly and yield (< 6 cores per
+ * process).  SLAM2D_GROUP_THREADS=0 / 1 forces out4[2]. */
+int slam2d_group_policy(int32_t* out4);
 
 /* ParticleFilter.resample's state movement (Algorithm/FastSlam.py:56-61) for maps of
  * identical shape: dst[p] = src[d_index[p]].  Ragged maps are copied by the host with

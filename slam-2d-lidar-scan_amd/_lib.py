@@ -40,7 +40,7 @@ MAX_BLUR_RADIUS = 16
 MAX_BEAMS = 2048
 SPOKE_BAND = 16
 SYNC_WORDS = 4
-ABI_VERSION = 13
+ABI_VERSION = 14
 MATCH_PRUNE_BY_PRIOR = 1
 MATCH_PRIOR_READY = 2
 PRUNE_MARGIN = 40.0
@@ -159,6 +159,7 @@ SIGNATURES = {
     "slam2d_groups_match": (C.c_int, [C.POINTER(Slam2dLidar), C.POINTER(Slam2dGroup), C.c_int32, C.POINTER(Slam2dScan)]),
     "slam2d_groups_commit": (C.c_int, [C.POINTER(Slam2dLidar), C.POINTER(Slam2dGroup), C.c_int32, C.POINTER(Slam2dScan)]),
     "slam2d_groups_step": (C.c_int, [C.POINTER(Slam2dLidar), C.POINTER(Slam2dGroup), C.c_int32, C.POINTER(Slam2dScan)]),
+    "slam2d_group_policy": (C.c_int, [C.POINTER(C.c_int32)]),
     "slam2d_weights_local": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _vp, _vp]),
     "slam2d_weights_merge": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, C.c_int64, _vp, _vp, _vp]),
     "slam2d_gather_maps": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int64, _vp]),
@@ -240,3 +241,12 @@ def check(rc, what):
 
 def describe_flags(bits):
     return "; ".join(msg for bit, msg in FLAG_NAMES.items() if bits & bit) or "none"
+
+
+def group_policy():
+    """How slam2d_groups_* issue their groups on this host (include/slam2d.h: slam2d_group_policy): dict of the host cores this
+    process may use, the local ranks assumed to share them, whether a worker thread per group is used and whether the threads wait
+    politely.  Decided once per process, at the first call of this function or of a grouped step."""
+    out = (C.c_int32 * 4)()
+    check(lib().slam2d_group_policy(out), "slam2d_group_policy")
+    return dict(cores=out[0], local_ranks=out[1], threads=bool(out[2]), polite=bool(out[3]))

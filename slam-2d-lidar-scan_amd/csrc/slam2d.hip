@@ -19,6 +19,8 @@
 #include <condition_variable>
 #include <mutex>
 #include <thread>
+#include <sched.h>
+#include <stdio.h>
 
 #include "slam2d.h"
 
@@ -4080,6 +4082,52 @@ static int run_group_job(int kind, const Slam2dLidar* lidar, const Slam2dGroup* 
     if (!rc && (kind & JOB_COMMIT)) rc = group_commit(lidar, groups, G, i, sc);
     return rc;
 }
+// Host cores this process may really use: the scheduler affinity capped by the cgroup CPU quota (v2 cpu.max, v1 cfs quota) --
+// what bench.effective_cores() reports.  A container often sees every core of the host and may use a few.
+static int effective_cores() {
+    int n = (int)std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c >= 1 && c < n) n = c; }
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64] = {0}; double period = 0.0;
+        if (fscanf(f, "%63s %lf", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0.0) { const int c = (int)(atof(q) / period); if (c < n) n = c < 1 ? 1 : c; }
+        fclose(f);
+    } else if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        long quota = -1, period = 0;
+        if (fscanf(g, "%ld", &quota) != 1) quota = -1;
+        fclose(g);
+        if (FILE* h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%ld", &period) != 1) period = 0; fclose(h); }
+        if (quota > 0 && period > 0) { const int c = (int)(quota / period); if (c < n) n = c < 1 ? 1 : c; }
+    }
+    return n;
+}
+// How the groups of a slam2d_groups_* call are issued on this host (decided once).  One worker thread per group beyond the first
+// halves the issue time of a scan -- when the threads have cores to run on: a worker polls for ~1-2 ms before it sleeps and the
+// caller polls for its workers, i.e. TWO spinning threads per process, and a node runs one process per GPU.  With fewer than 3
+// cores per local rank (8 ranks on a 16-core quota: the driver's box) the spinners would take the cores of Python, the HIP
+// runtime's signal threads and RCCL's proxy threads: the groups are then issued from the calling thread.  In between (< 6) the
+// threads stay but wait politely (short polls, sched_yield).
+//   SLAM2D_GROUP_THREADS = 0 / 1 forces the choice; SLAM2D_LOCAL_RANKS (default: LOCAL_WORLD_SIZE, torchrun's, else 1) says how
+//   many such processes share the host.
+struct GroupPolicy { bool threads; bool polite; int cores, ranks; };
+static const GroupPolicy& group_policy() {
+    static const GroupPolicy pol = [] {
+        GroupPolicy g;
+        g.cores = effective_cores();
+        const char* r = getenv("SLAM2D_LOCAL_RANKS");
+        if (!r || atoi(r) < 1) r = getenv("LOCAL_WORLD_SIZE");
+        g.ranks = r && atoi(r) >= 1 ? atoi(r) : 1;
+        const int per = g.cores / g.ranks;
+        g.threads = per >= 3;
+        g.polite = per < 6;
+        if (const char* e = getenv("SLAM2D_GROUP_THREADS")) g.threads = atoi(e) != 0;
+        return g;
+    }();
+    return pol;
+}
+
 struct GroupWorker {
     std::atomic<int> state{0};           // 0 idle, 1 job posted, 2 done
     std::atomic<bool> sleeping{false};
@@ -4091,10 +4139,11 @@ struct GroupWorker {
     const Slam2dScan* sc = nullptr;
     void loop() {
         int cur_dev = -1;
+        const int poll = group_policy().polite ? 2000 : 200000;              // ~1-2 ms of polling (polite: ~15 us), then sleep
         for (;;) {
             int spins = 0;
             while (state.load(std::memory_order_acquire) != 1) {
-                if (++spins < 200000) { __builtin_ia32_pause(); continue; }      // ~1-2 ms of polling, then sleep
+                if (++spins < poll) { __builtin_ia32_pause(); continue; }
                 std::unique_lock<std::mutex> lk(m);
                 sleeping.store(true);
                 cv.wait(lk, [&] { return state.load(std::memory_order_acquire) == 1; });
@@ -4117,8 +4166,12 @@ static GroupWorker* group_worker(int k) {
     return pool[k];
 }
 static int run_groups(int kind, const Slam2dLidar* lidar, const Slam2dGroup* groups, int32_t G, const Slam2dScan* scan) {
-    static const bool threads = [] { const char* e = getenv("SLAM2D_GROUP_THREADS"); return !e || atoi(e) != 0; }();
-    if (!threads || G < 2) {
+    // one call at a time: the workers are a process-wide pool indexed by group number (ctypes releases the GIL, so two Python
+    // threads could otherwise post into the same worker)
+    static std::mutex one_call;
+    std::lock_guard<std::mutex> serial(one_call);
+    const GroupPolicy& pol = group_policy();
+    if (!pol.threads || G < 2) {
         int rc = 0;
         for (int i = 0; i < G && !rc; ++i) rc = run_group_job(kind, lidar, groups, G, i, *scan);
         return rc;
@@ -4134,11 +4187,23 @@ static int run_groups(int kind, const Slam2dLidar* lidar, const Slam2dGroup* gro
     }
     int rc = run_group_job(kind, lidar, groups, G, 0, *scan);
     for (int i = 1; i < G; ++i) {
-        while (w[i]->state.load(std::memory_order_acquire) != 2) __builtin_ia32_pause();
+        int spins = 0;
+        while (w[i]->state.load(std::memory_order_acquire) != 2) {
+            if (pol.polite && ++spins > 256) sched_yield(); else __builtin_ia32_pause();
+        }
         if (!rc) rc = w[i]->rc;
         w[i]->state.store(0, std::memory_order_release);
     }
     return rc;
+}
+
+/* how slam2d_groups_* issue their groups on this host: out[0] = effective cores, out[1] = local ranks assumed, out[2] = 1 if a
+ * worker thread per group is used, out[3] = 1 if the threads wait politely */
+int slam2d_group_policy(int32_t* out4) {
+    if (!out4) return SLAM2D_E_BADARG;
+    const GroupPolicy& g = group_policy();
+    out4[0] = g.cores; out4[1] = g.ranks; out4[2] = g.threads ? 1 : 0; out4[3] = g.polite ? 1 : 0;
+    return 0;
 }
 
 int slam2d_groups_match(const Slam2dLidar* lidar, const Slam2dGroup* groups, int32_t G, const Slam2dScan* scan) {

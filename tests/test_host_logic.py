@@ -346,3 +346,33 @@ def test_division_free_truncation_matches_the_division():
         assert fast(v, step) == int(np.float64(v) / np.float64(step)), (v, step, n)
         checked += 1
     assert checked > 50000
+
+
+def test_group_issue_policy_follows_the_cores_per_rank():
+    """include/slam2d.h slam2d_group_policy: the grouped scan calls keep a polling worker thread per group only where every
+    process on the host has at least 3 cores of its own (scheduler affinity capped by the cgroup quota, divided by the local
+    ranks) -- 8 ranks on a 16-core quota issue from the calling thread.  No GPU needed: the policy is host-side."""
+    import subprocess, sys, json, shutil
+    REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import importlib, json; L = importlib.import_module('slam-2d-lidar-scan_amd._lib'); print(json.dumps(L.group_policy()))")
+
+    def ask(env=None, prefix=()):
+        e = dict(os.environ)
+        for k in ("SLAM2D_GROUP_THREADS", "SLAM2D_LOCAL_RANKS", "LOCAL_WORLD_SIZE"):
+            e.pop(k, None)
+        e.update(env or {})
+        out = subprocess.run(list(prefix) + [sys.executable, "-c", code], env=e, capture_output=True, text=True, cwd=REPO, timeout=120)
+        assert out.returncode == 0, out.stderr[-400:]
+        return json.loads(out.stdout.strip().splitlines()[-1])
+
+    base = ask()
+    assert base["cores"] >= 1 and base["local_ranks"] == 1
+    assert base["threads"] == (base["cores"] >= 3)
+    crowded = ask({"LOCAL_WORLD_SIZE": str(max(1, base["cores"]))})      # one core per rank
+    assert crowded["local_ranks"] == max(1, base["cores"]) and not crowded["threads"]
+    assert ask({"SLAM2D_LOCAL_RANKS": "1", "LOCAL_WORLD_SIZE": "64"})["local_ranks"] == 1      # the explicit variable wins
+    assert ask({"LOCAL_WORLD_SIZE": "64", "SLAM2D_GROUP_THREADS": "1"})["threads"]            # forced on
+    assert not ask({"SLAM2D_GROUP_THREADS": "0"})["threads"]                                   # forced off
+    if shutil.which("taskset") and base["cores"] >= 2:
+        two = ask(prefix=("taskset", "-c", "0-1"))
+        assert two["cores"] <= 2 and not two["threads"]
