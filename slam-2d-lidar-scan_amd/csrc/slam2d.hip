@@ -1869,6 +1869,9 @@ __global__ __launch_bounds__(256, (RQ == 1 && mode == 0 && !SKIP) ? 8 : 1) void 
         // ticket from the particle's third arrival counter once its partials are out, and the particle's LAST block selects --
         // k_select's work without its launch.
         if (sel_out != nullptr && wave == 0) {
+            // (publish / consume as in k_exact_select: the partials left as relaxed agent-scope 8-byte atomic stores, are drained here
+            // and read back by the last block with load_partial_through's agent-scope atomic loads -- MI355X_MICROARCH.md's "8-B agent
+            // atomics both sides"; no cache to write back or invalidate on either side)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __atomic_signal_fence(__ATOMIC_SEQ_CST);
             unsigned ticket = 0u;
@@ -2843,6 +2846,15 @@ __global__ __launch_bounds__(XS_THREADS) void k_exact_select(Slam2dLevel lv, con
             score_tiles(min(XS_TILES, n_all - base), part + nsplit * wave, nsplit * (XS_THREADS / WAVE));
             __syncthreads();                                           // list_s is rebuilt by the next pass / the tail
         }
+        // Publish / consume across blocks, the form MI355X_MICROARCH.md ("inter-workgroup visibility": valid forms) lists as "8-B agent
+        // atomics both sides": the scores leave as relaxed agent-scope 8-byte atomic stores (global_store ... sc1: past this CU's L1,
+        // the line dropped from the XCD's L2), every storing wave drains them (s_waitcnt vmcnt(0)), the block takes its ticket with an
+        // agent-scope atomic, and the last block reads the scores back with relaxed agent-scope atomic loads (sc1: never served from
+        // an L1).  No agent-scope fence on either side: a release (buffer_wbl2) costs 1.7-6.5 us per block and an acquire
+        // (buffer_inv) 1.7 us (the guide's price list; round 2 measured this kernel at 134 us with them), and neither is needed when
+        // both sides bypass the caches they would write back / invalidate.  What the C++ abstract machine is not told is kept in
+        // order by the signal fences (compiler only) around the barrier.  tests/test_gpu_parity.py::test_split_exact_select_stress
+        // runs 1 000 launches with every block count against the one-block path, bit for bit.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // every storing wave drains its write-through stores
         __atomic_signal_fence(__ATOMIC_SEQ_CST);                       // (no instruction: the compiler may not move the score stores
         __syncthreads();                                               //  below the ticket, nor the read-back loads above it)

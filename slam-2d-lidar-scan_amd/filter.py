@@ -81,6 +81,33 @@ def _heading(dx, dy, dist):
     return math.acos(dx / dist) if dy > 0 else -math.acos(dx / dist)
 
 
+class _ReadingWindow:
+    """``readings[i]`` over any iterable without materialising it: ParticleFilter.run() consumes its readings in order and steps back
+    at most two (a voided scan and its successor are re-issued), so the last few items suffice -- an unbounded iterator (a live
+    sensor) is read one item at a time."""
+
+    def __init__(self, iterable, keep=4):
+        self._it, self._buf, self._n, self._done, self._keep = iter(iterable), {}, 0, False, keep
+
+    def _fill(self, i):
+        while not self._done and self._n <= i:
+            try:
+                self._buf[self._n] = next(self._it)
+                self._n += 1
+            except StopIteration:
+                self._done = True
+        for k in [k for k in self._buf if k < i - self._keep]:
+            del self._buf[k]
+
+    def has(self, i):
+        self._fill(i)
+        return i < self._n
+
+    def __getitem__(self, i):
+        self._fill(i)
+        return self._buf[i]
+
+
 class ParticleFilter:
     """``ParticleFilter(numParticles, ogParameters, smParameters)`` as in
     Algorithm/FastSlam.py:11,197-207.
@@ -391,9 +418,9 @@ class ParticleFilter:
         reissue = os.environ.get("SLAM2D_FILTER_REISSUE", "1") != "0"
         retried = (None, 0)                                  # (count of the scan last re-issued, how often)
         if not isinstance(readings, (list, tuple)):
-            readings = list(readings)
+            readings = _ReadingWindow(readings)              # a generator (a live sensor) stays lazy: the loop steps back two items at most
         i = 0
-        while i < len(readings):
+        while (i < len(readings)) if isinstance(readings, (list, tuple)) else readings.has(i):
             count, reading = first_count + i, readings[i]
             i += 1
             if count == 1 or (pending is None and self.prev_raw is None) or not self.lazy_field:
@@ -607,9 +634,14 @@ class ParticleFilter:
 
     def _enqueue_commit_groups(self, abort_mask, parity):
         eng, grp, L = self.engine, self._grp, _lib.lib()
+        # A promotion to 64-bit cells re-allocates the promoted maps' cells and replaces the descriptor array, on the main stream, while the
+        # group streams may still run this scan's match over the old ones: they are idled BEFORE anything is freed (the caching
+        # allocator could hand the old blocks to the very allocations that follow).  The test is _before_update's own.
+        if eng._max_bound + 2 * (eng._pending_updates + 1) > _lib.COUNT_LIMIT:
+            torch.cuda.synchronize(self.device)
         seen = eng.maps_version
         eng._before_update()
-        if eng.maps_version != seen:                     # a map was promoted to 64-bit cells (new arrays, on the main stream)
+        if eng.maps_version != seen:                     # a map was promoted (new arrays, new descriptors)
             torch.cuda.synchronize(self.device)
             self._bind_groups(parity)
         sc = grp.scan

@@ -173,6 +173,7 @@ class OccupancyGrid:
     def mapImage(self, xRange, yRange, as_u8=False):
         """``np.flipud(1 - (visited / total)[yIdx[0]:yIdx[1], xIdx[0]:xIdx[1]])`` -- what plotOccupancyGrid (:168-170) and the
         FastSLAM driver (Algorithm/FastSlam.py:171-177) draw -- computed on the device (slam2d_map_image)."""
+        self.flush()                                                # (a fault of the last update must not pass unseen into a picture)
         xIdx, yIdx = self.convertRealXYToMapIdx(xRange, yRange)
         return self.map.image(xIdx[0], xIdx[1], yIdx[0], yIdx[1], flipud=True, as_u8=as_u8).cpu().numpy()
 
@@ -193,6 +194,7 @@ class OccupancyGrid:
 
     # ---- copy.deepcopy support (Algorithm/FastSlam.py:58,61) ----
     def __deepcopy__(self, memo):
+        self.flush()                                                # the copy has no engine to ask: faults are raised here, on the original
         new = OccupancyGrid.__new__(OccupancyGrid)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
@@ -204,5 +206,6 @@ class OccupancyGrid:
             self._engine.sync_bounds()
         new.map = self.map.clone()
         new._engine = None
+        new._update_pending = False
         new.version = 0
         return new

@@ -177,6 +177,7 @@ class ScanMatcher:
                 eng = og.engine()
             eng.match(fine, m_coarse, MATCH_DOUBLES, d_rng, estMovingDist, None, None, m_fine)
             c, f = io.download(eng)
+            og._update_pending = False                                            # (the download has looked at the last update's fault bits too)
             matched = {"x": float(f["x"]), "y": float(f["y"]), "theta": float(f["theta"]), "range": rMeasure}
             self.last = dict(coarse=c.copy(), fine=f.copy())
             return matched, np.float64(c["confidence"])                            # :79

@@ -106,8 +106,15 @@ class DirectRccl:
         th = threading.Thread(target=work, daemon=True)
         th.start()
         th.join(timeout)
-        if th.is_alive() or "obj" not in box:
-            cls.last_error = "timed out" if th.is_alive() else box.get("err")
+        if th.is_alive():
+            # a broadcast or ncclCommInitRank of the setup is still in flight on the helper thread: falling back to c10d now would
+            # let it pair with the job's next collective.  Fail hard; the option is opt-in.
+            raise RuntimeError(f"DirectRccl: the communicator did not form within {timeout:.0f} s (unset SLAM2D_DIRECT_RCCL)")
+        # every rank must take the same all-gather path: agree on the outcome over c10d, use the direct call only if ALL succeeded
+        ok = torch.tensor([1 if "obj" in box else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) != 1:
+            cls.last_error = box.get("err") or "another rank could not form the direct communicator"
             return None
         return box["obj"]
 

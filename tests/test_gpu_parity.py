@@ -1486,3 +1486,49 @@ def test_update_launch_with_the_normaliser_equals_separate_calls(pkg):
                 assert torch.equal(pfs[0].engine.maps[p].cells, other.engine.maps[p].cells), f"scan {s}: map {p}"
                 assert torch.equal(pfs[0].engine.maps[p].bits, other.engine.maps[p].bits), f"scan {s}: bits {p}"
     assert abs(float(st[1]["w"].sum()) - 1.0) < 1e-12
+
+
+def test_split_exact_select_stress(pkg):
+    """k_exact_select over several blocks per particle hands its scores to the particle's last-arriving block through
+    agent-scope 8-byte atomics and an arrival ticket, with no cache fence on either side (csrc/slam2d.hip at the ticket;
+    MI355X_MICROARCH.md "inter-workgroup visibility": "8-B agent atomics both sides").  1 000 launches at 64 particles
+    (4 blocks per particle, every XCD), estimates scattered from spot-on to 2 m off so that the surviving tiles range from
+    a dozen to hundreds per particle, arg-max and soft-max draw: the whole match record must equal, bit for bit, what ONE
+    block per particle (Slam2dLevel.sync = NULL) computes from the same inputs."""
+    synth = importlib.import_module("slam-2d-lidar-scan_amd.synth")
+    cfg = BNB_CASES["config2"]
+    P, unit = 64, cfg["unit"]
+    origin = (-cfg["map_m"] / 2, -cfg["map_m"] / 2)
+    pf, world = _synthetic_filter(pkg, cfg, P, True)
+    assert pf.coarse.bnb and pf.coarse.c.sync
+    eng = pf.engine
+    poses = synth.random_walk(world, unit, origin, 6, seed=5, step=0.3, max_radius=6.0)
+    rs = np.random.RandomState(11)
+    sync_ptr = pf.coarse.c.sync
+    single = torch.zeros_like(pf.m_coarse)
+    kept = []
+    launches = 0
+    for rep in range(125):
+        s = 1 + rep % 5
+        ranges = synth.raycast(world, unit, origin, poses[s], cfg["fov"], cfg["beams"], cfg["max_range"])
+        spread = (0, 2, 6, 20)[rep % 4]
+        k = rs.randint(-spread, spread + 1, size=(P, 2))
+        est = np.column_stack((poses[s][0] + k[:, 0] * unit, poses[s][1] + k[:, 1] * unit, poses[s][2] + rs.normal(0, 0.05, P)))
+        d = float(np.hypot(poses[s][0] - poses[s - 1][0], poses[s][1] - poses[s - 1][1]))
+        psi = np.arctan2(poses[s][1] - poses[s - 1][1], poses[s][0] - poses[s - 1][0])
+        d_psi, d_rng, d_est = eng.to_device(np.tile((np.cos(psi), np.sin(psi)), (P, 1))), eng.to_device(ranges), eng.to_device(est)
+        for d_u in (None, eng.to_device(rs.random_sample(P))):
+            pf.coarse.c.sync = None                          # one block per particle: no hand-off
+            eng.match(pf.coarse, d_est, 3, d_rng, d, d_psi, d_u, single, prune=False)
+            eng.take_flags()
+            want = single.cpu().numpy().copy()
+            pf.coarse.c.sync = sync_ptr
+            for _ in range(4):                               # the split launch, repeatedly: placement and arrival order vary
+                eng.match(pf.coarse, d_est, 3, d_rng, d, d_psi, d_u, pf.m_coarse, prune=False)
+                launches += 1
+            eng.take_flags()
+            got = pf.m_coarse.cpu().numpy()
+            assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), f"launch {launches}: split result differs from the one-block path"
+        kept.append(float(pf.coarse.bnb_stats()["kept_per_particle"]))
+    assert launches == 1000 and min(kept) < 40 and max(kept) > 100, (launches, min(kept), max(kept))
+    assert int(pf.coarse.t["sync"].abs().sum().item()) == 0         # every launch left the arrival counters at zero

@@ -96,19 +96,30 @@ for wl in ("config2", "ref2level", "config5"):
         pb, P = doc["roofline"]["processed_bytes_per_particle_scan"], doc["config"]["particles_per_gpu"]
         nprobe = min(8, doc["steps"])
         lps_of = {k: v["launches"] / nprobe for k, v in doc["stages_probe"].items()}
-        extra_stage = {"k_tile_triage": "triage", "k_blur_check_redo": "check"}
         for base in per_kernel:
             stage = {"k_exact_select": "k_exact"}.get(base, base)
-            if stage in lps_of:
-                proc = bench.stage_bytes_per_launch(stage, pb, P, lps_of[stage])
-            elif base in extra_stage:
-                proc = sum(v.get(extra_stage[base], 0.0) for k, v in pb.items() if k != "update") * P / max(lps_of.get("k_blur_clamp", 1.0), 1e-9)
-            else:
+            if base not in bench.STAGE_OF_KERNEL and base != "k_grid_update":
                 continue
+            # launches per step of the kernel: the probe's count where the stage has events, else one per level and group (the blur's)
+            lps = lps_of.get(stage, lps_of.get("k_blur_clamp", 1.0))
+            proc = bench.stage_bytes_per_launch(base, pb, P, lps)
             entries[f"{wl}:{base}"]["processed_bytes_at_measurement"] = proc
             entries[f"{wl}:{base}"]["tile_stats_at_measurement"] = doc["roofline"]["tile_stats"]
     except Exception as exc:                               # the summaries stand without it
         print("no processed-bytes accounting for", wl, repr(exc))
+    try:                                                   # rocprofv3 --kernel-trace --stats averages of the same command (tools/gpu_r5.sh kstat)
+        import csv as _csv
+        ks = glob.glob(f"gpurun_out/kstat_{wl}/**/k_kernel_stats.csv", recursive=True)
+        if ks:
+            dur = collections.defaultdict(lambda: [0.0, 0])
+            for r in _csv.DictReader(open(ks[0])):
+                nm = r["Name"].split("(")[0].split("<")[0].replace("void ", "").strip()
+                dur[nm][0] += float(r["AverageNs"]) * int(r["Calls"]); dur[nm][1] += int(r["Calls"])
+            for base in per_kernel:
+                if dur[base][1]:
+                    entries[f"{wl}:{base}"]["avg_us_rocprof"] = dur[base][0] / dur[base][1] / 1e3
+    except Exception as exc:
+        print("no kernel-stats durations for", wl, repr(exc))
     step_total = sum(v["hbm_bytes_corrected"] * v["launches_per_step"] for kk, v in entries.items() if kk.startswith(wl + ":") and v["in_step"])
     head = (f"rocprofv3 --pmc {{FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum}} --kernel-trace -- python bench.py --workload {wl} --steps 12 --warmup 6 "
             "--repeats 1 --no-cpu-baseline --no-variants\nper-launch means after the warm-up launches; FETCH/WRITE_SIZE are KB counters (x1024 here); "
