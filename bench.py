@@ -776,7 +776,7 @@ def roofline_of(hot, scen, P, ms_per_step, stage_ms, launches_per_step_of, workl
     out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": "whole step"}
     ngroups = len(hot.groups)
     lps_default = {"k_grid_update": float(ngroups)}
-    per_level = ngroups * sum(1 for lv in hot.levels())
+    per_level = launches_per_step_of.get("k_blur_clamp", float(ngroups * sum(1 for lv in (hot.coarse, hot.fine) if lv is not None)))      # one launch per level and group
 
     def lps_of(kernel):
         stage = {"k_exact_select": "k_exact"}.get(kernel, kernel)

@@ -1505,6 +1505,7 @@ def test_split_exact_select_stress(pkg):
     poses = synth.random_walk(world, unit, origin, 6, seed=5, step=0.3, max_radius=6.0)
     rs = np.random.RandomState(11)
     sync_ptr = pf.coarse.c.sync
+    import torch
     single = torch.zeros_like(pf.m_coarse)
     kept = []
     launches = 0

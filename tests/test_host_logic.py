@@ -399,3 +399,30 @@ def test_reading_window_keeps_iterators_lazy():
     assert len(w._buf) <= 6
     short = filt._ReadingWindow(iter([{"k": 0}, {"k": 1}]))
     assert short.has(0) and short.has(1) and not short.has(2) and not short.has(3)
+
+
+def test_traffic_json_is_consistent():
+    """profiles/traffic.json (what bench.py's roofline replays): every kernel of a step that carries both figures must process no
+    more than 4x its counter bytes (a processed figure far above the measured traffic is an accounting slip -- round 4's
+    k_grid_update entry held a whole step's bytes against one launch's counters; the gather kernels are exempt: their processed
+    figure counts every gather and L2 serves most), launches per step must be whole multiples of
+    a half, and the file must name the source it was measured on."""
+    import json
+    doc = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")))
+    assert len(doc["source_sha256"]) == 64 and doc["entries"]
+    seen = 0
+    for key, e in doc["entries"].items():
+        if not e.get("in_step"):
+            continue
+        assert abs(e["launches_per_step"] * 2 - round(e["launches_per_step"] * 2)) < 1e-9, (key, e["launches_per_step"])
+        if "processed_bytes_at_measurement" in e and e.get("hbm_bytes_corrected"):
+            seen += 1
+            if key.split(":")[1] in ("k_exact_select", "k_sweep", "k_bound"):
+                continue          # gather kernels: every gather is counted as processed, most are served by L2 (97 % hits at config 5)
+            assert e["processed_bytes_at_measurement"] <= 4.0 * e["hbm_bytes_corrected"], (key, e["processed_bytes_at_measurement"], e["hbm_bytes_corrected"])
+    assert seen >= 6
+    # k_grid_update: one launch per particle group -- its processed bytes are those of the group's particles, not the step's
+    for wl in ("config2", "ref2level"):
+        g = doc["entries"].get(f"{wl}:k_grid_update")
+        if g and "processed_bytes_at_measurement" in g:
+            assert 0.3 < g["hbm_bytes_corrected"] / g["processed_bytes_at_measurement"] < 4.0, (wl, g)
