@@ -363,6 +363,10 @@ class HotPathGroups:
         self.ev_merged = C.c_void_p(self.L.slam2d_event_create())
         self.merged_once = False
         self.prune = False
+        # round 5: on one rank the groups' normaliser blocks merge among themselves on the device (Slam2dScan.d_norm_sync): no merge
+        # launch, no event packet between a group's kernels (SLAM2D_BENCH_DEVICE_MERGE=0: the merge launch on a third stream, rounds 3-4)
+        self.device_merge = os.environ.get("SLAM2D_BENCH_DEVICE_MERGE", "1") != "0"
+        self.norm_sync = torch.zeros(64, dtype=torch.int32, device=device)
         # round 4: the whole step is issued by ONE library call (slam2d_groups_step); SLAM2D_BENCH_PYSTEP=1 keeps round 3's
         # call-by-call issue from Python (~7 us of interpreter + ctypes per launch: 0.103 of the 0.131 ms step)
         self.c_step = os.environ.get("SLAM2D_BENCH_PYSTEP", "0") != "1"
@@ -447,8 +451,9 @@ class HotPathGroups:
         sc.options = E._lib.MATCH_PRUNE_BY_PRIOR if self.prune else 0
         sc.d_parts, sc.n_parts, sc.total_particles = self.parts_all.data_ptr(), self.G * self.world, self.total_particles
         sc.wait_merged, sc.merge = int(self.merged_once), 0 if self.sharded else 1
+        sc.d_norm_sync = self.norm_sync.data_ptr() if (self.device_merge and sc.merge) else None
         if os.environ.get("SLAM2D_BENCH_UNCOUPLED") == "1":       # timing experiment: the groups never meet (no normaliser)
-            sc.wait_merged, sc.merge = 0, 0
+            sc.wait_merged, sc.merge, sc.d_norm_sync = 0, 0, None
         E._lib.check(L.slam2d_groups_step(self._lidar_ref, self.cgroups, self.G, C.byref(sc)), "slam2d_groups_step")
         if self.sharded:
             self._gather_and_merge()

@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define SLAM2D_ABI_VERSION 14
+#define SLAM2D_ABI_VERSION 15
 #define SLAM2D_SPOKE_BAND 16         /* radial band width of the beam-major spoke table, in cells */
 
 /* library error codes (negative; positive values are hipError_t) */
@@ -500,6 +500,13 @@ typedef struct {
     int32_t wait_merged;         /* 0: first scan, nothing to wait for */
     int32_t merge;               /* 1: issue the merge here.  0: the caller does (sharded: an all-gather of the partials comes
                                     first); norm_stream is still ordered behind every group's ev_done */
+    uint32_t* d_norm_sync;       /* NULL, or 64 device words, ZEROED ONCE, kept for the life of these groups (ABI 15): with merge == 1 and
+                                    no abort_mask the groups' normaliser blocks merge among themselves on the device -- the block
+                                    that arrives last merges for all -- and a group's next update waits for that inside its own
+                                    normaliser block: no merge launch, no norm_stream, no ev_merged / ev_done / wait_merged (they may
+                                    be NULL / 0; ev_done is still recorded when given).  d_w / d_stats / the log-weights are final
+                                    once EVERY group's stream has passed the scan.  Needs n_parts == G, the groups' d_part being
+                                    rows 0 .. G-1 of d_parts.  Use it for every scan of the groups or for none */
 } Slam2dScan;
 
 /* match of every group (prior when d_est == NULL, coarse level, fine level) on its stream; records ev_matched */

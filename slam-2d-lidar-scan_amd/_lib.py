@@ -40,7 +40,7 @@ MAX_BLUR_RADIUS = 16
 MAX_BEAMS = 2048
 SPOKE_BAND = 16
 SYNC_WORDS = 4
-ABI_VERSION = 14
+ABI_VERSION = 15
 MATCH_PRUNE_BY_PRIOR = 1
 MATCH_PRIOR_READY = 2
 PRUNE_MARGIN = 40.0
@@ -126,7 +126,7 @@ class Slam2dScan(C.Structure):
                 ("d_abort_flags", _vp), ("ev_inputs", _vp),
                 ("d_logw_all", _vp), ("n_local", C.c_int32), ("n_parts", C.c_int32), ("d_parts", _vp),
                 ("total_particles", C.c_int64), ("d_w", _vp), ("d_stats", _vp),
-                ("norm_stream", _vp), ("ev_merged", _vp), ("wait_merged", C.c_int32), ("merge", C.c_int32)]
+                ("norm_stream", _vp), ("ev_merged", _vp), ("wait_merged", C.c_int32), ("merge", C.c_int32), ("d_norm_sync", _vp)]
 
 
 STRUCTS = {"Slam2dGroup": Slam2dGroup, "Slam2dScan": Slam2dScan, "Slam2dMap": Slam2dMap, "Slam2dLidar": Slam2dLidar, "Slam2dFrame": Slam2dFrame,

@@ -3095,6 +3095,10 @@ struct WeightsJob {
     const uint32_t* abort_flags; int abort_n;   // slam2d_groups_commit: the abort is decided over the fault bits of ALL groups (NULL: flags[0 .. N))
     // slam2d_scan_commit_next: the NEXT scan's pose prior (k_prior's work) behind this scan's bookkeeping, same thread per particle
     double* next_est; double* next_psi; double next_raw_theta, next_prev_raw_theta, next_raw_turn; int next_has_turn;
+    // slam2d_groups_* with Slam2dScan.d_norm_sync (round 5): the groups' normaliser blocks merge among themselves on the device --
+    // no stream, no event between the groups (normaliser_wait / normaliser_arrive)
+    uint32_t* nsync = nullptr; int ngroups = 0, gidx = 0;
+    const double* parts_all = nullptr; double* logw_all = nullptr; int n_all = 0; double total = 0.0; double* w_all = nullptr; double* stats_all = nullptr;
 };
 // pose / heading / log-weight bookkeeping of one particle after its match (Algorithm/FastSlam.py:110-117,134-135)
 __device__ __forceinline__ void post_match_one(const Slam2dMatch* __restrict__ fine, const Slam2dMatch* __restrict__ coarse, const int p,
@@ -3192,6 +3196,66 @@ __global__ __launch_bounds__(256) void k_weights_local(double* logw, const doubl
     weights_local_body(logw, logconf, cstride, N, part);
 }
 
+// The normaliser of G particle groups WITHOUT a stream of its own (round 5).  Every group's map-update launch has one block that
+// folds the scan's confidences into the group's log-weights and leaves the group's partial [max, sum, sum of squares]
+// (weights_local_body); the merge over the groups (k_weights_merge's arithmetic, partials in group order: the same bits) used to be a
+// launch on a third stream behind an event of every group, and every group's next update waited for an event behind it: two event
+// packets between a group's kernels per scan, 6-8 us each on the group's own chain (kernel trace: exact -> update 6.5 us,
+// update -> next endpoints 7.5 us of a 126 us step).  Now the blocks settle it among themselves through three kinds of device
+// words (Slam2dScan.d_norm_sync, zeroed once): [0] arrivals of this scan, [1] merges completed so far, [2 + g] merges group g's next
+// normaliser block has to see.  The block that arrives last merges for all groups and publishes; a group's next block waits for
+// that before it touches its log-weights.  Plain stores + release fence before every flag, one acquire fence behind every wait
+// (MI355X_MICROARCH.md, "inter-workgroup visibility", the valid producer / consumer forms): placement-independent.  No deadlock:
+// a waiting block was enqueued after everything it waits for (slam2d_groups_* issue a whole scan of every group per call).
+__device__ __forceinline__ void normaliser_wait(uint32_t* nsync, const int g) {
+    if (threadIdx.x == 0) {
+        const uint32_t want = nsync[2 + g];
+        while ((int)(__hip_atomic_load(&nsync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void normaliser_arrive(const WeightsJob& wj) {
+    __shared__ int last_s;
+    __syncthreads();                                       // every wave's stores of this block (log-weights, the partial) are out
+    if (threadIdx.x == 0) {
+        wj.nsync[2 + wj.gidx] += 1u;                       // (this group's next block: after THIS scan's merge)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const uint32_t ticket = __hip_atomic_fetch_add(&wj.nsync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = ticket == (uint32_t)(wj.ngroups - 1);
+        if (last) {
+            __hip_atomic_store(&wj.nsync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (nobody arrives for the next scan before the merge below is published)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                                      // the other groups' partials and log-weights
+        }
+        last_s = last;
+    }
+    __syncthreads();
+    if (!last_s) return;
+    // k_weights_merge's arithmetic, over the partials in group order
+    const double* parts = wj.parts_all;
+    double gm = -INFINITY;
+    for (int r = 0; r < wj.ngroups; ++r) gm = fmax(gm, parts[3 * r]);
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < wj.ngroups; ++r) {
+        const double sc = exp(parts[3 * r] - gm);
+        s1 += parts[3 * r + 1] * sc;
+        s2 += parts[3 * r + 2] * sc * sc;
+    }
+    const double lse = gm + log(s1);
+    for (int i = threadIdx.x; i < wj.n_all; i += 256) {
+        const double lw = wj.logw_all[i];
+        wj.w_all[i] = exp(lw - gm) / s1;
+        wj.logw_all[i] = lw - lse;
+    }
+    if (threadIdx.x == 0) { wj.stats_all[0] = s2 / (s1 * s1) - 1.0 / wj.total; wj.stats_all[1] = lse; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const uint32_t gen = __hip_atomic_load(&wj.nsync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&wj.nsync[1], gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_weights(double* logw, const double* __restrict__ logconf, int cstride, int N,
                                                  double* w, double* stats, uint32_t* flags, uint32_t* flag_snapshot) {
     weights_body(logw, logconf, cstride, N, w, stats, flags, flag_snapshot, false);
@@ -3251,6 +3315,7 @@ __global__ __launch_bounds__(256, UPDB_MIN_WAVES) void k_grid_update(Slam2dLidar
     DBG_CLOCK(58, wj.logw && blockIdx.x == 0);
     if (wj.logw && blockIdx.x == 0) {                      // one extra block: the normaliser, beside the update (one launch less;
         //                                                    block 0, so that it starts with the launch and not as its tail)
+        if (wj.nsync) normaliser_wait(wj.nsync, wj.gidx);  // (device-merged groups: the previous scan's merge has reached the log-weights)
         if (wj.fine) {                                     // ... after the scan's bookkeeping (the update blocks take their
             for (int i = threadIdx.x; i < wj.N; i += blockDim.x) {        // poses from the match buffer themselves)
                 post_match_one(wj.fine, wj.coarse, i, wj.prev, wj.heading, wj.logw, wj.report);
@@ -3264,6 +3329,7 @@ __global__ __launch_bounds__(256, UPDB_MIN_WAVES) void k_grid_update(Slam2dLidar
             if (wj.flags && wj.flag_snapshot)              // (slam2d_groups_commit: the scan's fault bits move into the report)
                 for (int i = threadIdx.x; i < wj.N; i += blockDim.x) wj.flag_snapshot[i] = atomicExch(&wj.flags[i], 0u);
             weights_local_body(wj.logw, wj.logconf, wj.cstride, wj.N, wj.part);
+            if (wj.nsync) normaliser_arrive(wj);
         }
         else weights_body(wj.logw, wj.logconf, wj.cstride, wj.N, wj.w, wj.stats, wj.flags, wj.flag_snapshot, true);
         DBG_CLOCK(59, true);
@@ -4008,25 +4074,33 @@ int slam2d_scan_commit_next(const Slam2dLidar* lidar, const Slam2dMap* d_maps, i
 }
 
 // ---- particle groups on several streams, one host call per scan (include/slam2d.h, "one scan for several particle GROUPS") ----
+// The normaliser merged by the groups' own blocks (Slam2dScan.d_norm_sync): one rank (the sharded merge has an all-gather in front of
+// it), no abort decision across groups (a voided scan's groups would not all arrive), the groups' partials in d_parts in group order.
+static inline bool device_merged(const Slam2dScan& sc) { return sc.d_norm_sync != nullptr && sc.merge && !sc.abort_mask; }
 static int groups_check(const Slam2dLidar* lidar, const Slam2dGroup* groups, int32_t G, const Slam2dScan* sc, bool commit) {
     if (!lidar || !groups || !sc || G <= 0 || G > 64 || !sc->d_ranges) return SLAM2D_E_BADARG;
     for (int i = 0; i < G; ++i) {
         const Slam2dGroup& g = groups[i];
-        if (!g.coarse || !g.d_maps || g.P <= 0 || !g.d_coarse || (g.fine && !g.d_fine) || !g.d_flags || !g.ev_done) return SLAM2D_E_BADARG;
+        if (!g.coarse || !g.d_maps || g.P <= 0 || !g.d_coarse || (g.fine && !g.d_fine) || !g.d_flags || (!g.ev_done && !sc->d_norm_sync)) return SLAM2D_E_BADARG;
         if (g.d_est ? g.est_stride < 3 : (!g.d_prev_pose || !g.d_heading || !g.d_est_out || !g.d_psi_out)) return SLAM2D_E_BADARG;
         if (commit && (!g.d_logw || !g.d_part)) return SLAM2D_E_BADARG;
         if (commit && sc->abort_mask && !g.ev_matched) return SLAM2D_E_BADARG;
     }
     if (commit) {
-        if (!sc->norm_stream && sc->merge) return SLAM2D_E_BADARG;
-        if (sc->merge && (!sc->d_logw_all || !sc->d_parts || !sc->d_w || !sc->d_stats || !sc->ev_merged || sc->n_local <= 0 || sc->n_parts <= 0 ||
+        const bool dm = device_merged(*sc);
+        if (!dm && !sc->norm_stream && sc->merge) return SLAM2D_E_BADARG;
+        if (sc->merge && (!sc->d_logw_all || !sc->d_parts || !sc->d_w || !sc->d_stats || (!dm && !sc->ev_merged) || sc->n_local <= 0 || sc->n_parts <= 0 ||
                           sc->total_particles < sc->n_local)) return SLAM2D_E_BADARG;
+        if (dm && (sc->n_parts != G || G > 60)) return SLAM2D_E_BADARG;      // (one partial per group, in group order; d_norm_sync holds 2 + G words)
+        if (sc->d_norm_sync && sc->merge && sc->abort_mask) {                // (every group must know there is no device merge: mixed scans would desynchronise the words)
+            return SLAM2D_E_BADARG;
+        }
         if (sc->abort_mask && (!sc->d_abort_flags || sc->n_abort_flags <= 0)) return SLAM2D_E_BADARG;
     }
     return 0;
 }
 
-static int group_match(const Slam2dLidar* lidar, const Slam2dGroup& g, const Slam2dScan& sc) {
+static int group_match(const Slam2dLidar* lidar, const Slam2dGroup& g, const Slam2dScan& sc, const bool step = false) {
     hipStream_t s = (hipStream_t)g.stream;
     int rc = 0;
     if (sc.ev_inputs && (rc = (int)hipStreamWaitEvent(s, (hipEvent_t)sc.ev_inputs, 0))) return rc;
@@ -4043,7 +4117,9 @@ static int group_match(const Slam2dLidar* lidar, const Slam2dGroup& g, const Sla
     if (g.fine && (rc = slam2d_match(lidar, g.fine, g.d_maps, g.P, reinterpret_cast<const double*>(g.d_coarse),
                                      (int32_t)(sizeof(Slam2dMatch) / sizeof(double)), sc.d_ranges, sc.est_moving_dist, nullptr, nullptr,
                                      g.d_fine, g.d_flags, 0u, g.stream))) return rc;
-    if (g.ev_matched) rc = (int)hipEventRecord((hipEvent_t)g.ev_matched, s);
+    // (ev_matched serves a LATER commit call's abort decision; slam2d_groups_step has none, and an event packet between two kernels
+    // of a group costs its chain 3 us)
+    if (g.ev_matched && !step) rc = (int)hipEventRecord((hipEvent_t)g.ev_matched, s);
     return rc;
 }
 
@@ -4054,23 +4130,30 @@ static int group_commit(const Slam2dLidar* lidar, const Slam2dGroup* groups, int
     if (sc.abort_mask)                                 // the abort is decided over every group's fault bits: wait for every group's match
         for (int j = 0; j < G; ++j)
             if (j != i && (rc = (int)hipStreamWaitEvent(s, (hipEvent_t)groups[j].ev_matched, 0))) return rc;
-    // the previous scan's merge works on the log-weights this launch rewrites
-    if (sc.wait_merged && sc.ev_merged && (rc = (int)hipStreamWaitEvent(s, (hipEvent_t)sc.ev_merged, 0))) return rc;
+    // the previous scan's merge works on the log-weights this launch rewrites: an event behind the merge launch -- or, with
+    // Slam2dScan.d_norm_sync, nothing on the stream: the normaliser blocks settle it on the device (normaliser_wait / _arrive)
+    const bool device_merge = device_merged(sc);
+    if (!device_merge && sc.wait_merged && sc.ev_merged && (rc = (int)hipStreamWaitEvent(s, (hipEvent_t)sc.ev_merged, 0))) return rc;
     const Slam2dMatch* fin = g.fine ? g.d_fine : g.d_coarse;
     const int md = (int)(sizeof(Slam2dMatch) / sizeof(double));
-    if (g.d_est)                                       // open loop: weight *= coarse confidence, update at the matched pose
-        rc = launch_update(lidar, g.d_maps, g.P, reinterpret_cast<const double*>(fin), md, sc.d_ranges, nullptr, g.d_flags,
-                           WeightsJob{g.d_logw, &g.d_coarse->log_confidence, md, g.P, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                      nullptr, nullptr, g.d_part, 0u, nullptr, 0}, g.stream);
-    else                                               // closed loop: slam2d_scan_commit's launch with the normaliser's local half
-        rc = launch_update(lidar, g.d_maps, g.P, reinterpret_cast<const double*>(fin), md, sc.d_ranges, nullptr, g.d_flags,
-                           WeightsJob{g.d_logw, nullptr, 1, g.P, nullptr, nullptr, g.d_flags, g.d_flag_snapshot, fin, g.d_coarse, g.d_prev_pose,
-                                      g.d_heading, g.d_report, g.d_part, sc.abort_mask, sc.d_abort_flags, sc.n_abort_flags}, g.stream);
-    if (rc) return rc;
+    WeightsJob wj = g.d_est                            // open loop: weight *= coarse confidence, update at the matched pose
+        ? WeightsJob{g.d_logw, &g.d_coarse->log_confidence, md, g.P, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                     nullptr, nullptr, g.d_part, 0u, nullptr, 0}
+        // closed loop: slam2d_scan_commit's launch with the normaliser's local half
+        : WeightsJob{g.d_logw, nullptr, 1, g.P, nullptr, nullptr, g.d_flags, g.d_flag_snapshot, fin, g.d_coarse, g.d_prev_pose,
+                     g.d_heading, g.d_report, g.d_part, sc.abort_mask, sc.d_abort_flags, sc.n_abort_flags};
+    if (device_merge) {
+        wj.nsync = sc.d_norm_sync; wj.ngroups = G; wj.gidx = i;
+        wj.parts_all = sc.d_parts; wj.logw_all = sc.d_logw_all; wj.n_all = sc.n_local; wj.total = (double)sc.total_particles;
+        wj.w_all = sc.d_w; wj.stats_all = sc.d_stats;
+    }
+    rc = launch_update(lidar, g.d_maps, g.P, reinterpret_cast<const double*>(fin), md, sc.d_ranges, nullptr, g.d_flags, wj, g.stream);
+    if (rc || (device_merge && !g.ev_done)) return rc;
     return (int)hipEventRecord((hipEvent_t)g.ev_done, s);
 }
 
 static int groups_merge(const Slam2dGroup* groups, int32_t G, const Slam2dScan& sc) {
+    if (device_merged(sc)) return 0;                   // the last group's normaliser block has merged (or will)
     hipStream_t ns = (hipStream_t)sc.norm_stream;
     int rc = 0;
     for (int i = 0; i < G; ++i)
@@ -4090,7 +4173,7 @@ static int groups_merge(const Slam2dGroup* groups, int32_t G, const Slam2dScan& 
 enum { JOB_MATCH = 1, JOB_COMMIT = 2, JOB_STEP = 3 };
 static int run_group_job(int kind, const Slam2dLidar* lidar, const Slam2dGroup* groups, int G, int i, const Slam2dScan& sc) {
     int rc = 0;
-    if (kind & JOB_MATCH) rc = group_match(lidar, groups[i], sc);
+    if (kind & JOB_MATCH) rc = group_match(lidar, groups[i], sc, kind == JOB_STEP);
     if (!rc && (kind & JOB_COMMIT)) rc = group_commit(lidar, groups, G, i, sc);
     return rc;
 }
