@@ -452,6 +452,8 @@ class HotPathGroups:
         sc.d_parts, sc.n_parts, sc.total_particles = self.parts_all.data_ptr(), self.G * self.world, self.total_particles
         sc.wait_merged, sc.merge = int(self.merged_once), 0 if self.sharded else 1
         sc.d_norm_sync = self.norm_sync.data_ptr() if (self.device_merge and sc.merge) else None
+        for g in range(self.G):                              # (nobody waits for a group's update on a stream then: no event packet behind it)
+            self.cgroups[g].ev_done = None if sc.d_norm_sync else self.ev_done[g]
         if os.environ.get("SLAM2D_BENCH_UNCOUPLED") == "1":       # timing experiment: the groups never meet (no normaliser)
             sc.wait_merged, sc.merge, sc.d_norm_sync = 0, 0, None
         E._lib.check(L.slam2d_groups_step(self._lidar_ref, self.cgroups, self.G, C.byref(sc)), "slam2d_groups_step")
