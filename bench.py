@@ -451,7 +451,7 @@ class HotPathGroups:
         sc.options = E._lib.MATCH_PRUNE_BY_PRIOR if self.prune else 0
         sc.d_parts, sc.n_parts, sc.total_particles = self.parts_all.data_ptr(), self.G * self.world, self.total_particles
         sc.wait_merged, sc.merge = int(self.merged_once), 0 if self.sharded else 1
-        sc.d_norm_sync = self.norm_sync.data_ptr() if (self.device_merge and sc.merge) else None
+        sc.d_norm_sync = self.norm_sync.data_ptr() if self.device_merge else None      # (sharded: the groups only wait / arrive; _gather_and_merge follows)
         for g in range(self.G):                              # (nobody waits for a group's update on a stream then: no event packet behind it)
             self.cgroups[g].ev_done = None if sc.d_norm_sync else self.ev_done[g]
         if os.environ.get("SLAM2D_BENCH_UNCOUPLED") == "1":       # timing experiment: the groups never meet (no normaliser)
@@ -463,6 +463,9 @@ class HotPathGroups:
 
     def _gather_and_merge(self):
         E, L = self.E, self.L
+        dsync = bool(self.cscan.d_norm_sync)
+        if dsync:        # the normaliser's stream waits for the groups' partials on the device (no ev_done behind the groups' updates)
+            E._lib.check(L.slam2d_norm_gate(C.c_void_p(self.norm_sync.data_ptr()), self.G, self.norm_handle), "slam2d_norm_gate")
         if self.rccl is not None:                        # ONE ncclAllGather on the normaliser's stream, straight from librccl
             self.rccl.all_gather(self.parts_local.data_ptr(), self.parts_all.data_ptr(), 3 * self.G, self.norm_handle)
         else:
@@ -474,6 +477,11 @@ class HotPathGroups:
                     self.parts_all.copy_(torch.cat(got))
                 else:
                     dist.all_gather_into_tensor(self.parts_all, self.parts_local)
+        if dsync:        # ... and the groups' next normaliser blocks for the merge (no ev_merged)
+            E._lib.check(L.slam2d_weights_merge_publish(E._ptr(self.d_logw), self.P, E._ptr(self.parts_all), self.G * self.world, self.total_particles,
+                                                        E._ptr(self.d_w), E._ptr(self.d_stats), C.c_void_p(self.norm_sync.data_ptr()), self.norm_handle),
+                         "slam2d_weights_merge_publish")
+            return
         E._lib.check(L.slam2d_weights_merge(E._ptr(self.d_logw), self.P, E._ptr(self.parts_all), self.G * self.world,
                                             self.total_particles, E._ptr(self.d_w), E._ptr(self.d_stats), self.norm_handle),
                      "slam2d_weights_merge")

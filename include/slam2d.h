@@ -434,6 +434,14 @@ int slam2d_weights_local(double* d_logw, const double* d_logconf, int32_t logcon
                          double* d_part, void* stream);
 int slam2d_weights_merge(double* d_logw, int32_t N, const double* d_parts, int32_t world,
                          int64_t total_particles, double* d_w, double* d_stats, void* stream);
+/* The sharded normaliser of particle GROUPS without events between the groups' streams and the normaliser's (round 5; see
+ * Slam2dScan.d_norm_sync with merge == 0): slam2d_norm_gate enqueues a one-wave kernel that waits until the normaliser blocks of all
+ * G groups of the scan issued just before have left their partials (they count themselves in d_norm_sync[0]); the caller's
+ * all-gather of the partials follows on that stream, then slam2d_weights_merge_publish = slam2d_weights_merge + the word the groups'
+ * next normaliser blocks wait for (d_norm_sync[1]).  Call both, in this order, once per scan, behind slam2d_groups_step / _commit. */
+int slam2d_norm_gate(uint32_t* d_norm_sync, int32_t G, void* stream);
+int slam2d_weights_merge_publish(double* d_logw, int32_t N, const double* d_parts, int32_t world, int64_t total_particles,
+                                 double* d_w, double* d_stats, uint32_t* d_norm_sync, void* stream);
 
 /* ---- one scan for several particle GROUPS, each on its own HIP stream, issued from C in ONE call ----
  * Particles are independent during a scan (Algorithm/FastSlam.py:25-27); every kernel of the step is latency- or issue-bound
@@ -506,7 +514,9 @@ typedef struct {
                                     normaliser block: no merge launch, no norm_stream, no ev_merged / ev_done / wait_merged (they may
                                     be NULL / 0; ev_done is still recorded when given).  d_w / d_stats / the log-weights are final
                                     once EVERY group's stream has passed the scan.  Needs n_parts == G, the groups' d_part being
-                                    rows 0 .. G-1 of d_parts.  Use it for every scan of the groups or for none */
+                                    rows 0 .. G-1 of d_parts.  With merge == 0 (sharded) the groups only wait and arrive through
+                                    the words; the caller follows with slam2d_norm_gate, its collective, slam2d_weights_merge_publish.
+                                    Use it for every scan of the groups or for none */
 } Slam2dScan;
 
 /* match of every group (prior when d_est == NULL, coarse level, fine level) on its stream; records ev_matched */

@@ -160,6 +160,8 @@ SIGNATURES = {
     "slam2d_groups_commit": (C.c_int, [C.POINTER(Slam2dLidar), C.POINTER(Slam2dGroup), C.c_int32, C.POINTER(Slam2dScan)]),
     "slam2d_groups_step": (C.c_int, [C.POINTER(Slam2dLidar), C.POINTER(Slam2dGroup), C.c_int32, C.POINTER(Slam2dScan)]),
     "slam2d_group_policy": (C.c_int, [C.POINTER(C.c_int32)]),
+    "slam2d_norm_gate": (C.c_int, [_vp, C.c_int32, _vp]),
+    "slam2d_weights_merge_publish": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, C.c_int64, _vp, _vp, _vp, _vp]),
     "slam2d_weights_local": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _vp, _vp]),
     "slam2d_weights_merge": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, C.c_int64, _vp, _vp, _vp]),
     "slam2d_gather_maps": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int64, _vp]),

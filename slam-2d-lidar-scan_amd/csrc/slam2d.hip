@@ -3222,7 +3222,9 @@ __device__ __forceinline__ void normaliser_arrive(const WeightsJob& wj) {
         wj.nsync[2 + wj.gidx] += 1u;                       // (this group's next block: after THIS scan's merge)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         const uint32_t ticket = __hip_atomic_fetch_add(&wj.nsync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = ticket == (uint32_t)(wj.ngroups - 1);
+        // (sharded, wj.logw_all == NULL: nobody merges here -- the caller's gate kernel on the normaliser's stream counts the arrivals,
+        // the all-gather and slam2d_weights_merge_publish follow there)
+        const int last = wj.logw_all != nullptr && ticket == (uint32_t)(wj.ngroups - 1);
         if (last) {
             __hip_atomic_store(&wj.nsync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (nobody arrives for the next scan before the merge below is published)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                                      // the other groups' partials and log-weights
@@ -3515,7 +3517,8 @@ __global__ __launch_bounds__(256, UPDB_MIN_WAVES) void k_grid_update(Slam2dLidar
 // and evaluates sum (w - 1/N)^2 = sum w^2 - 1/N over ALL N particles (Algorithm/FastSlam.py:32-35).
 __global__ __launch_bounds__(256) void k_weights_merge(double* logw, int N, const double* __restrict__ parts, int world,
                                                        double total_particles, double* w, double* stats,
-                                                       const uint32_t* __restrict__ abort_flags, int abort_n, uint32_t abort_mask) {
+                                                       const uint32_t* __restrict__ abort_flags, int abort_n, uint32_t abort_mask,
+                                                       uint32_t* nsync = nullptr) {
     if (abort_mask) {                                      // slam2d_groups_commit: a voided scan (see k_grid_update) has no partials to merge
         bool bad = false;
         for (int i = threadIdx.x; i < abort_n; i += blockDim.x) bad |= (abort_flags[i] & abort_mask) != 0u;
@@ -3536,6 +3539,26 @@ __global__ __launch_bounds__(256) void k_weights_merge(double* logw, int N, cons
         logw[i] = lw - lse;
     }
     if (threadIdx.x == 0) { stats[0] = s2 / (s1 * s1) - 1.0 / total_particles; stats[1] = lse; }
+    if (nsync) {                                           // (slam2d_weights_merge_publish: the groups' next normaliser blocks wait for this)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            const uint32_t gen = __hip_atomic_load(&nsync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&nsync[1], gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// The sharded normaliser without events between the groups and the normaliser's stream (round 5): the groups' blocks arrive on
+// d_norm_sync[0] (normaliser_arrive), this one-wave kernel on the normaliser's stream waits for all of them -- they were enqueued
+// before it -- and takes the counter back to zero; the all-gather of the partials and the merge follow on that stream, and the merge
+// publishes d_norm_sync[1], which the groups' next normaliser blocks wait for (normaliser_wait).
+__global__ __launch_bounds__(64) void k_norm_gate(uint32_t* nsync, int G) {
+    if (threadIdx.x == 0) {
+        while (__hip_atomic_load(&nsync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)G) __builtin_amdgcn_s_sleep(8);
+        __hip_atomic_store(&nsync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // (the partials: the collective behind this kernel reads them)
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -4077,6 +4100,9 @@ int slam2d_scan_commit_next(const Slam2dLidar* lidar, const Slam2dMap* d_maps, i
 // The normaliser merged by the groups' own blocks (Slam2dScan.d_norm_sync): one rank (the sharded merge has an all-gather in front of
 // it), no abort decision across groups (a voided scan's groups would not all arrive), the groups' partials in d_parts in group order.
 static inline bool device_merged(const Slam2dScan& sc) { return sc.d_norm_sync != nullptr && sc.merge && !sc.abort_mask; }
+// ... or only synchronised through those words (merge == 0, the sharded normaliser: slam2d_norm_gate, the collective and
+// slam2d_weights_merge_publish follow on the caller's stream)
+static inline bool device_synced(const Slam2dScan& sc) { return sc.d_norm_sync != nullptr && !sc.abort_mask; }
 static int groups_check(const Slam2dLidar* lidar, const Slam2dGroup* groups, int32_t G, const Slam2dScan* sc, bool commit) {
     if (!lidar || !groups || !sc || G <= 0 || G > 64 || !sc->d_ranges) return SLAM2D_E_BADARG;
     for (int i = 0; i < G; ++i) {
@@ -4091,10 +4117,9 @@ static int groups_check(const Slam2dLidar* lidar, const Slam2dGroup* groups, int
         if (!dm && !sc->norm_stream && sc->merge) return SLAM2D_E_BADARG;
         if (sc->merge && (!sc->d_logw_all || !sc->d_parts || !sc->d_w || !sc->d_stats || (!dm && !sc->ev_merged) || sc->n_local <= 0 || sc->n_parts <= 0 ||
                           sc->total_particles < sc->n_local)) return SLAM2D_E_BADARG;
-        if (dm && (sc->n_parts != G || G > 60)) return SLAM2D_E_BADARG;      // (one partial per group, in group order; d_norm_sync holds 2 + G words)
-        if (sc->d_norm_sync && sc->merge && sc->abort_mask) {                // (every group must know there is no device merge: mixed scans would desynchronise the words)
-            return SLAM2D_E_BADARG;
-        }
+        if (dm && sc->n_parts != G) return SLAM2D_E_BADARG;                  // (one partial per group, in group order)
+        if (sc->d_norm_sync && (G > 60 || sc->abort_mask)) return SLAM2D_E_BADARG;      // (2 + G words; an abort decision across groups needs the
+        //                                                                                  events: mixed scans would desynchronise the words)
         if (sc->abort_mask && (!sc->d_abort_flags || sc->n_abort_flags <= 0)) return SLAM2D_E_BADARG;
     }
     return 0;
@@ -4132,8 +4157,8 @@ static int group_commit(const Slam2dLidar* lidar, const Slam2dGroup* groups, int
             if (j != i && (rc = (int)hipStreamWaitEvent(s, (hipEvent_t)groups[j].ev_matched, 0))) return rc;
     // the previous scan's merge works on the log-weights this launch rewrites: an event behind the merge launch -- or, with
     // Slam2dScan.d_norm_sync, nothing on the stream: the normaliser blocks settle it on the device (normaliser_wait / _arrive)
-    const bool device_merge = device_merged(sc);
-    if (!device_merge && sc.wait_merged && sc.ev_merged && (rc = (int)hipStreamWaitEvent(s, (hipEvent_t)sc.ev_merged, 0))) return rc;
+    const bool device_merge = device_merged(sc), device_sync = device_synced(sc);
+    if (!device_sync && sc.wait_merged && sc.ev_merged && (rc = (int)hipStreamWaitEvent(s, (hipEvent_t)sc.ev_merged, 0))) return rc;
     const Slam2dMatch* fin = g.fine ? g.d_fine : g.d_coarse;
     const int md = (int)(sizeof(Slam2dMatch) / sizeof(double));
     WeightsJob wj = g.d_est                            // open loop: weight *= coarse confidence, update at the matched pose
@@ -4142,18 +4167,19 @@ static int group_commit(const Slam2dLidar* lidar, const Slam2dGroup* groups, int
         // closed loop: slam2d_scan_commit's launch with the normaliser's local half
         : WeightsJob{g.d_logw, nullptr, 1, g.P, nullptr, nullptr, g.d_flags, g.d_flag_snapshot, fin, g.d_coarse, g.d_prev_pose,
                      g.d_heading, g.d_report, g.d_part, sc.abort_mask, sc.d_abort_flags, sc.n_abort_flags};
+    if (device_sync) { wj.nsync = sc.d_norm_sync; wj.ngroups = G; wj.gidx = i; }
     if (device_merge) {
-        wj.nsync = sc.d_norm_sync; wj.ngroups = G; wj.gidx = i;
         wj.parts_all = sc.d_parts; wj.logw_all = sc.d_logw_all; wj.n_all = sc.n_local; wj.total = (double)sc.total_particles;
         wj.w_all = sc.d_w; wj.stats_all = sc.d_stats;
     }
     rc = launch_update(lidar, g.d_maps, g.P, reinterpret_cast<const double*>(fin), md, sc.d_ranges, nullptr, g.d_flags, wj, g.stream);
-    if (rc || (device_merge && !g.ev_done)) return rc;
+    if (rc || (device_sync && !g.ev_done)) return rc;
     return (int)hipEventRecord((hipEvent_t)g.ev_done, s);
 }
 
 static int groups_merge(const Slam2dGroup* groups, int32_t G, const Slam2dScan& sc) {
     if (device_merged(sc)) return 0;                   // the last group's normaliser block has merged (or will)
+    if (device_synced(sc)) return 0;                   // (merge == 0: the caller's slam2d_norm_gate orders its stream behind the groups)
     hipStream_t ns = (hipStream_t)sc.norm_stream;
     int rc = 0;
     for (int i = 0; i < G; ++i)
@@ -4330,6 +4356,19 @@ int slam2d_weights_merge(double* d_logw, int32_t N, const double* d_parts, int32
                          double* d_w, double* d_stats, void* stream) {
     if (!d_logw || !d_parts || !d_w || !d_stats || N <= 0 || world <= 0 || total_particles < N) return SLAM2D_E_BADARG;
     k_weights_merge<<<1, 256, 0, (hipStream_t)stream>>>(d_logw, N, d_parts, world, (double)total_particles, d_w, d_stats, nullptr, 0, 0u);
+    return launch_status();
+}
+
+int slam2d_norm_gate(uint32_t* d_norm_sync, int32_t G, void* stream) {
+    if (!d_norm_sync || G <= 0 || G > 60) return SLAM2D_E_BADARG;
+    k_norm_gate<<<1, 64, 0, (hipStream_t)stream>>>(d_norm_sync, G);
+    return launch_status();
+}
+
+int slam2d_weights_merge_publish(double* d_logw, int32_t N, const double* d_parts, int32_t world, int64_t total_particles,
+                                 double* d_w, double* d_stats, uint32_t* d_norm_sync, void* stream) {
+    if (!d_logw || !d_parts || !d_w || !d_stats || !d_norm_sync || N <= 0 || world <= 0 || total_particles < N) return SLAM2D_E_BADARG;
+    k_weights_merge<<<1, 256, 0, (hipStream_t)stream>>>(d_logw, N, d_parts, world, (double)total_particles, d_w, d_stats, nullptr, 0, 0u, d_norm_sync);
     return launch_status();
 }
 
