@@ -15,6 +15,12 @@ CPU fallback.
 """
 __version__ = "0.1.0"
 
+# Particle groups run on their own HIP streams (ParticleFilter(groups=G), slam2d_groups_*), and streams that share a hardware queue
+# serialise: the HIP runtime's default of 4 queues holds two groups beside the default stream.  The runtime reads this when it
+# initialises, i.e. at the process's first HIP call -- import this package (or set the variable) before that for more than two groups.
+import os as _os
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _LAZY = {
     "OccupancyGrid": ("grid", "OccupancyGrid"),
     "ScanMatcher": ("matcher", "ScanMatcher"),

@@ -150,7 +150,7 @@ def test_benchmarked_config2_matches_oracle(bench, variant, monkeypatch):
         chosen = [0, 9, 18, 27, 36, 45, 54, 63]
     if variant == "P13":
         P, chosen = 13, [0, 5, 7, 8, 11, 12]           # a particle count that is no multiple of 8
-    # "two_groups": what `python bench.py` runs by default -- the particles in two groups on two HIP streams, the normaliser's
+    # "two_groups": what `python bench.py` ran by default in rounds 3-4 -- the particles in two groups on two HIP streams, the normaliser's
     # partials merged on a third (bench.HotPathGroups); three scans, so that the cross-stream ordering of the merges is exercised
     # "four_groups": the same through slam2d_groups_step with four streams; "..._issued_from_python": round 3's call-by-call issue
     groups = {"two_groups": 2, "four_groups": 4, "two_groups_issued_from_python": 2}.get(variant, 1)
@@ -160,7 +160,7 @@ def test_benchmarked_config2_matches_oracle(bench, variant, monkeypatch):
     if groups >= 2:
         assert hot.c_step == (variant != "two_groups_issued_from_python")
     assert hot.coarse.bnb and hot.coarse.bnb_levels == (2 if variant == "two_level_bounds" else 1)
-    assert bench.bench_groups(None, 64) == 2
+    assert bench.bench_groups(None, 64) == 4          # round 5: what `python bench.py` runs by default (the 'four_groups' variant above)
 
 
 def test_benchmarked_config5_slice_matches_oracle(bench):
