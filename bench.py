@@ -977,11 +977,18 @@ def config3_closed_loop(P, device):
     legs = sorted((leg() for _ in range(3)), key=lambda r: r["seconds"])      # three timed legs, the median reported: a leg holds 143
     out = legs[1]                                                              # growth re-allocations and the host's per-scan work, and
     out["seconds_of_each_leg"] = [round(r["seconds"], 5) for r in legs]        # boxes of the pool differ by 25 % on it
-    out["note"] = ("closed loop through ParticleFilter.run(): host decisions (growth, resampling), per-scan H2D staging, one packed D2H per "
-                   "scan; scan s is enqueued before scan s-1's results are read; a scan voided on the device (a search window left its map) is issued "
-                   "again through the pipeline once the maps have grown (slam2d_map_grow: one device pass per map)")
-    out["two_groups"] = {k: v for k, v in leg(groups=2).items() if k in ("value", "seconds", "scans_per_sec", "particle_groups")}
-    out["two_groups"]["note"] = "the particles in two groups on two streams (slam2d_groups_match / slam2d_groups_commit): no gain in the closed loop"
+    out["note"] = ("closed loop through ParticleFilter.run(): host decisions (growth, resampling); the particles in groups on their own streams "
+                   "(ParticleFilter.auto_groups), each scan's ranges pulled from pinned host memory and its report pushed there by the device (no copy, "
+                   "no event); scan s is enqueued before scan s-1's results are read; a scan voided on the device (a search window left its map) is "
+                   "issued again through the pipeline once the maps have grown (slam2d_map_grow: one device pass per map)")
+    # the same in one group (through the same event-free calls) and through round 4's one-stream calls (staging copy, download, event)
+    out["one_group"] = {k: v for k, v in leg(groups=1).items() if k in ("value", "seconds", "scans_per_sec", "particle_groups")}
+    os.environ["SLAM2D_FILTER_GROUPED1"] = "0"
+    try:
+        out["one_stream_calls"] = {k: v for k, v in leg(groups=1).items() if k in ("value", "seconds", "scans_per_sec", "particle_groups")}
+    finally:
+        del os.environ["SLAM2D_FILTER_GROUPED1"]
+    out["one_stream_calls"]["note"] = "slam2d_scan_match / slam2d_scan_commit_next on one stream: rounds 3-4's closed loop"
     # the same log with a resample forced every 100 scans (64 particles never degenerate by themselves on this log): the gather
     # of 64 maps, the stop of the group streams and the redone speculative scan are inside the timed figure
     forced = leg(force=range(100, len(readings), 100))

@@ -52,12 +52,13 @@
 extern "C" {
 #endif
 
-#define SLAM2D_ABI_VERSION 15
+#define SLAM2D_ABI_VERSION 16
 #define SLAM2D_SPOKE_BAND 16         /* radial band width of the beam-major spoke table, in cells */
 
 /* library error codes (negative; positive values are hipError_t) */
 #define SLAM2D_E_BADARG   (-1)
 #define SLAM2D_E_TOOLARGE (-2)   /* a size exceeds a compiled-in limit */
+#define SLAM2D_E_TIMEOUT  (-3)   /* slam2d_host_wait_seq: the device did not publish the awaited scan in time */
 
 /* per-particle fault bits OR-ed into d_flags[p] */
 #define SLAM2D_F_WINDOW_OUTSIDE_MAP 0x01u  /* search window not inside the map: grow first (checkAndExapndOG) */
@@ -66,6 +67,7 @@ extern "C" {
 #define SLAM2D_F_UPDATE_OUTSIDE_MAP 0x08u  /* map update touched a cell outside the map */
 #define SLAM2D_F_COUNT_OVERFLOW     0x10u  /* a 16-bit count would overflow */
 #define SLAM2D_F_FLOOR_REDO         0x20u  /* informational: field minimum != analytic floor, clamp pass redone */
+#define SLAM2D_F_SYNC_TIMEOUT       0x40u  /* a device-side wait of the groups' normaliser (d_norm_sync) gave up after 2 s */
 
 #define SLAM2D_INIT_CELL 0x00010002u       /* visited = 1, total = 2 */
 #define SLAM2D_MAX_BLUR_RADIUS 16
@@ -293,7 +295,8 @@ int slam2d_sweep(const Slam2dLidar* lidar, const Slam2dLevel* level, int32_t P,
  * prior outside the ring) is swept in full by the same call: d_out never differs in arg-max from the
  * unpruned result. */
 #define SLAM2D_MATCH_PRUNE_BY_PRIOR 1u
-#define SLAM2D_MATCH_PRIOR_READY    2u   /* slam2d_scan_match only: d_est / d_psi_cs already hold this scan's prior (slam2d_scan_commit_next) */
+#define SLAM2D_MATCH_PRIOR_READY    2u   /* slam2d_scan_match, slam2d_groups_match[_begin]: d_est / d_psi_cs (the groups: and d_pull) already hold
+                                              this scan's prior (slam2d_scan_commit_next, Slam2dScan.h_next_ranges) */
 #define SLAM2D_PRUNE_MARGIN 40.0
 #define SLAM2D_BNB_MARGIN 30.0
 /* Branch and bound (Slam2dLevel.bnb != 0; every level whose cube has 2*ncell+1 in [9, 64] may use it).
@@ -479,6 +482,14 @@ typedef struct {
     void* stream;                /* the group's HIP stream */
     void* ev_matched;            /* slam2d_event_create(): recorded behind the group's match (needed with abort_mask) or NULL */
     void* ev_done;               /* recorded behind the group's map update */
+    /* ABI 16, with Slam2dScan.h_ranges (closed loop only): */
+    double* d_pull;              /* [beams] the group's own device copy of the scan's ranges, written by its prior launch (or by the
+                                    previous commit, d_pull_next) and read by every later kernel of the group's scan (d_uniform and
+                                    Slam2dScan.d_ranges are then ignored) */
+    const double* h_uniform;     /* PINNED HOST [P]: the group's soft-max uniforms of this scan (read there by the selecting kernel,
+                                    once per particle), or NULL: arg-max */
+    double* d_pull_next;         /* [beams] with Slam2dScan.h_next_ranges: where the commit leaves the NEXT scan's ranges -- that
+                                    scan's d_pull (the caller alternates two buffers) */
 } Slam2dGroup;
 
 /* What all groups of a scan share. */
@@ -516,7 +527,37 @@ typedef struct {
                                     once EVERY group's stream has passed the scan.  Needs n_parts == G, the groups' d_part being
                                     rows 0 .. G-1 of d_parts.  With merge == 0 (sharded) the groups only wait and arrive through
                                     the words; the caller follows with slam2d_norm_gate, its collective, slam2d_weights_merge_publish.
-                                    Use it for every scan of the groups or for none */
+                                    Use it for every scan of the groups or for none.  The device-side waits are bounded: after
+                                    2 s a group's fault word 0 receives SLAM2D_F_SYNC_TIMEOUT (word 62 carries it from the gate) */
+    /* ---- ABI 16: the closed loop without events and without copies (all optional; 0 / NULL = as before) ----
+     * Measured in round 5: an event packet between two kernels of a stream costs 3 us, a wait across streams 6-8 us, a copy-engine
+     * transfer in front of a kernel ~10 us; a grouped closed-loop scan had ten of them. */
+    const double* h_ranges;      /* PINNED HOST [beams], device-visible (hipHostMalloc / torch pin_memory): every group's prior launch
+                                    pulls the ranges and Slam2dGroup.h_uniform into Slam2dGroup.d_pull -- no staging copy, no ev_inputs.
+                                    The caller alternates two host buffers between scans (a group may still be pulling scan s
+                                    while the host stages s + 1) */
+    uint32_t match_seq;          /* != 0 (needs d_norm_sync): the number of slam2d_groups_commit calls with abort_mask since d_norm_sync
+                                    was zeroed, this one included.  Every group's commit starts with a one-wave gate kernel that counts
+                                    the group in (word 61: its match has finished) and waits (bounded) for G * match_seq arrivals: the
+                                    abort_mask decision over all groups' fault bits without ev_matched, and d_norm_sync's device-side
+                                    merge stays usable with abort_mask (a voided scan has no normaliser: nobody arrives there, the
+                                    words stay in step) */
+    uint32_t report_seq;         /* with h_seq: the value to publish for this scan (the caller counts its commits) */
+    uint32_t* h_seq;             /* PINNED HOST word, or NULL.  With d_norm_sync and merge == 1: the block that finishes the scan for
+                                    all groups (the merging normaliser block; for a voided scan the last group's block 0, counted in
+                                    word 60) copies d_pack[0 .. pack_doubles) to h_pack and then stores report_seq here, system scope.
+                                    The host waits with slam2d_host_wait_seq: no download, no event */
+    double* h_pack;              /* PINNED HOST [pack_doubles] */
+    const double* d_pack;        /* device [pack_doubles]: whatever the caller wants of the scan -- it lays d_report, d_w, d_stats and
+                                    d_flag_snapshot out inside this buffer */
+    int32_t pack_doubles;
+    /* commit only, closed loop with h_ranges: the NEXT scan's prior (slam2d_prior's arguments for it) and ranges ride in this
+     * commit's bookkeeping block -- into every group's d_est_out / d_psi_out and d_pull_next -- and the next match is called with
+     * SLAM2D_MATCH_PRIOR_READY in `options`: one launch less per group and scan.  A voided scan writes neither: the caller
+     * re-issues without the option.  NULL: no such thing */
+    const double* h_next_ranges; /* PINNED HOST [beams] */
+    double next_raw_theta, next_prev_raw_theta, next_raw_turn;
+    int32_t next_has_turn;
 } Slam2dScan;
 
 /* match of every group (prior when d_est == NULL, coarse level, fine level) on its stream; records ev_matched */
@@ -524,6 +565,14 @@ int slam2d_groups_match(const Slam2dLidar* lidar, const Slam2dGroup* groups, int
 /* map update at the matched poses + bookkeeping + the group's normaliser partial in ONE launch per group (closed loop:
  * slam2d_scan_commit's work with the abort decided over all groups), then the merge.  */
 int slam2d_groups_commit(const Slam2dLidar* lidar, const Slam2dGroup* groups, int32_t G, const Slam2dScan* scan);
+/* slam2d_groups_match, but the call returns while worker threads still issue the launches (all groups on workers; the
+ * descriptors are copied, the level descriptors they point to must stay untouched until the join).  The next slam2d_groups_* call
+ * waits for them first and returns their error; slam2d_groups_join does only that -- call it before synchronising the device or
+ * touching anything the match reads.  Without worker threads (slam2d_group_policy) the call is slam2d_groups_match. */
+int slam2d_groups_match_begin(const Slam2dLidar* lidar, const Slam2dGroup* groups, int32_t G, const Slam2dScan* scan);
+int slam2d_groups_join(void);
+/* Host side of Slam2dScan.h_seq: spin until the word has reached `want` (wrap-safe); SLAM2D_E_TIMEOUT after timeout_s seconds. */
+int slam2d_host_wait_seq(const uint32_t* h_seq, uint32_t want, double timeout_s);
 /* both, group by group (a group's update is enqueued right behind its match): the open-loop step of bench.py */
 int slam2d_groups_step(const Slam2dLidar* lidar, const Slam2dGroup* groups, int32_t G, const Slam2dScan* scan);
 /* How these three calls issue their groups on this host (decided at the first call; one call runs at a time, a second caller
@@ -590,6 +639,10 @@ void slam2d_prof_disable(void);
 /* Ordering between streams for a host driver that runs groups of particles on several HIP streams (particles are
  * independent during a scan, Algorithm/FastSlam.py:25-27; only the weight normaliser, :30-48, joins them): events without
  * timing.  slam2d_event_record marks a point of `stream`; slam2d_stream_wait_event makes later work of `stream` wait for it. */
+/* n non-blocking streams created in one batch and each used once, so that they sit on distinct hardware queues (up to the
+ * runtime's GPU_MAX_HW_QUEUES): the streams of particle groups.  A host driver creates them ONCE per process and reuses them. */
+int   slam2d_streams_create(void** out, int32_t n);
+void  slam2d_stream_destroy(void* stream);
 void* slam2d_event_create(void);
 void  slam2d_event_destroy(void* event);
 int   slam2d_event_record(void* event, void* stream);

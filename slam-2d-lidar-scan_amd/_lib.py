@@ -24,7 +24,8 @@ F_ENDPOINT_OUTSIDE = 0x04
 F_UPDATE_OUTSIDE_MAP = 0x08
 F_COUNT_OVERFLOW = 0x10
 F_FLOOR_REDO = 0x20
-FATAL_FLAGS = F_WINDOW_OUTSIDE_MAP | F_FIELD_INDEX | F_ENDPOINT_OUTSIDE | F_UPDATE_OUTSIDE_MAP | F_COUNT_OVERFLOW
+F_SYNC_TIMEOUT = 0x40
+FATAL_FLAGS = F_WINDOW_OUTSIDE_MAP | F_FIELD_INDEX | F_ENDPOINT_OUTSIDE | F_UPDATE_OUTSIDE_MAP | F_COUNT_OVERFLOW | F_SYNC_TIMEOUT
 FLAG_NAMES = {
     F_WINDOW_OUTSIDE_MAP: "search window outside the map (grow the map first)",
     F_FIELD_INDEX: "occupied cell mapped outside the search field",
@@ -32,6 +33,7 @@ FLAG_NAMES = {
     F_UPDATE_OUTSIDE_MAP: "map update touched a cell outside the map",
     F_COUNT_OVERFLOW: "16-bit cell count overflow",
     F_FLOOR_REDO: "field minimum differed from the analytic floor (clamp redone)",
+    F_SYNC_TIMEOUT: "a device-side wait of the groups' normaliser gave up after 2 s (a producer never arrived)",
 }
 INIT_CELL = 0x00010002
 INIT_CELL_WIDE = (1 << 32) | 2        # the same in the 64-bit cell format (Slam2dMap.wide)
@@ -40,7 +42,7 @@ MAX_BLUR_RADIUS = 16
 MAX_BEAMS = 2048
 SPOKE_BAND = 16
 SYNC_WORDS = 4
-ABI_VERSION = 15
+ABI_VERSION = 16
 MATCH_PRUNE_BY_PRIOR = 1
 MATCH_PRIOR_READY = 2
 PRUNE_MARGIN = 40.0
@@ -115,7 +117,7 @@ class Slam2dGroup(C.Structure):
                 ("d_prev_pose", _vp), ("d_heading", _vp), ("d_est_out", _vp), ("d_psi_out", _vp),
                 ("d_coarse", _vp), ("d_fine", _vp), ("d_flags", _vp), ("d_logw", _vp), ("d_part", _vp),
                 ("d_report", _vp), ("d_flag_snapshot", _vp),
-                ("stream", _vp), ("ev_matched", _vp), ("ev_done", _vp)]
+                ("stream", _vp), ("ev_matched", _vp), ("ev_done", _vp), ("d_pull", _vp), ("h_uniform", _vp), ("d_pull_next", _vp)]
 
 
 class Slam2dScan(C.Structure):
@@ -126,7 +128,10 @@ class Slam2dScan(C.Structure):
                 ("d_abort_flags", _vp), ("ev_inputs", _vp),
                 ("d_logw_all", _vp), ("n_local", C.c_int32), ("n_parts", C.c_int32), ("d_parts", _vp),
                 ("total_particles", C.c_int64), ("d_w", _vp), ("d_stats", _vp),
-                ("norm_stream", _vp), ("ev_merged", _vp), ("wait_merged", C.c_int32), ("merge", C.c_int32), ("d_norm_sync", _vp)]
+                ("norm_stream", _vp), ("ev_merged", _vp), ("wait_merged", C.c_int32), ("merge", C.c_int32), ("d_norm_sync", _vp),
+                ("h_ranges", _vp), ("match_seq", C.c_uint32), ("report_seq", C.c_uint32), ("h_seq", _vp), ("h_pack", _vp), ("d_pack", _vp),
+                ("pack_doubles", C.c_int32), ("h_next_ranges", _vp), ("next_raw_theta", C.c_double), ("next_prev_raw_theta", C.c_double),
+                ("next_raw_turn", C.c_double), ("next_has_turn", C.c_int32)]
 
 
 STRUCTS = {"Slam2dGroup": Slam2dGroup, "Slam2dScan": Slam2dScan, "Slam2dMap": Slam2dMap, "Slam2dLidar": Slam2dLidar, "Slam2dFrame": Slam2dFrame,
@@ -160,6 +165,9 @@ SIGNATURES = {
     "slam2d_groups_commit": (C.c_int, [C.POINTER(Slam2dLidar), C.POINTER(Slam2dGroup), C.c_int32, C.POINTER(Slam2dScan)]),
     "slam2d_groups_step": (C.c_int, [C.POINTER(Slam2dLidar), C.POINTER(Slam2dGroup), C.c_int32, C.POINTER(Slam2dScan)]),
     "slam2d_group_policy": (C.c_int, [C.POINTER(C.c_int32)]),
+    "slam2d_groups_match_begin": (C.c_int, [C.POINTER(Slam2dLidar), C.POINTER(Slam2dGroup), C.c_int32, C.POINTER(Slam2dScan)]),
+    "slam2d_groups_join": (C.c_int, []),
+    "slam2d_host_wait_seq": (C.c_int, [_vp, C.c_uint32, C.c_double]),
     "slam2d_norm_gate": (C.c_int, [_vp, C.c_int32, _vp]),
     "slam2d_weights_merge_publish": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, C.c_int64, _vp, _vp, _vp, _vp]),
     "slam2d_weights_local": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _vp, _vp]),
@@ -174,6 +182,8 @@ SIGNATURES = {
     "slam2d_prof_collect": (C.c_int, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "slam2d_prof_every": (C.c_int, [C.c_int32]),
     "slam2d_prof_disable": (None, []),
+    "slam2d_streams_create": (C.c_int, [C.POINTER(_vp), C.c_int32]),
+    "slam2d_stream_destroy": (None, [_vp]),
     "slam2d_event_create": (_vp, []),
     "slam2d_event_destroy": (None, [_vp]),
     "slam2d_event_record": (C.c_int, [_vp, _vp]),
@@ -237,7 +247,7 @@ def lib():
 
 def check(rc, what):
     if rc != 0:
-        kind = "HIP error" if rc > 0 else "argument error"
+        kind = "HIP error" if rc > 0 else "timeout" if rc == -3 else "argument error"
         raise Slam2dError(f"{what}: {kind} {rc}")
 
 

@@ -16,6 +16,7 @@
 #include <limits.h>
 #include <stdlib.h>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -3099,7 +3100,23 @@ struct WeightsJob {
     // no stream, no event between the groups (normaliser_wait / normaliser_arrive)
     uint32_t* nsync = nullptr; int ngroups = 0, gidx = 0;
     const double* parts_all = nullptr; double* logw_all = nullptr; int n_all = 0; double total = 0.0; double* w_all = nullptr; double* stats_all = nullptr;
+    // the scan's report pushed to the host by the block that finishes it (Slam2dScan.h_pack / h_seq, ABI 16): no copy, no event
+    const double* pack_d = nullptr; double* pack_h = nullptr; int pack_n = 0; uint32_t* h_seq = nullptr; uint32_t seq = 0u;
+    // the NEXT scan's ranges pulled from pinned host memory by the bookkeeping block, beside its prior (Slam2dScan.h_next_ranges)
+    const double* pull_src = nullptr; double* pull_dst = nullptr; int pull_n = 0;
 };
+// Whoever finishes a scan for all groups -- the block that merged the normaliser, or the last group's block 0 of a voided scan --
+// copies the scan's pack (report, weights, variance, fault-bit snapshot: device memory the groups' blocks have written and
+// released) into the caller's pinned host buffer and publishes the scan's sequence number behind it, system scope: the host
+// polls that word (slam2d_host_wait_seq) instead of waiting for a copy engine and an event (~15 us per scan).
+__device__ __forceinline__ void publish_pack(const WeightsJob& wj) {
+    if (!wj.h_seq) return;
+    __syncthreads();
+    for (int i = threadIdx.x; i < wj.pack_n; i += blockDim.x) wj.pack_h[i] = wj.pack_d[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(wj.h_seq, wj.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // pose / heading / log-weight bookkeeping of one particle after its match (Algorithm/FastSlam.py:110-117,134-135)
 __device__ __forceinline__ void post_match_one(const Slam2dMatch* __restrict__ fine, const Slam2dMatch* __restrict__ coarse, const int p,
                                                double* prev, double* heading, double* logw, double* report) {
@@ -3207,11 +3224,21 @@ __global__ __launch_bounds__(256) void k_weights_local(double* logw, const doubl
 // that before it touches its log-weights.  Plain stores + release fence before every flag, one acquire fence behind every wait
 // (MI355X_MICROARCH.md, "inter-workgroup visibility", the valid producer / consumer forms): placement-independent.  No deadlock:
 // a waiting block was enqueued after everything it waits for (slam2d_groups_* issue a whole scan of every group per call).
-__device__ __forceinline__ void normaliser_wait(uint32_t* nsync, const int g) {
+// Both waits are BOUNDED (SYNC_SPIN_TICKS of the 100 MHz wall clock = 2 s, five orders of magnitude above a scan): a producer
+// that never comes -- a dead rank behind the all-gather, a caller that broke the whole-scan-per-call order -- ends as the fatal
+// SLAM2D_F_SYNC_TIMEOUT in the group's fault words (word 62 of the sync block carries it from the gate kernel), not as a hung GPU.
+#define SYNC_SPIN_TICKS 200000000ull
+__device__ __forceinline__ void normaliser_wait(uint32_t* nsync, const int g, uint32_t* flags) {
     if (threadIdx.x == 0) {
         const uint32_t want = nsync[2 + g];
-        while ((int)(__hip_atomic_load(&nsync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) __builtin_amdgcn_s_sleep(8);
+        const unsigned long long t0 = wall_clock64();
+        bool late = false;
+        while ((int)(__hip_atomic_load(&nsync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > SYNC_SPIN_TICKS) { late = true; break; }
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if ((late || __hip_atomic_load(&nsync[62], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) && flags) atomicOr(&flags[0], SLAM2D_F_SYNC_TIMEOUT);
     }
     __syncthreads();
 }
@@ -3256,6 +3283,26 @@ __device__ __forceinline__ void normaliser_arrive(const WeightsJob& wj) {
         const uint32_t gen = __hip_atomic_load(&wj.nsync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&wj.nsync[1], gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    publish_pack(wj);                                      // (behind the word the groups wait for: the host is not on their path)
+}
+// A voided scan (k_grid_update's abort) has no normaliser: the groups' blocks 0 count themselves in word 60 instead and the last one
+// publishes the report (fault-bit snapshot + coarse poses) to the host.
+__device__ __forceinline__ void abort_arrive(const WeightsJob& wj) {
+    if (!wj.h_seq || !wj.nsync) return;
+    __shared__ int last_a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const uint32_t ticket = __hip_atomic_fetch_add(&wj.nsync[60], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = ticket == (uint32_t)(wj.ngroups - 1);
+        if (last) {
+            __hip_atomic_store(&wj.nsync[60], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        last_a = last;
+    }
+    __syncthreads();
+    if (last_a) publish_pack(wj);
 }
 
 __global__ __launch_bounds__(256) void k_weights(double* logw, const double* __restrict__ logconf, int cstride, int N,
@@ -3311,13 +3358,14 @@ __global__ __launch_bounds__(256, UPDB_MIN_WAVES) void k_grid_update(Slam2dLidar
                 for (int i = threadIdx.x; i < wj.N; i += blockDim.x) {
                     wj.report[5 * i] = wj.coarse[i].x; wj.report[5 * i + 1] = wj.coarse[i].y; wj.report[5 * i + 2] = wj.coarse[i].theta;
                 }
+            if (blockIdx.x == 0) abort_arrive(wj);
             return;
         }
     }
     DBG_CLOCK(58, wj.logw && blockIdx.x == 0);
     if (wj.logw && blockIdx.x == 0) {                      // one extra block: the normaliser, beside the update (one launch less;
         //                                                    block 0, so that it starts with the launch and not as its tail)
-        if (wj.nsync) normaliser_wait(wj.nsync, wj.gidx);  // (device-merged groups: the previous scan's merge has reached the log-weights)
+        if (wj.nsync) normaliser_wait(wj.nsync, wj.gidx, flags);  // (device-merged groups: the previous scan's merge has reached the log-weights)
         if (wj.fine) {                                     // ... after the scan's bookkeeping (the update blocks take their
             for (int i = threadIdx.x; i < wj.N; i += blockDim.x) {        // poses from the match buffer themselves)
                 post_match_one(wj.fine, wj.coarse, i, wj.prev, wj.heading, wj.logw, wj.report);
@@ -3325,6 +3373,7 @@ __global__ __launch_bounds__(256, UPDB_MIN_WAVES) void k_grid_update(Slam2dLidar
                     prior_one(wj.prev, wj.heading, i, wj.next_raw_theta, wj.next_prev_raw_theta, wj.next_has_turn, wj.next_raw_turn,
                               wj.next_est, wj.next_psi);
             }
+            for (int i = threadIdx.x; i < wj.pull_n; i += blockDim.x) wj.pull_dst[i] = __builtin_nontemporal_load(wj.pull_src + i);
             __syncthreads();
         }
         if (wj.part) {
@@ -3555,7 +3604,14 @@ __global__ __launch_bounds__(256) void k_weights_merge(double* logw, int N, cons
 // publishes d_norm_sync[1], which the groups' next normaliser blocks wait for (normaliser_wait).
 __global__ __launch_bounds__(64) void k_norm_gate(uint32_t* nsync, int G) {
     if (threadIdx.x == 0) {
-        while (__hip_atomic_load(&nsync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)G) __builtin_amdgcn_s_sleep(8);
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(&nsync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)G) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > SYNC_SPIN_TICKS) {           // (sticky: every later normaliser block raises the fault bit)
+                __hip_atomic_store(&nsync[62], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
         __hip_atomic_store(&nsync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // (the partials: the collective behind this kernel reads them)
     }
@@ -3569,6 +3625,34 @@ __global__ void k_prior(const double* __restrict__ prev, double raw_theta, doubl
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     prior_one(prev, heading, p, raw_theta, prev_raw_theta, has_turn, raw_turn, est, psi_cs);
+}
+
+// The closed loop's prior of a particle group with the scan's ranges PULLED from the caller's pinned host buffer in the same launch
+// (Slam2dScan.h_ranges, ABI 16) into the group's own device buffer, which every later kernel of the group's scan reads -- instead
+// of a copy-engine transfer and an event in front of every group's match.  (The uniforms, one per particle and read once by the
+// selecting kernel, are read from the pinned buffer where they are used.)  Normally neither is launched: the previous scan's commit
+// has written this scan's prior and pulled its ranges (Slam2dScan.h_next_ranges).
+__global__ __launch_bounds__(256) void k_prior_pull(const double* __restrict__ prev, double raw_theta, double prev_raw_theta, int has_turn,
+                                                    double raw_turn, const double* __restrict__ heading, int P, double* est, double* psi_cs,
+                                                    const double* h_ranges, int B, double* d_pull) {
+    for (int i = threadIdx.x; i < B; i += blockDim.x) d_pull[i] = __builtin_nontemporal_load(h_ranges + i);
+    for (int p = threadIdx.x; p < P; p += blockDim.x) prior_one(prev, heading, p, raw_theta, prev_raw_theta, has_turn, raw_turn, est, psi_cs);
+}
+// Abort decision across groups without events (Slam2dScan.match_seq, ABI 16): every group's commit starts with k_abort_gate, ONE
+// wave that counts its group in (word 61 of the sync block: group-matches finished since the words were zeroed -- the gate sits
+// behind the group's match on its stream) and waits -- bounded -- until all G groups of this scan have: the update launch behind it
+// then reads every group's fault bits as it did behind the events.  No deadlock: a commit call is issued after the match call of
+// ALL groups, and only one wave per group waits.
+__global__ __launch_bounds__(64) void k_abort_gate(uint32_t* nsync, uint32_t want, uint32_t* flags) {
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(&nsync[61], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the match's kernels have ended: their stores are out)
+        const unsigned long long t0 = wall_clock64();
+        while ((int)(__hip_atomic_load(&nsync[61], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > SYNC_SPIN_TICKS) { atomicOr(&flags[0], SLAM2D_F_SYNC_TIMEOUT); break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
 }
 
 __global__ void k_post_match(const Slam2dMatch* __restrict__ fine, const Slam2dMatch* __restrict__ coarse, int P,
@@ -4099,18 +4183,24 @@ int slam2d_scan_commit_next(const Slam2dLidar* lidar, const Slam2dMap* d_maps, i
 // ---- particle groups on several streams, one host call per scan (include/slam2d.h, "one scan for several particle GROUPS") ----
 // The normaliser merged by the groups' own blocks (Slam2dScan.d_norm_sync): one rank (the sharded merge has an all-gather in front of
 // it), no abort decision across groups (a voided scan's groups would not all arrive), the groups' partials in d_parts in group order.
-static inline bool device_merged(const Slam2dScan& sc) { return sc.d_norm_sync != nullptr && sc.merge && !sc.abort_mask; }
+// (round 5, ABI 16: ... or an abort decided behind k_match_arrive / k_abort_gate, Slam2dScan.match_seq != 0)
+static inline bool abort_on_device(const Slam2dScan& sc) { return sc.d_norm_sync != nullptr && sc.match_seq != 0u; }
+static inline bool device_merged(const Slam2dScan& sc) { return sc.d_norm_sync != nullptr && sc.merge && (!sc.abort_mask || sc.match_seq != 0u); }
 // ... or only synchronised through those words (merge == 0, the sharded normaliser: slam2d_norm_gate, the collective and
 // slam2d_weights_merge_publish follow on the caller's stream)
-static inline bool device_synced(const Slam2dScan& sc) { return sc.d_norm_sync != nullptr && !sc.abort_mask; }
+static inline bool device_synced(const Slam2dScan& sc) { return sc.d_norm_sync != nullptr && (!sc.abort_mask || sc.match_seq != 0u); }
 static int groups_check(const Slam2dLidar* lidar, const Slam2dGroup* groups, int32_t G, const Slam2dScan* sc, bool commit) {
-    if (!lidar || !groups || !sc || G <= 0 || G > 64 || !sc->d_ranges) return SLAM2D_E_BADARG;
+    if (!lidar || !groups || !sc || G <= 0 || G > 64 || (!sc->d_ranges && !sc->h_ranges)) return SLAM2D_E_BADARG;
+    if (sc->match_seq && !sc->d_norm_sync) return SLAM2D_E_BADARG;
+    if (sc->h_seq && (!device_merged(*sc) || !sc->h_pack || !sc->d_pack || sc->pack_doubles <= 0)) return SLAM2D_E_BADARG;
     for (int i = 0; i < G; ++i) {
         const Slam2dGroup& g = groups[i];
         if (!g.coarse || !g.d_maps || g.P <= 0 || !g.d_coarse || (g.fine && !g.d_fine) || !g.d_flags || (!g.ev_done && !sc->d_norm_sync)) return SLAM2D_E_BADARG;
         if (g.d_est ? g.est_stride < 3 : (!g.d_prev_pose || !g.d_heading || !g.d_est_out || !g.d_psi_out)) return SLAM2D_E_BADARG;
         if (commit && (!g.d_logw || !g.d_part)) return SLAM2D_E_BADARG;
-        if (commit && sc->abort_mask && !g.ev_matched) return SLAM2D_E_BADARG;
+        if (commit && sc->abort_mask && !g.ev_matched && !abort_on_device(*sc)) return SLAM2D_E_BADARG;
+        if (sc->h_ranges && (g.d_est || !g.d_pull)) return SLAM2D_E_BADARG;          // (the pull rides in the closed loop's prior launch)
+        if (commit && sc->h_next_ranges && (!sc->h_ranges || !g.d_pull_next || !device_merged(*sc))) return SLAM2D_E_BADARG;
     }
     if (commit) {
         const bool dm = device_merged(*sc);
@@ -4118,30 +4208,40 @@ static int groups_check(const Slam2dLidar* lidar, const Slam2dGroup* groups, int
         if (sc->merge && (!sc->d_logw_all || !sc->d_parts || !sc->d_w || !sc->d_stats || (!dm && !sc->ev_merged) || sc->n_local <= 0 || sc->n_parts <= 0 ||
                           sc->total_particles < sc->n_local)) return SLAM2D_E_BADARG;
         if (dm && sc->n_parts != G) return SLAM2D_E_BADARG;                  // (one partial per group, in group order)
-        if (sc->d_norm_sync && (G > 60 || sc->abort_mask)) return SLAM2D_E_BADARG;      // (2 + G words; an abort decision across groups needs the
-        //                                                                                  events: mixed scans would desynchronise the words)
+        if (sc->d_norm_sync && (G > 57 || (sc->abort_mask && !sc->match_seq))) return SLAM2D_E_BADARG;  // (2 + G words, 60-62 taken; an abort
+        //                                                             decision across groups needs the events or k_match_arrive / k_abort_gate)
         if (sc->abort_mask && (!sc->d_abort_flags || sc->n_abort_flags <= 0)) return SLAM2D_E_BADARG;
     }
     return 0;
 }
 
-static int group_match(const Slam2dLidar* lidar, const Slam2dGroup& g, const Slam2dScan& sc, const bool step = false) {
+static int group_match(const Slam2dLidar* lidar, const Slam2dGroup& g, const Slam2dScan& sc, const int G, const bool step = false) {
     hipStream_t s = (hipStream_t)g.stream;
     int rc = 0;
     if (sc.ev_inputs && (rc = (int)hipStreamWaitEvent(s, (hipEvent_t)sc.ev_inputs, 0))) return rc;
     const double* est = g.d_est;
     const double* psi = g.d_psi_cs;
     int stride = g.est_stride;
+    const double* ranges = sc.d_ranges;
+    const double* uniform = g.d_uniform;
     if (!est) {                                        // closed loop: the pose prior from the previous matched poses
-        if ((rc = slam2d_prior(g.d_prev_pose, sc.raw_theta, sc.prev_raw_theta, sc.has_turn, sc.raw_turn, g.d_heading, g.P, g.d_est_out,
-                               g.d_psi_out, g.stream))) return rc;
+        if (sc.h_ranges) {                             // ... and the scan's ranges pulled from pinned host memory in the same launch
+            if (!(sc.options & SLAM2D_MATCH_PRIOR_READY)) {             // (else: the previous commit did both, Slam2dScan.h_next_ranges)
+                k_prior_pull<<<1, 256, 0, s>>>(g.d_prev_pose, sc.raw_theta, sc.prev_raw_theta, sc.has_turn, sc.raw_turn, g.d_heading, g.P,
+                                               g.d_est_out, g.d_psi_out, sc.h_ranges, lidar->beams, g.d_pull);
+                if ((rc = launch_status())) return rc;
+            }
+            ranges = g.d_pull; uniform = g.h_uniform;
+        } else if ((rc = slam2d_prior(g.d_prev_pose, sc.raw_theta, sc.prev_raw_theta, sc.has_turn, sc.raw_turn, g.d_heading, g.P, g.d_est_out,
+                                      g.d_psi_out, g.stream))) return rc;
         est = g.d_est_out; psi = g.d_psi_out; stride = 3;
     }
-    if ((rc = slam2d_match(lidar, g.coarse, g.d_maps, g.P, est, stride, sc.d_ranges, sc.est_moving_dist, psi, g.d_uniform, g.d_coarse,
-                           g.d_flags, sc.options, g.stream))) return rc;
+    if ((rc = slam2d_match(lidar, g.coarse, g.d_maps, g.P, est, stride, ranges, sc.est_moving_dist, psi, uniform, g.d_coarse,
+                           g.d_flags, sc.options & ~SLAM2D_MATCH_PRIOR_READY, g.stream))) return rc;
     if (g.fine && (rc = slam2d_match(lidar, g.fine, g.d_maps, g.P, reinterpret_cast<const double*>(g.d_coarse),
-                                     (int32_t)(sizeof(Slam2dMatch) / sizeof(double)), sc.d_ranges, sc.est_moving_dist, nullptr, nullptr,
+                                     (int32_t)(sizeof(Slam2dMatch) / sizeof(double)), ranges, sc.est_moving_dist, nullptr, nullptr,
                                      g.d_fine, g.d_flags, 0u, g.stream))) return rc;
+    if (abort_on_device(sc) && !step) return rc;        // (the commit's gate kernel counts this group's match in)
     // (ev_matched serves a LATER commit call's abort decision; slam2d_groups_step has none, and an event packet between two kernels
     // of a group costs its chain 3 us)
     if (g.ev_matched && !step) rc = (int)hipEventRecord((hipEvent_t)g.ev_matched, s);
@@ -4152,7 +4252,12 @@ static int group_commit(const Slam2dLidar* lidar, const Slam2dGroup* groups, int
     const Slam2dGroup& g = groups[i];
     hipStream_t s = (hipStream_t)g.stream;
     int rc = 0;
-    if (sc.abort_mask)                                 // the abort is decided over every group's fault bits: wait for every group's match
+    if (sc.abort_mask && abort_on_device(sc)) {        // the abort is decided over every group's fault bits: wait for every group's match
+        if (G > 1) {
+            k_abort_gate<<<1, 64, 0, s>>>(sc.d_norm_sync, (uint32_t)G * sc.match_seq, g.d_flags);
+            if ((rc = launch_status())) return rc;
+        }
+    } else if (sc.abort_mask)
         for (int j = 0; j < G; ++j)
             if (j != i && (rc = (int)hipStreamWaitEvent(s, (hipEvent_t)groups[j].ev_matched, 0))) return rc;
     // the previous scan's merge works on the log-weights this launch rewrites: an event behind the merge launch -- or, with
@@ -4171,8 +4276,14 @@ static int group_commit(const Slam2dLidar* lidar, const Slam2dGroup* groups, int
     if (device_merge) {
         wj.parts_all = sc.d_parts; wj.logw_all = sc.d_logw_all; wj.n_all = sc.n_local; wj.total = (double)sc.total_particles;
         wj.w_all = sc.d_w; wj.stats_all = sc.d_stats;
+        if (sc.h_next_ranges && !g.d_est) {             // closed loop: the next scan's prior and ranges ride in this launch's block 0
+            wj.next_est = g.d_est_out; wj.next_psi = g.d_psi_out; wj.next_raw_theta = sc.next_raw_theta;
+            wj.next_prev_raw_theta = sc.next_prev_raw_theta; wj.next_raw_turn = sc.next_raw_turn; wj.next_has_turn = sc.next_has_turn;
+            wj.pull_src = sc.h_next_ranges; wj.pull_dst = g.d_pull_next; wj.pull_n = lidar->beams;
+        }
+        if (sc.h_seq) { wj.pack_d = sc.d_pack; wj.pack_h = sc.h_pack; wj.pack_n = sc.pack_doubles; wj.h_seq = sc.h_seq; wj.seq = sc.report_seq; }
     }
-    rc = launch_update(lidar, g.d_maps, g.P, reinterpret_cast<const double*>(fin), md, sc.d_ranges, nullptr, g.d_flags, wj, g.stream);
+    rc = launch_update(lidar, g.d_maps, g.P, reinterpret_cast<const double*>(fin), md, sc.h_ranges ? g.d_pull : sc.d_ranges, nullptr, g.d_flags, wj, g.stream);
     if (rc || (device_sync && !g.ev_done)) return rc;
     return (int)hipEventRecord((hipEvent_t)g.ev_done, s);
 }
@@ -4199,7 +4310,7 @@ static int groups_merge(const Slam2dGroup* groups, int32_t G, const Slam2dScan& 
 enum { JOB_MATCH = 1, JOB_COMMIT = 2, JOB_STEP = 3 };
 static int run_group_job(int kind, const Slam2dLidar* lidar, const Slam2dGroup* groups, int G, int i, const Slam2dScan& sc) {
     int rc = 0;
-    if (kind & JOB_MATCH) rc = group_match(lidar, groups[i], sc, kind == JOB_STEP);
+    if (kind & JOB_MATCH) rc = group_match(lidar, groups[i], sc, G, kind == JOB_STEP);
     if (!rc && (kind & JOB_COMMIT)) rc = group_commit(lidar, groups, G, i, sc);
     return rc;
 }
@@ -4286,36 +4397,82 @@ static GroupWorker* group_worker(int k) {
     }
     return pool[k];
 }
-static int run_groups(int kind, const Slam2dLidar* lidar, const Slam2dGroup* groups, int32_t G, const Slam2dScan* scan) {
-    // one call at a time: the workers are a process-wide pool indexed by group number (ctypes releases the GIL, so two Python
-    // threads could otherwise post into the same worker)
-    static std::mutex one_call;
-    std::lock_guard<std::mutex> serial(one_call);
+// One call at a time: the workers are a process-wide pool indexed by group number (ctypes releases the GIL, so two Python threads
+// could otherwise post into the same worker).  A call may be left RUNNING (slam2d_groups_match_begin: the caller goes on while the
+// workers issue the launches -- every group on a worker then, the descriptors copied so that the caller may rewrite its own); the
+// next slam2d_groups_* call, or slam2d_groups_join, waits for it first and returns its error.
+static std::mutex g_one_call;
+static struct { int G = 0; int rc = 0; Slam2dScan scan; Slam2dGroup groups[64]; } g_begun;
+static int join_locked() {
     const GroupPolicy& pol = group_policy();
-    if (!pol.threads || G < 2) {
-        int rc = 0;
+    int rc = g_begun.rc;
+    for (int i = 0; i < g_begun.G; ++i) {
+        GroupWorker* w = group_worker(i);
+        int spins = 0;
+        while (w->state.load(std::memory_order_acquire) != 2) {
+            if (pol.polite && ++spins > 256) sched_yield(); else __builtin_ia32_pause();
+        }
+        if (!rc) rc = w->rc;
+        w->state.store(0, std::memory_order_release);
+    }
+    g_begun.G = 0; g_begun.rc = 0;
+    return rc;
+}
+static void post(GroupWorker* g, int kind, const Slam2dLidar* lidar, const Slam2dGroup* groups, int G, int i, const Slam2dScan* scan, int dev) {
+    g->kind = kind; g->lidar = lidar; g->groups = groups; g->G = G; g->i = i; g->sc = scan; g->dev = dev;
+    g->state.store(1, std::memory_order_seq_cst);
+    if (g->sleeping.load()) { { std::lock_guard<std::mutex> lk(g->m); } g->cv.notify_one(); }
+}
+static int run_groups(int kind, const Slam2dLidar* lidar, const Slam2dGroup* groups, int32_t G, const Slam2dScan* scan, const bool leave_running = false) {
+    std::lock_guard<std::mutex> serial(g_one_call);
+    int rc = join_locked();
+    if (rc) return rc;
+    const GroupPolicy& pol = group_policy();
+    if (!pol.threads || (G < 2 && !leave_running)) {
         for (int i = 0; i < G && !rc; ++i) rc = run_group_job(kind, lidar, groups, G, i, *scan);
         return rc;
     }
     int dev = 0;
     (void)hipGetDevice(&dev);
-    GroupWorker* w[64];
-    for (int i = 1; i < G; ++i) {
-        GroupWorker* g = w[i] = group_worker(i - 1);
-        g->kind = kind; g->lidar = lidar; g->groups = groups; g->G = G; g->i = i; g->sc = scan; g->dev = dev;
-        g->state.store(1, std::memory_order_seq_cst);
-        if (g->sleeping.load()) { { std::lock_guard<std::mutex> lk(g->m); } g->cv.notify_one(); }
+    if (leave_running) {
+        g_begun.scan = *scan;
+        for (int i = 0; i < G; ++i) g_begun.groups[i] = groups[i];
+        for (int i = 0; i < G; ++i) post(group_worker(i), kind, lidar, g_begun.groups, G, i, &g_begun.scan, dev);
+        g_begun.G = G;
+        return 0;
     }
-    int rc = run_group_job(kind, lidar, groups, G, 0, *scan);
+    for (int i = 1; i < G; ++i) post(group_worker(i), kind, lidar, groups, G, i, scan, dev);
+    rc = run_group_job(kind, lidar, groups, G, 0, *scan);
     for (int i = 1; i < G; ++i) {
+        GroupWorker* w = group_worker(i);
         int spins = 0;
-        while (w[i]->state.load(std::memory_order_acquire) != 2) {
+        while (w->state.load(std::memory_order_acquire) != 2) {
             if (pol.polite && ++spins > 256) sched_yield(); else __builtin_ia32_pause();
         }
-        if (!rc) rc = w[i]->rc;
-        w[i]->state.store(0, std::memory_order_release);
+        if (!rc) rc = w->rc;
+        w->state.store(0, std::memory_order_release);
     }
     return rc;
+}
+
+int slam2d_groups_match_begin(const Slam2dLidar* lidar, const Slam2dGroup* groups, int32_t G, const Slam2dScan* scan) {
+    const int rc = groups_check(lidar, groups, G, scan, false);
+    return rc ? rc : run_groups(JOB_MATCH, lidar, groups, G, scan, true);
+}
+
+int slam2d_groups_join(void) {
+    std::lock_guard<std::mutex> serial(g_one_call);
+    return join_locked();
+}
+
+int slam2d_host_wait_seq(const uint32_t* h_seq, uint32_t want, double timeout_s) {
+    if (!h_seq) return SLAM2D_E_BADARG;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        if ((int32_t)(__atomic_load_n(h_seq, __ATOMIC_ACQUIRE) - want) >= 0) return 0;
+        __builtin_ia32_pause();
+        if ((spins & 1023u) == 1023u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return SLAM2D_E_TIMEOUT;
+    }
 }
 
 /* how slam2d_groups_* issue their groups on this host: out[0] = effective cores, out[1] = local ranks assumed, out[2] = 1 if a
@@ -4360,7 +4517,7 @@ int slam2d_weights_merge(double* d_logw, int32_t N, const double* d_parts, int32
 }
 
 int slam2d_norm_gate(uint32_t* d_norm_sync, int32_t G, void* stream) {
-    if (!d_norm_sync || G <= 0 || G > 60) return SLAM2D_E_BADARG;
+    if (!d_norm_sync || G <= 0 || G > 59) return SLAM2D_E_BADARG;
     k_norm_gate<<<1, 64, 0, (hipStream_t)stream>>>(d_norm_sync, G);
     return launch_status();
 }
@@ -4523,6 +4680,27 @@ void* slam2d_event_create(void) {
 void slam2d_event_destroy(void* event) { if (event) (void)hipEventDestroy((hipEvent_t)event); }
 int slam2d_event_record(void* event, void* stream) { return event ? (int)hipEventRecord((hipEvent_t)event, (hipStream_t)stream) : SLAM2D_E_BADARG; }
 int slam2d_stream_wait_event(void* stream, void* event) { return event ? (int)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0) : SLAM2D_E_BADARG; }
+
+// ---- a batch of streams for particle groups ----
+// Which HARDWARE queue a HIP stream sits on decides whether two groups overlap or take turns: the runtime keeps at most
+// GPU_MAX_HW_QUEUES of them and hands a new stream the least-referenced one.  Streams created one after the other, in one batch and
+// each used once at once, land on distinct queues (up to that limit); streams picked one by one out of a framework's round-robin pool
+// at different times do not (round 5: the closed loop in four groups ran 0.21 s with the first five pooled streams of a process and
+// 0.42-0.50 s with the pool's later ones; the bench's probe legs 0.12 against 0.25 ms per scan).
+__global__ void k_touch() {}
+int slam2d_streams_create(void** out, int32_t n) {
+    if (!out || n <= 0 || n > 64) return SLAM2D_E_BADARG;
+    for (int i = 0; i < n; ++i) {
+        hipStream_t st;
+        const hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        if (e != hipSuccess) { for (int j = 0; j < i; ++j) (void)hipStreamDestroy((hipStream_t)out[j]); return (int)e; }
+        out[i] = (void*)st;
+        k_touch<<<1, 64, 0, st>>>();                   // (first use = queue assignment, in creation order)
+    }
+    for (int i = 0; i < n; ++i) (void)hipStreamSynchronize((hipStream_t)out[i]);
+    return launch_status();
+}
+void slam2d_stream_destroy(void* stream) { if (stream) (void)hipStreamDestroy((hipStream_t)stream); }
 
 // ---- plain event timer ----
 struct Timer { hipEvent_t a, b; };

@@ -84,15 +84,21 @@ _GROUP_STREAMS = {}
 
 
 def group_streams(device, n):
-    """``n`` HIP streams for particle groups (+ the normaliser's), created ONCE per device and handed out again to every later
-    caller.  torch hands out its 32 pooled streams round-robin, and which hardware queue a pooled stream sits on decides how
-    well the groups overlap: the twelfth set of three fresh streams in one process measured 0.146 ms per step against 0.130 for
-    the first eleven (round 4, tools/exp_stream_modes.py), later sets in a long bench run 0.23.  The first streams of a process
-    are spread over distinct queues; everybody gets those."""
-    key = str(torch.device(device))
+    """``n`` HIP streams for particle groups (+ the normaliser's), created ONCE per device -- the first call makes a batch of
+    nine through the library (slam2d_streams_create: created and first used one after the other, so that they land on distinct
+    hardware queues) -- and handed out again to every later caller.  Which hardware queue a stream sits on decides how well the
+    groups overlap, and streams taken one by one out of torch's round-robin pool of 32 end up sharing queues: the twelfth set of
+    three fresh streams in one process measured 0.146 ms per step against 0.130 for the first eleven (round 4), the closed loop in
+    four groups 0.42-0.50 s against 0.21 s when two of its streams were taken from the pool later than the others (round 5)."""
+    dev = torch.device(device)
+    key = str(dev)
     have = _GROUP_STREAMS.setdefault(key, [])
     while len(have) < n:
-        have.append(torch.cuda.Stream(device))
+        k = max(9 if not have else 0, n - len(have))
+        out = (C.c_void_p * k)()
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().slam2d_streams_create(out, k), "slam2d_streams_create")
+        have.extend(torch.cuda.ExternalStream(int(p), device=dev) for p in out)
     return have[:n]
 
 

@@ -77,6 +77,18 @@ class MapView:
         return self._m.image(xIdx[0], xIdx[1], yIdx[0], yIdx[1], flipud=True, as_u8=as_u8).cpu().numpy()
 
 
+class _ReportWaiter:
+    """Stands where a torch Event stood in run()'s pending tuple: the scan's report is PUSHED into the pinned host pack by the
+    device (Slam2dScan.h_seq); synchronize() polls the sequence word from C (GIL released), bounded."""
+    __slots__ = ("ptr", "seq")
+
+    def __init__(self, ptr, seq):
+        self.ptr, self.seq = ptr, seq
+
+    def synchronize(self):
+        _lib.check(_lib.lib().slam2d_host_wait_seq(self.ptr, self.seq, 20.0), "slam2d_host_wait_seq")
+
+
 def _heading(dx, dy, dist):
     return math.acos(dx / dist) if dy > 0 else -math.acos(dx / dist)
 
@@ -126,10 +138,10 @@ class ParticleFilter:
     ``bnb``: score the pose cubes by branch and bound over 4x4 pose tiles (include/slam2d.h) -- None: wherever
     the cube is large enough for it to pay (engine.bnb_default), True / False: wherever applicable / nowhere.
     ``groups``: ``run()`` steps the particles in this many groups, each on its own HIP stream, joined only by the weight
-    normaliser (slam2d_groups_match / slam2d_groups_commit: what bench.py's open loop does) -- None: one (SLAM2D_FILTER_GROUPS
-    overrides): measured on the Intel log at 64 particles the closed loop gains nothing from two groups (0.253 s against 0.246 s for
-    910 scans; four: 0.43 s) -- unlike the open loop, every scan ends in a download the host waits for, so the groups cannot drift
-    apart and fill each other's gaps.  Results are those of one group."""
+    normaliser (slam2d_groups_match_begin / slam2d_groups_commit) -- None: ``auto_groups`` (SLAM2D_FILTER_GROUPS overrides).
+    Through round 4 the closed loop gained nothing from groups (ten event packets and two copy-engine transfers per scan tied the
+    groups together); round 5's grouped calls need none of them (include/slam2d.h, ABI 16) and the closed loop runs 10-12 % faster in
+    two or four groups than in one.  Results are those of one group."""
 
     def __init__(self, numParticles, ogParameters, smParameters, device=None, growable=True, rng=None,
                  total_particles=None, first_index=0, group=None, bnb=None, match_max=False, groups=None):
@@ -209,13 +221,28 @@ class ParticleFilter:
         self.prune_by_prior = env == "1" or (env != "0" and self.coarse.ntheta * self.coarse.nx ** 2 * beams >= BNB_MIN_WORK)
         self.step = 0
         env_g = os.environ.get("SLAM2D_FILTER_GROUPS", "")
-        g = int(env_g) if env_g.isdigit() else (groups if groups is not None else 1)
+        g = int(env_g) if env_g.isdigit() else (groups if groups is not None else self.auto_groups(P, self.sharded))
         self.n_groups = g if (g > 1 and P % g == 0 and not self.sharded) else 1
+        # run() goes through the grouped calls even with ONE group (their event-free closed loop: ranges pulled, report pushed:
+        # 0.2215 s against 0.2284 s for the 910 Intel scans at 64 particles); SLAM2D_FILTER_GROUPED1=0: the one-stream calls
+        self.grouped_single = os.environ.get("SLAM2D_FILTER_GROUPED1", "1") == "1" and not self.sharded
         self._grp = None                                 # streams, events, level views: built by the first grouped run()
         # run(): scans redone step by step (discarded speculative match); resample(): all / those that moved any state
         self.stats = {"redo": 0, "aborted": 0, "reissued": 0, "step_by_step": 0, "resamples": 0, "state_moving_resamples": 0}
 
     # ---- odometry prior (Algorithm/FastSlam.py:77-106) ----
+    @staticmethod
+    def auto_groups(P, sharded=False):
+        """Particle groups of run() when the caller names none: four from 32 particles (a multiple of 4), two from 16, where the
+        host has cores for the threads that issue them (slam2d_group_policy); else one.  Round 5, 64 particles x the 910 Intel
+        scans, legs interleaved in one process: one group 0.2284 s, one through the event-free calls 0.2215, two 0.2064, four
+        0.2043 (the event path of rounds 3-4: 0.238 in two, 0.42-0.60 in four)."""
+        if sharded or not _lib.group_policy()["threads"]:
+            return 1
+        if P >= 32 and P % 4 == 0:
+            return 4
+        return 2 if (P >= 16 and P % 2 == 0) else 1
+
     def _raw_odometry(self, raw, prev_raw=None, prev_raw_heading="same"):
         """The particle-independent part of updateEstimatedPose: distance and heading of the raw
         odometry step (:81-104).  Returns (estMovingDist, rawMovingTheta, has_turn, raw_turn)."""
@@ -331,7 +358,7 @@ class ParticleFilter:
         # pending = (count, reading, raw_heading, event, state of the random stream before the scan's uniforms) of the scan in flight
         resamples, pending = [], None
         events = [torch.cuda.Event(), torch.cuda.Event()]
-        grouped = self.n_groups > 1 and self.lazy_field and not self.sharded
+        grouped = (self.n_groups > 1 or self.grouped_single) and self.lazy_field and not self.sharded
         if grouped and self._grp is None:
             self._setup_groups()
 
@@ -371,7 +398,7 @@ class ParticleFilter:
 
         # the next scan's pose prior rides in this scan's commit (slam2d_scan_commit_next) when the next reading is at hand:
         # prior_ready = count of the scan whose prior the last commit wrote (its match then skips the prior's launch)
-        fold_prior = not grouped and not self.sharded and os.environ.get("SLAM2D_FILTER_FOLD_PRIOR", "1") != "0"
+        fold_prior = (not grouped or self._grp.devsync) and not self.sharded and os.environ.get("SLAM2D_FILTER_FOLD_PRIOR", "1") != "0"
         prior_ready = [None]
 
         def plain(count, reading):
@@ -390,6 +417,7 @@ class ParticleFilter:
             """Throw away what is in flight: its fault flags and its draws from the random stream."""
             prior_ready[0] = None
             if grouped:
+                self._join_groups()
                 torch.cuda.synchronize(self.device)
                 self._grp.flags2.zero_()
                 self._grp.active = False
@@ -419,8 +447,12 @@ class ParticleFilter:
         retried = (None, 0)                                  # (count of the scan last re-issued, how often)
         if not isinstance(readings, (list, tuple)):
             readings = _ReadingWindow(readings)              # a generator (a live sensor) stays lazy: the loop steps back two items at most
+
+        def has_reading(k):
+            return (k < len(readings)) if isinstance(readings, (list, tuple)) else readings.has(k)
+
         i = 0
-        while (i < len(readings)) if isinstance(readings, (list, tuple)) else readings.has(i):
+        while has_reading(i):
             count, reading = first_count + i, readings[i]
             i += 1
             if count == 1 or (pending is None and self.prev_raw is None) or not self.lazy_field:
@@ -451,7 +483,7 @@ class ParticleFilter:
             state_before = rng_state
             if grouped:
                 self._stage_inputs_group(parity, np.asarray(reading['range'], dtype=np.float64), None if self.match_max else self._draw_uniforms())
-                self._enqueue_match_groups(reading, prev_raw, dist, has_turn, turn, parity)
+                self._enqueue_match_groups(reading, prev_raw, dist, has_turn, turn, parity, prior_ready[0] == count)
             else:
                 self._stage_inputs(parity, np.asarray(reading['range'], dtype=np.float64), None if self.match_max else self._draw_uniforms())
                 self._enqueue_match(reading, prev_raw, dist, has_turn, turn, prior_ready[0] == count)   # speculative: scan count-1 not seen yet
@@ -504,14 +536,14 @@ class ParticleFilter:
                 discard_speculation(rng_state)
                 plain(count, reading)
                 continue
+            nxt = None
+            if fold_prior and has_reading(i):
+                _, _, n_has_turn, n_turn = self._raw_odometry(readings[i], reading, raw_heading)
+                nxt = (float(readings[i]['theta']), float(reading['theta']), int(n_has_turn), float(n_turn))
+                prior_ready[0] = count + 1
             if grouped:
-                ev = self._enqueue_commit_groups(abort_mask, parity)
+                ev = self._enqueue_commit_groups(abort_mask, parity, nxt, readings[i]['range'] if nxt is not None else None)
             else:
-                nxt = None
-                if fold_prior and i < len(readings):
-                    _, _, n_has_turn, n_turn = self._raw_odometry(readings[i], reading, raw_heading)
-                    nxt = (float(readings[i]['theta']), float(reading['theta']), int(n_has_turn), float(n_turn))
-                    prior_ready[0] = count + 1
                 self._enqueue_commit(abort_mask, nxt)
                 ev = events[parity]
                 ev.record()
@@ -571,7 +603,32 @@ class ParticleFilter:
         sc.norm_stream, sc.ev_merged, sc.ev_inputs = C.c_void_p(grp.norm.cuda_stream), grp.ev_merged, grp.ev_inputs
         sc.merge = 1
         grp.merged_once, grp.active = False, False
+        # Round 5: the grouped closed loop WITHOUT events and copies (include/slam2d.h, ABI 16).  Every group's prior launch pulls the
+        # scan's inputs from the pinned staging buffer; the abort decision over all groups' fault bits sits behind an arrival counter
+        # and a one-wave gate kernel; the normaliser merges on the device; the block that finishes a scan pushes the report into the
+        # pinned host pack and publishes the scan's number, which the host polls; the match is issued by worker threads while this
+        # thread goes on (slam2d_groups_match_begin).  SLAM2D_FILTER_EVENTS=1: the event path of rounds 3-4.
+        grp.devsync = os.environ.get("SLAM2D_FILTER_EVENTS", "0") != "1"
+        if grp.devsync:
+            B = self.lidar.beams
+            grp.sync = torch.zeros(64, dtype=torch.int32, device=dev)
+            grp.h_seq = torch.zeros(16, dtype=torch.int32).pin_memory()
+            grp.d_pull = torch.zeros((2, G, B), dtype=torch.float64, device=dev)      # (scan parity: a commit leaves the next scan's ranges)
+            grp.gate_seq = grp.report_seq = 0
+            for g in range(G):
+                grp.c[g].ev_matched = grp.c[g].ev_done = None
+            sc.ev_inputs = sc.ev_merged = sc.norm_stream = None
+            sc.d_norm_sync = grp.sync.data_ptr()
+            sc.h_seq, sc.h_pack, sc.d_pack = grp.h_seq.data_ptr(), self._h_pack.data_ptr(), self._d_pack.data_ptr()
+            sc.pack_doubles = self._d_pack.numel()
+            torch.cuda.synchronize(dev)
         self._grp = grp
+
+    def _join_groups(self):
+        """Wait for the worker threads of a match left running (slam2d_groups_match_begin) -- before the device is synchronised or
+        anything that match reads is touched."""
+        if self._grp is not None and self._grp.devsync:
+            _lib.check(_lib.lib().slam2d_groups_join(), "slam2d_groups_join")
 
     def _bind_groups(self, parity):
         """Per-scan pointers of the group descriptors (resampling replaces pose / heading tensors, growth the map descriptors)."""
@@ -596,6 +653,14 @@ class ParticleFilter:
             cg.d_flag_snapshot = self._d_flagsnap.data_ptr() + p0 * 4
         sc = grp.scan
         sc.d_ranges = d_in.data_ptr()
+        if grp.devsync:
+            h = self._h_in[parity].data_ptr()
+            sc.d_ranges, sc.h_ranges = None, h
+            for g in range(self.n_groups):
+                cg = grp.c[g]
+                cg.d_uniform = None
+                cg.h_uniform = None if self.match_max else h + (B + g * per) * 8
+                cg.d_pull, cg.d_pull_next = grp.d_pull[parity, g].data_ptr(), grp.d_pull[parity ^ 1, g].data_ptr()
         sc.d_abort_flags, sc.n_abort_flags = flags.data_ptr(), self.numParticles
         sc.d_logw_all, sc.d_w, sc.d_stats = self.d_logw.data_ptr(), self.d_w.data_ptr(), self.d_stats.data_ptr()
 
@@ -603,6 +668,7 @@ class ParticleFilter:
         """Before anything that runs on the main stream over all particles (the call-by-call path, a resample, a growth): wait
         for the group streams."""
         if self._grp is not None and self._grp.active:
+            self._join_groups()
             torch.cuda.synchronize(self.device)
             self._grp.active = False
 
@@ -613,27 +679,44 @@ class ParticleFilter:
         h.numpy()[:B] = ranges
         if uniforms is not None:
             h.numpy()[B:] = uniforms
-        self._grp.d_in[parity].copy_(h, non_blocking=True)
+        if not self._grp.devsync:                        # (device-synced groups pull from the pinned buffer themselves)
+            self._grp.d_in[parity].copy_(h, non_blocking=True)
 
-    def _enqueue_match_groups(self, reading, prev_raw, dist, has_turn, turn, parity):
+    def _enqueue_match_groups(self, reading, prev_raw, dist, has_turn, turn, parity, prior_ready=False):
         eng, grp, L = self.engine, self._grp, _lib.lib()
+        self._join_groups()
         eng.refresh_bits()
         for lv in (self.coarse, self.fine):
             if lv.c.occ_gen >= 254:                      # the stamp wraps: the occupancy images are zeroed -- with every stream idle
                 torch.cuda.synchronize(self.device)
             lv.next_generation()
         self._bind_groups(parity)
-        L.slam2d_event_record(grp.ev_inputs, _stream())  # behind the staging copy (and a bit refresh) on the main stream
         sc = grp.scan
+        if grp.devsync:
+            # nothing orders the group streams behind the main stream any more (the event path's ev_inputs did): whatever the main
+            # stream still holds -- a bit refresh, an image zeroed, a growth, a step-by-step scan -- is finished first (one query
+            # per scan; idle in the steady state)
+            ms = torch.cuda.current_stream(self.device)
+            if not ms.query():
+                ms.synchronize()
+            sc.match_seq = grp.gate_seq or 1
+        else:
+            L.slam2d_event_record(grp.ev_inputs, _stream())  # behind the staging copy (and a bit refresh) on the main stream
         sc.est_moving_dist, sc.raw_theta, sc.prev_raw_theta = float(dist), float(reading['theta']), float(prev_raw['theta'])
         sc.has_turn, sc.raw_turn = int(has_turn), float(turn)
         sc.options = _lib.MATCH_PRUNE_BY_PRIOR if self.prune_by_prior else 0
+        if prior_ready and grp.devsync:                  # (the previous commit wrote this scan's prior and pulled its ranges)
+            sc.options |= _lib.MATCH_PRIOR_READY
         sc.abort_mask = 0
-        _lib.check(L.slam2d_groups_match(C.byref(eng.lidar_c), grp.c, self.n_groups, C.byref(sc)), "slam2d_groups_match")
+        if grp.devsync:
+            _lib.check(L.slam2d_groups_match_begin(C.byref(eng.lidar_c), grp.c, self.n_groups, C.byref(sc)), "slam2d_groups_match_begin")
+        else:
+            _lib.check(L.slam2d_groups_match(C.byref(eng.lidar_c), grp.c, self.n_groups, C.byref(sc)), "slam2d_groups_match")
         grp.active = True
 
-    def _enqueue_commit_groups(self, abort_mask, parity):
+    def _enqueue_commit_groups(self, abort_mask, parity, next_prior=None, next_ranges=None):
         eng, grp, L = self.engine, self._grp, _lib.lib()
+        self._join_groups()                              # (the match's launches are all enqueued before anything below synchronises)
         # A promotion to 64-bit cells re-allocates the promoted maps' cells and replaces the descriptor array, on the main stream, while the
         # group streams may still run this scan's match over the old ones: they are idled BEFORE anything is freed (the caching
         # allocator could hand the old blocks to the very allocations that follow).  The test is _before_update's own.
@@ -648,6 +731,24 @@ class ParticleFilter:
         sc.abort_mask, sc.wait_merged = int(abort_mask), int(grp.merged_once)
         if os.environ.get("SLAM2D_FILTER_NO_ABORT") == "1":      # timing experiment only (a window leaving a map is then fatal)
             sc.abort_mask = 0
+        if grp.devsync:
+            if sc.abort_mask and self.n_groups > 1:      # (this commit's gate kernels count themselves in: G per such call)
+                grp.gate_seq = ((grp.gate_seq + 1) & 0xFFFFFFFF) or 1
+            sc.match_seq = grp.gate_seq or 1
+            if next_prior is not None:
+                # the next scan's prior and ranges ride in this commit (Slam2dScan.h_next_ranges): its ranges go into the OTHER
+                # staging buffer now -- the one that scan's uniforms will follow into
+                hn = self._h_in[parity ^ 1]
+                hn.numpy()[:self.lidar.beams] = np.asarray(next_ranges, dtype=np.float64)
+                sc.h_next_ranges = hn.data_ptr()
+                sc.next_raw_theta, sc.next_prev_raw_theta, sc.next_has_turn, sc.next_raw_turn = next_prior
+            else:
+                sc.h_next_ranges = None
+            grp.report_seq = (grp.report_seq + 1) & 0xFFFFFFFF
+            sc.report_seq = grp.report_seq
+            _lib.check(L.slam2d_groups_commit(C.byref(eng.lidar_c), grp.c, self.n_groups, C.byref(sc)), "slam2d_groups_commit")
+            grp.merged_once = True
+            return _ReportWaiter(grp.h_seq.data_ptr(), grp.report_seq)
         _lib.check(L.slam2d_groups_commit(C.byref(eng.lidar_c), grp.c, self.n_groups, C.byref(sc)), "slam2d_groups_commit")
         grp.merged_once = True
         with torch.cuda.stream(grp.norm):                # behind the merge: report, weights, variance and the fault-bit snapshot

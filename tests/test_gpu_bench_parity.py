@@ -171,3 +171,37 @@ def test_benchmarked_config5_slice_matches_oracle(bench):
     different XCD classes against the oracle (two-level matchScan, draw, update)."""
     hot = _run_against_oracle(bench, "config5", 128, [3, 70, 125], n_scans=1, n_worlds=4, groups=2)
     assert hot.coarse.bnb and hot.coarse.bnb_levels == 2
+
+
+def test_device_side_waits_are_bounded(bench):
+    """The groups' normaliser waits on the device (Slam2dScan.d_norm_sync); a producer that never arrives must end as the fatal
+    SLAM2D_F_SYNC_TIMEOUT after the 2 s bound, not as a hung GPU: (a) the sharded path's gate kernel with nobody to count,
+    (b) a group's normaliser block told to expect a merge that never happens (its step still completes, flagged)."""
+    import ctypes as C
+    import time
+    import torch
+    L = E._lib.lib()
+    sync = torch.zeros(64, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    E._lib.check(L.slam2d_norm_gate(C.c_void_p(sync.data_ptr()), 1, E._stream()), "slam2d_norm_gate")
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    got = sync.cpu().numpy()
+    assert 1.0 < dt < 10.0 and got[62] == 1 and got[0] == 0, (dt, got[:4].tolist(), int(got[62]))
+
+    cfg = bench.WORKLOADS["config2"]
+    scen = bench.Scenario(cfg, 16, 3, seed=0)
+    hot = bench.make_hot_path(cfg, 16, scen, torch.device("cuda", 0), 2)
+    if not (hot.c_step and hot.device_merge):
+        pytest.skip("the device-side merge is switched off in this environment")
+    hot.step(0)
+    assert not (hot.take_flags() & E._lib.FATAL_FLAGS).any()
+    hot.norm_sync[2] += 1                         # group 0's next normaliser block now waits for a merge nobody will publish
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    hot.step(1)
+    with pytest.raises(E._lib.Slam2dError, match="particle 0: a device-side wait"):      # (the bit is fatal: the first group's word 0)
+        hot.take_flags()
+    dt = time.perf_counter() - t0
+    assert 1.0 < dt < 10.0, dt

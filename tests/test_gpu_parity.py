@@ -377,23 +377,35 @@ def _pipelined_run_against(pkg, z, readings, **kw):
 @pytest.mark.parametrize("golden", ["flow_fastslam_growth.npz", "flow_fastslam_long.npz"])
 def test_pipelined_driver_reproduces_reference_runs(pkg, intel_readings, golden, monkeypatch):
     pf = _pipelined_run_against(pkg, load_golden(golden), intel_readings)
+    # (round 5: one group goes through the grouped, event-free calls -- ranges pulled from pinned memory, the next prior and ranges in
+    # the commit, the report pushed by the device)
+    assert pf._grp is not None and pf._grp.devsync and pf.n_groups == 1
     # scans voided on the device (a window left its map) went through the pipeline again after the growth -- for the coarse
     # windows from the host's poses, for the fine windows from the coarse poses the voided commit reports -- not step by step
     assert pf.stats["aborted"] > 0 and pf.stats["reissued"] > 0, pf.stats
+    # ... the one-stream calls of rounds 3-4 (what a sharded filter still runs) give the same run
+    monkeypatch.setenv("SLAM2D_FILTER_GROUPED1", "0")
+    pf1 = _pipelined_run_against(pkg, load_golden(golden), intel_readings)
+    assert pf1._grp is None and pf1.stats["aborted"] == pf.stats["aborted"] and pf1.stats["reissued"] == pf.stats["reissued"]
     # ... and round 3's handling (the voided scan and its successor step by step) gives the same run
     monkeypatch.setenv("SLAM2D_FILTER_REISSUE", "0")
     pf0 = _pipelined_run_against(pkg, load_golden(golden), intel_readings)
     assert pf0.stats["reissued"] == 0 and pf0.stats["step_by_step"] > pf.stats["step_by_step"]
 
 
-@pytest.mark.parametrize("golden,groups", [("flow_fastslam_growth.npz", 3), ("flow_fastslam_long.npz", 2), ("flow_fastslam_long.npz", 3)])
-def test_grouped_pipelined_driver_reproduces_reference_runs(pkg, intel_readings, golden, groups):
+@pytest.mark.parametrize("golden,groups,events", [("flow_fastslam_growth.npz", 3, False), ("flow_fastslam_long.npz", 2, False),
+                                                  ("flow_fastslam_long.npz", 3, False), ("flow_fastslam_long.npz", 2, True)])
+def test_grouped_pipelined_driver_reproduces_reference_runs(pkg, intel_readings, golden, groups, events, monkeypatch):
     """The pipelined driver with the particles in groups on their own HIP streams (slam2d_groups_match / slam2d_groups_commit:
     one library call each per scan, the groups joined only by the normaliser's merge; the abort of a scan whose window left a
     map decided over ALL groups' fault bits): the reference's results scan for scan -- growth inside speculated scans, natural and
     forced resamples (every one a full stop of the group streams), the random stream's state at the end."""
+    # events: the event path of rounds 3-4 (SLAM2D_FILTER_EVENTS=1: staging copy + ev_inputs, ev_matched across groups, the merge
+    # launch on a third stream, a download) -- round 5's default needs none of them (Slam2dScan.h_ranges / match_seq / h_seq)
+    if events:
+        monkeypatch.setenv("SLAM2D_FILTER_EVENTS", "1")
     pf = _pipelined_run_against(pkg, load_golden(golden), intel_readings, groups=groups)
-    assert pf.n_groups == groups and pf._grp is not None and pf._grp.merged_once
+    assert pf.n_groups == groups and pf._grp is not None and pf._grp.merged_once and pf._grp.devsync == (not events)
     assert pf.stats["aborted"] > 0 or golden != "flow_fastslam_long.npz"
 
 

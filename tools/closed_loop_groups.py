@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Closed loop (BASELINE config 3, 64 particles x 910 scans) in G particle groups: seconds per leg.  python tools/closed_loop_groups.py [G ...]"""
-import importlib, os, sys, time, math
+"""Closed loop (BASELINE config 3, 64 particles x 910 scans) in G particle groups: seconds per leg, the group counts INTERLEAVED
+(boxes of the pool and the first seconds of a process differ by up to 25 %: legs of one count run back to back say little).
+python tools/closed_loop_groups.py [G ...]   (G = 0: one group through the grouped, event-free calls)"""
+import importlib, os, statistics, sys, time, math
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import numpy as np, torch
@@ -10,12 +12,18 @@ readings = dataio.read_npz(os.path.join(REPO, "tests", "golden", "intel_gfs.npz"
 u = 0.02
 ogP = [50.0, 50.0, readings[0], u, math.pi, 10, 180, 5 * u]
 smP = [1.4, 0.25, 2, 0.1, 0.25, 0.3, 0.15, 5]
-for G in [int(a) for a in sys.argv[1:]] or [1, 2]:
-    best = None
-    for rep in range(3):
-        pf = pkg.ParticleFilter(64, ogP, smP, rng=np.random.RandomState(0), groups=G)
+Gs = [int(a) for a in sys.argv[1:]] or [1, 2]
+legs = {G: [] for G in Gs}
+for rep in range(int(os.environ.get("REPS", "4"))):
+    for G in Gs:
+        os.environ["SLAM2D_FILTER_GROUPED1"] = "1" if G == 0 else "0"
+        pf = pkg.ParticleFilter(64, ogP, smP, rng=np.random.RandomState(0), groups=max(1, G))
         torch.cuda.synchronize(); t0 = time.perf_counter()
         pf.run(readings)
-        torch.cuda.synchronize(); el = time.perf_counter() - t0
-        best = el if best is None else min(best, el)
-    print(f"groups {pf.n_groups}: best of 3 {best:.4f} s = {910 / best:.0f} scans/s  (aborted {pf.stats.get('aborted', 0)}, redo {pf.stats['redo']})", flush=True)
+        torch.cuda.synchronize(); legs[G].append(time.perf_counter() - t0)
+        stats = dict(pf.stats)
+        del pf
+for G in Gs:
+    v = legs[G]
+    print(f"groups {G}: legs {' '.join(f'{x:.4f}' for x in v)} s; best {min(v):.4f} s = {910 / min(v):.0f} scans/s, median {statistics.median(v):.4f} s = "
+          f"{910 / statistics.median(v):.0f} scans/s  (aborted {stats.get('aborted', 0)}, redo {stats['redo']})", flush=True)

@@ -37,6 +37,28 @@ def timed_up(self, reading, count):
 
 
 filt.ParticleFilter.updateParticles = timed_up
+_rw = filt._ReportWaiter.synchronize          # (round 5: the device-synced groups wait for a pushed report, not for an event)
+
+
+def timed_rw(self):
+    t0 = time.perf_counter()
+    _rw(self)
+    waited[0] += time.perf_counter() - t0
+    waited[1] += 1
+
+
+filt._ReportWaiter.synchronize = timed_rw
+joined = [0.0, 0]
+_join = filt.ParticleFilter._join_groups
+
+
+def timed_join(self):
+    t0 = time.perf_counter()
+    _join(self)
+    joined[0] += time.perf_counter() - t0; joined[1] += 1
+
+
+filt.ParticleFilter._join_groups = timed_join
 grow = [0.0, 0]
 _mat = engine.MapState._materialise
 
@@ -64,11 +86,12 @@ engine.ParticleEngine.refresh_maps = timed_refresh
 for G in [int(a) for a in sys.argv[1:]] or [1, 2]:
     for rep in range(3):
         pf = pkg.ParticleFilter(64, ogP, smP, rng=np.random.RandomState(0), groups=G)
-        waited[:] = [0.0, 0]; slow[:] = [0.0, 0]; grow[:] = [0.0, 0]; refr[:] = [0.0, 0]
+        waited[:] = [0.0, 0]; slow[:] = [0.0, 0]; grow[:] = [0.0, 0]; refr[:] = [0.0, 0]; joined[:] = [0.0, 0]
         torch.cuda.synchronize(); t0 = time.perf_counter()
         pf.run(readings)
         torch.cuda.synchronize(); el = time.perf_counter() - t0
         print(f"groups {pf.n_groups}: {el:.4f} s = {910 / el:.0f} scans/s; host waited {waited[0]:.4f} s in {waited[1]} report waits "
               f"({1e3 * waited[0] / max(1, waited[1]):.3f} ms each), issued for {1e3 * (el - waited[0]) / 910:.3f} ms per scan "
               f"(aborted {pf.stats.get('aborted', 0)}, redo {pf.stats['redo']}, step by step {pf.stats['step_by_step']}); step-by-step scans: {slow[1]} in {slow[0]:.4f} s, "
-              f"of which {grow[1]} map re-allocations {grow[0]:.4f} s (host); {refr[1]} descriptor refreshes {refr[0]:.4f} s", flush=True)
+              f"of which {grow[1]} map re-allocations {grow[0]:.4f} s (host); {refr[1]} descriptor refreshes {refr[0]:.4f} s; "
+              f"{joined[1]} joins of the issuing threads {joined[0]:.4f} s", flush=True)
