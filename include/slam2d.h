@@ -231,6 +231,8 @@ typedef struct {
                                 occ / tilemask byte means "occupied" only when it equals occ_gen, so nothing is
                                 cleared; the caller passes a value unused since the buffers were last zeroed
                                 (count 1, 2, ... 254, zero the buffers, start again at 1) */
+    uint32_t* arrive;        /* NULL, or a device word the wave that writes a particle's Slam2dMatch adds 1 to behind it (ABI 16):
+                                slam2d_groups_match sets it on its own copy of a scan's last level (Slam2dScan.match_seq) */
 } Slam2dLevel;
 
 /* Result of one level for one particle. */
@@ -536,12 +538,13 @@ typedef struct {
                                     pulls the ranges and Slam2dGroup.h_uniform into Slam2dGroup.d_pull -- no staging copy, no ev_inputs.
                                     The caller alternates two host buffers between scans (a group may still be pulling scan s
                                     while the host stages s + 1) */
-    uint32_t match_seq;          /* != 0 (needs d_norm_sync): the number of slam2d_groups_commit calls with abort_mask since d_norm_sync
-                                    was zeroed, this one included.  Every group's commit starts with a one-wave gate kernel that counts
-                                    the group in (word 61: its match has finished) and waits (bounded) for G * match_seq arrivals: the
-                                    abort_mask decision over all groups' fault bits without ev_matched, and d_norm_sync's device-side
-                                    merge stays usable with abort_mask (a voided scan has no normaliser: nobody arrives there, the
-                                    words stay in step) */
+    uint32_t match_seq;          /* != 0 (needs d_norm_sync): the number of slam2d_groups_match[_begin] calls with match_seq != 0 since
+                                    d_norm_sync was zeroed, this one included, passed AGAIN to the commit of the same scan.  In the
+                                    match, the wave that writes a particle's result at the last level counts the particle in (word
+                                    61); every group's commit starts with a one-wave gate kernel that waits (bounded) for
+                                    n_abort_flags * match_seq arrivals: the abort_mask decision over all groups' fault bits without
+                                    ev_matched, and d_norm_sync's device-side merge stays usable with abort_mask (a voided scan has no
+                                    normaliser: nobody arrives there, the words stay in step).  n_abort_flags = all groups' particles */
     uint32_t report_seq;         /* with h_seq: the value to publish for this scan (the caller counts its commits) */
     uint32_t* h_seq;             /* PINNED HOST word, or NULL.  With d_norm_sync and merge == 1: the block that finishes the scan for
                                     all groups (the merging normaliser block; for a voided scan the last group's block 0, counted in

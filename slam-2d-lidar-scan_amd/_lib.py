@@ -99,7 +99,7 @@ class Slam2dLevel(C.Structure):
                 ("ring", _vp), ("prune_state", _vp), ("ring_cap", C.c_int32),
                 ("gmin", _vp), ("gmin2", _vp), ("pcells", _vp), ("bounds", _vp), ("tile_pmax", _vp), ("bnb_best", _vp),
                 ("gmin3d", _vp), ("p3cells", _vp), ("bounds1", _vp), ("seed_key", _vp),
-                ("beam_xy", _vp), ("sync", _vp), ("bnb", C.c_int32), ("ep_group", C.c_int32), ("occ_gen", C.c_int32)]
+                ("beam_xy", _vp), ("sync", _vp), ("bnb", C.c_int32), ("ep_group", C.c_int32), ("occ_gen", C.c_int32), ("arrive", _vp)]
 
 
 class Slam2dMatch(C.Structure):

@@ -1615,6 +1615,7 @@ __device__ __forceinline__ void select_argmax_from_partials(const Slam2dLevel& l
         m.pick = pick;
         m.argmax = me.i;
         out[p] = m;
+        if (lv.arrive) __hip_atomic_fetch_add(lv.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (Slam2dScan.match_seq)
     }
 }
 
@@ -2189,6 +2190,7 @@ __global__ __launch_bounds__(64) void k_select(Slam2dLevel lv, int chunks, int R
         m.pick = pick;
         m.argmax = me.i;
         out[p] = m;
+        if (lv.arrive) __hip_atomic_fetch_add(lv.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (Slam2dScan.match_seq)
     }
 }
 
@@ -3062,6 +3064,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_exact_select(Slam2dLevel lv, con
         m.pick = pick;
         m.argmax = Mi_s[0];
         out[p] = m;
+        if (lv.arrive) __hip_atomic_fetch_add(lv.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (Slam2dScan.match_seq)
     }
     DBG_CLOCK(13, p == 0);
 }
@@ -3638,14 +3641,16 @@ __global__ __launch_bounds__(256) void k_prior_pull(const double* __restrict__ p
     for (int i = threadIdx.x; i < B; i += blockDim.x) d_pull[i] = __builtin_nontemporal_load(h_ranges + i);
     for (int p = threadIdx.x; p < P; p += blockDim.x) prior_one(prev, heading, p, raw_theta, prev_raw_theta, has_turn, raw_turn, est, psi_cs);
 }
-// Abort decision across groups without events (Slam2dScan.match_seq, ABI 16): every group's commit starts with k_abort_gate, ONE
-// wave that counts its group in (word 61 of the sync block: group-matches finished since the words were zeroed -- the gate sits
-// behind the group's match on its stream) and waits -- bounded -- until all G groups of this scan have: the update launch behind it
-// then reads every group's fault bits as it did behind the events.  No deadlock: a commit call is issued after the match call of
-// ALL groups, and only one wave per group waits.
+// Abort decision across groups without events (Slam2dScan.match_seq, ABI 16): the wave that writes a particle's result at the scan's
+// LAST level counts the particle in (Slam2dLevel.arrive = word 61 of the sync block: particle-matches finished since the words were
+// zeroed); every group's commit starts with k_abort_gate, ONE wave that waits -- bounded -- until all particles of all groups of this
+// scan's match call have been counted: the update launch behind it then reads every group's fault bits as it did behind the events.
+// No deadlock, whatever hardware queues the groups' streams share: a commit call is issued after the match call of ALL groups has
+// been issued completely, so everything a gate waits for sits in front of it in every queue; and only one wave per group waits.
+// (A gate that counted its own group in -- one launch less per match -- deadlocked with eight groups on eight hardware queues, one
+// of them the default stream's: two groups shared a queue and the first gate waited for the one queued behind it.)
 __global__ __launch_bounds__(64) void k_abort_gate(uint32_t* nsync, uint32_t want, uint32_t* flags) {
     if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(&nsync[61], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the match's kernels have ended: their stores are out)
         const unsigned long long t0 = wall_clock64();
         while ((int)(__hip_atomic_load(&nsync[61], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
             __builtin_amdgcn_s_sleep(8);
@@ -3653,6 +3658,9 @@ __global__ __launch_bounds__(64) void k_abort_gate(uint32_t* nsync, uint32_t wan
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
+}
+__global__ __launch_bounds__(64) void k_match_arrive(uint32_t* nsync, uint32_t n) {       // (single-level matches: no level to carry the word)
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(&nsync[61], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ void k_post_match(const Slam2dMatch* __restrict__ fine, const Slam2dMatch* __restrict__ coarse, int P,
@@ -4238,10 +4246,18 @@ static int group_match(const Slam2dLidar* lidar, const Slam2dGroup& g, const Sla
     }
     if ((rc = slam2d_match(lidar, g.coarse, g.d_maps, g.P, est, stride, ranges, sc.est_moving_dist, psi, uniform, g.d_coarse,
                            g.d_flags, sc.options & ~SLAM2D_MATCH_PRIOR_READY, g.stream))) return rc;
-    if (g.fine && (rc = slam2d_match(lidar, g.fine, g.d_maps, g.P, reinterpret_cast<const double*>(g.d_coarse),
-                                     (int32_t)(sizeof(Slam2dMatch) / sizeof(double)), ranges, sc.est_moving_dist, nullptr, nullptr,
-                                     g.d_fine, g.d_flags, 0u, g.stream))) return rc;
-    if (abort_on_device(sc) && !step) return rc;        // (the commit's gate kernel counts this group's match in)
+    const bool count_in = abort_on_device(sc) && !step && G > 1;       // (one group: its stream orders its commit behind its match)
+    if (g.fine) {
+        Slam2dLevel last = *g.fine;                    // (the level whose selecting waves count their particles in for the commit's gate)
+        if (count_in) last.arrive = sc.d_norm_sync + 61;
+        if ((rc = slam2d_match(lidar, &last, g.d_maps, g.P, reinterpret_cast<const double*>(g.d_coarse),
+                               (int32_t)(sizeof(Slam2dMatch) / sizeof(double)), ranges, sc.est_moving_dist, nullptr, nullptr,
+                               g.d_fine, g.d_flags, 0u, g.stream))) return rc;
+    } else if (count_in) {
+        k_match_arrive<<<1, 64, 0, s>>>(sc.d_norm_sync, (uint32_t)g.P);
+        if ((rc = launch_status())) return rc;
+    }
+    if (abort_on_device(sc) && !step) return rc;
     // (ev_matched serves a LATER commit call's abort decision; slam2d_groups_step has none, and an event packet between two kernels
     // of a group costs its chain 3 us)
     if (g.ev_matched && !step) rc = (int)hipEventRecord((hipEvent_t)g.ev_matched, s);
@@ -4254,7 +4270,7 @@ static int group_commit(const Slam2dLidar* lidar, const Slam2dGroup* groups, int
     int rc = 0;
     if (sc.abort_mask && abort_on_device(sc)) {        // the abort is decided over every group's fault bits: wait for every group's match
         if (G > 1) {
-            k_abort_gate<<<1, 64, 0, s>>>(sc.d_norm_sync, (uint32_t)G * sc.match_seq, g.d_flags);
+            k_abort_gate<<<1, 64, 0, s>>>(sc.d_norm_sync, (uint32_t)sc.n_abort_flags * sc.match_seq, g.d_flags);
             if ((rc = launch_status())) return rc;
         }
     } else if (sc.abort_mask)

@@ -138,7 +138,8 @@ class ParticleFilter:
     ``bnb``: score the pose cubes by branch and bound over 4x4 pose tiles (include/slam2d.h) -- None: wherever
     the cube is large enough for it to pay (engine.bnb_default), True / False: wherever applicable / nowhere.
     ``groups``: ``run()`` steps the particles in this many groups, each on its own HIP stream, joined only by the weight
-    normaliser (slam2d_groups_match_begin / slam2d_groups_commit) -- None: ``auto_groups`` (SLAM2D_FILTER_GROUPS overrides).
+    normaliser (slam2d_groups_match_begin / slam2d_groups_commit) -- None: ``auto_groups`` (SLAM2D_FILTER_GROUPS overrides); at
+    most six (the runtime keeps eight hardware queues; groups that share one take turns).
     Through round 4 the closed loop gained nothing from groups (ten event packets and two copy-engine transfers per scan tied the
     groups together); round 5's grouped calls need none of them (include/slam2d.h, ABI 16) and the closed loop runs 10-12 % faster in
     two or four groups than in one.  Results are those of one group."""
@@ -222,6 +223,8 @@ class ParticleFilter:
         self.step = 0
         env_g = os.environ.get("SLAM2D_FILTER_GROUPS", "")
         g = int(env_g) if env_g.isdigit() else (groups if groups is not None else self.auto_groups(P, self.sharded))
+        if g > 6:                                        # (more groups than hardware queues take turns: eight measured 0.91 s against 0.20)
+            g = 4 if P % 4 == 0 else 2
         self.n_groups = g if (g > 1 and P % g == 0 and not self.sharded) else 1
         # run() goes through the grouped calls even with ONE group (their event-free closed loop: ranges pulled, report pushed:
         # 0.2215 s against 0.2284 s for the 910 Intel scans at 64 particles); SLAM2D_FILTER_GROUPED1=0: the one-stream calls
@@ -699,6 +702,8 @@ class ParticleFilter:
             ms = torch.cuda.current_stream(self.device)
             if not ms.query():
                 ms.synchronize()
+            if self.n_groups > 1:                        # (every particle's selecting wave counts itself in: P per such call)
+                grp.gate_seq = ((grp.gate_seq + 1) & 0xFFFFFFFF) or 1
             sc.match_seq = grp.gate_seq or 1
         else:
             L.slam2d_event_record(grp.ev_inputs, _stream())  # behind the staging copy (and a bit refresh) on the main stream
@@ -732,9 +737,7 @@ class ParticleFilter:
         if os.environ.get("SLAM2D_FILTER_NO_ABORT") == "1":      # timing experiment only (a window leaving a map is then fatal)
             sc.abort_mask = 0
         if grp.devsync:
-            if sc.abort_mask and self.n_groups > 1:      # (this commit's gate kernels count themselves in: G per such call)
-                grp.gate_seq = ((grp.gate_seq + 1) & 0xFFFFFFFF) or 1
-            sc.match_seq = grp.gate_seq or 1
+            sc.match_seq = grp.gate_seq or 1             # (the match call's: its particles are what this commit's gates wait for)
             if next_prior is not None:
                 # the next scan's prior and ranges ride in this commit (Slam2dScan.h_next_ranges): its ranges go into the OTHER
                 # staging buffer now -- the one that scan's uniforms will follow into

@@ -13,15 +13,18 @@ u = 0.02
 ogP = [50.0, 50.0, readings[0], u, math.pi, 10, 180, 5 * u]
 smP = [1.4, 0.25, 2, 0.1, 0.25, 0.3, 0.15, 5]
 Gs = [int(a) for a in sys.argv[1:]] or [1, 2]
+NP = int(os.environ.get("P", "64"))
 legs = {G: [] for G in Gs}
 for rep in range(int(os.environ.get("REPS", "4"))):
     for G in Gs:
-        os.environ["SLAM2D_FILTER_GROUPED1"] = "1" if G == 0 else "0"
-        pf = pkg.ParticleFilter(64, ogP, smP, rng=np.random.RandomState(0), groups=max(1, G))
+        os.environ["SLAM2D_FILTER_GROUPED1"] = "1" if G == 0 else "0"      # (G = 1: the one-stream calls of rounds 3-4)
+        pf = pkg.ParticleFilter(NP, ogP, smP, rng=np.random.RandomState(0), groups=max(1, G))
         torch.cuda.synchronize(); t0 = time.perf_counter()
         pf.run(readings)
         torch.cuda.synchronize(); legs[G].append(time.perf_counter() - t0)
         stats = dict(pf.stats)
+        if os.environ.get("VERBOSE"):
+            print(f"  rep {rep} groups {G}: {legs[G][-1]:.4f} s", flush=True)
         del pf
 for G in Gs:
     v = legs[G]

@@ -10,7 +10,7 @@ readings = dataio.read_npz(os.path.join(REPO, "tests", "golden", "intel_gfs.npz"
 u = 0.02
 ogP = [50.0, 50.0, readings[0], u, math.pi, 10, 180, 5 * u]
 smP = [1.4, 0.25, 2, 0.1, 0.25, 0.3, 0.15, 5]
-G = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+G = int(sys.argv[1]) if len(sys.argv) > 1 else None      # (None: ParticleFilter.auto_groups)
 pf = pkg.ParticleFilter(64, ogP, smP, rng=np.random.RandomState(0), groups=G)
 pf.run(readings[:20])
 pf = pkg.ParticleFilter(64, ogP, smP, rng=np.random.RandomState(0), groups=G)

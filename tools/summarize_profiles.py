@@ -124,7 +124,7 @@ for wl in ("config2", "ref2level", "config5"):
     head = (f"rocprofv3 --pmc {{FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum}} --kernel-trace -- python bench.py --workload {wl} --steps 12 --warmup 6 "
             "--repeats 1 --no-cpu-baseline --no-variants\nper-launch means after the warm-up launches; FETCH/WRITE_SIZE are KB counters (x1024 here); "
             f"slam2d.hip sha256 {sha[:16]}\nlaunches/step is relative to k_grid_update (one launch per scan and particle group: bench.py steps its particles in "
-            f"groups on separate streams, so a 64-particle scan is two launch sequences of 32)\n"
+            f"groups on separate streams, so a 64-particle scan is four launch sequences of 16 -- config 5: two of 64)\n"
             f"HBM bytes of one launch sequence (all kernels of one scan of one particle group): {step_total / 1e6:.1f} MB\n")
     open(f"profiles/{ROUND}_pmc_{wl}.txt", "w").write(head + "\n".join(lines) + "\n")
     print(head + "\n".join(lines))
