@@ -963,20 +963,25 @@ def config3_closed_loop(P, device):
     def leg(force=(), groups=None, P=P):
         pf = pkg.ParticleFilter(P, ogP, smP, device=device, rng=np.random.RandomState(0), groups=groups)
         torch.cuda.synchronize()
+        ms0 = torch.cuda.memory_stats(device)
         t0 = time.perf_counter()
         resamples = pf.run(readings, force_resample=set(force))      # the pipelined driver: same decisions as the per-call loop
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        ms1 = torch.cuda.memory_stats(device)
+        # (hipMalloc / hipFree calls inside the leg: a growth re-allocation the caching allocator cannot serve costs ~0.5 ms)
+        dev_allocs = [int(ms1.get(k, 0) - ms0.get(k, 0)) for k in ("num_device_alloc", "num_device_free")]
         m = pf.engine.maps[int(np.argmax(pf.weights))]
         return dict(value=P * len(readings) / el, unit="particle-scans/s", scans=len(readings), particles=P, seconds=el,
                     scans_per_sec=len(readings) / el, resamples=len(resamples), state_moving_resamples=pf.stats["state_moving_resamples"],
                     scans_voided_and_repeated=pf.stats.get("aborted", 0), scans_redone=pf.stats["redo"], scans_reissued_in_pipeline=pf.stats["reissued"],
-                    scans_step_by_step=pf.stats["step_by_step"], particle_groups=pf.n_groups,
+                    scans_step_by_step=pf.stats["step_by_step"], particle_groups=pf.n_groups, device_allocs_and_frees=dev_allocs,
                     final_map=[m.rows, m.cols])
     leg()                                              # (first leg: allocator warm-up, 1.6 GB of maps)
     legs = sorted((leg() for _ in range(3)), key=lambda r: r["seconds"])      # three timed legs, the median reported: a leg holds 143
     out = legs[1]                                                              # growth re-allocations and the host's per-scan work, and
     out["seconds_of_each_leg"] = [round(r["seconds"], 5) for r in legs]        # boxes of the pool differ by 25 % on it
+    out["device_allocs_and_frees_of_each_leg"] = [r["device_allocs_and_frees"] for r in legs]
     out["note"] = ("closed loop through ParticleFilter.run(): host decisions (growth, resampling); the particles in groups on their own streams "
                    "(ParticleFilter.auto_groups), each scan's ranges pulled from pinned host memory and its report pushed there by the device (no copy, "
                    "no event); scan s is enqueued before scan s-1's results are read; a scan voided on the device (a search window left its map) is "
@@ -993,7 +998,7 @@ def config3_closed_loop(P, device):
     # of 64 maps, the stop of the group streams and the redone speculative scan are inside the timed figure
     forced = leg(force=range(100, len(readings), 100))
     out["forced_resample_every_100"] = {k: v for k, v in forced.items() if k in ("value", "seconds", "scans_per_sec", "resamples",
-                                                                                "state_moving_resamples", "scans_redone")}
+                                                                                "state_moving_resamples", "scans_redone", "device_allocs_and_frees")}
     # the closed loop at other particle counts (one leg each after a warm-up leg: 16 / 256 particles x 910 scans)
     out["p_sweep"] = {}
     for PP in (16, 256):

@@ -85,7 +85,7 @@ def timed_refresh(self):
 engine.ParticleEngine.refresh_maps = timed_refresh
 for G in [int(a) for a in sys.argv[1:]] or [1, 2]:
     for rep in range(3):
-        pf = pkg.ParticleFilter(64, ogP, smP, rng=np.random.RandomState(0), groups=G)
+        pf = pkg.ParticleFilter(64, ogP, smP, rng=np.random.RandomState(0), groups=G or None)
         waited[:] = [0.0, 0]; slow[:] = [0.0, 0]; grow[:] = [0.0, 0]; refr[:] = [0.0, 0]; joined[:] = [0.0, 0]
         torch.cuda.synchronize(); t0 = time.perf_counter()
         pf.run(readings)
