@@ -354,7 +354,15 @@ class ParticleFilter:
         ``force_resample``: scan counts after which to resample regardless (tests).  ``on_scan(count, self, unbalanced)``
         is called once a scan's results are on the host.  Returns the list of (count, resample indices)."""
         with pinned_stream():
-            return self._run(readings, first_count, force_resample, on_scan)
+            try:
+                return self._run(readings, first_count, force_resample, on_scan)
+            finally:
+                # whatever ended the run (a fault raised from a scan's report, the caller's on_scan): no worker thread may still be
+                # issuing a match over descriptors this object owns
+                try:
+                    self._join_groups()
+                except _lib.Slam2dError:
+                    pass
 
     def _run(self, readings, first_count, force_resample, on_scan):
         eng, P = self.engine, self.numParticles
