@@ -4484,9 +4484,11 @@ int slam2d_groups_join(void) {
 int slam2d_host_wait_seq(const uint32_t* h_seq, uint32_t want, double timeout_s) {
     if (!h_seq) return SLAM2D_E_BADARG;
     const auto t0 = std::chrono::steady_clock::now();
+    const GroupPolicy& pol = group_policy();
+    const bool polite = pol.polite || !pol.threads;        // (few cores per rank: the runtime's and RCCL's threads need them too)
     for (unsigned spins = 0;; ++spins) {
         if ((int32_t)(__atomic_load_n(h_seq, __ATOMIC_ACQUIRE) - want) >= 0) return 0;
-        __builtin_ia32_pause();
+        if (polite && (spins & 63u) == 63u) sched_yield(); else __builtin_ia32_pause();
         if ((spins & 1023u) == 1023u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return SLAM2D_E_TIMEOUT;
     }
 }

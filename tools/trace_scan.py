@@ -1,22 +1,27 @@
 #!/usr/bin/env python3
-"""One scan of a rocprofv3 kernel trace as a timeline (steady state, from one k_grid_update wave of launches to the next) plus
-per-kernel averages and per-queue sums.  python tools/trace_scan.py <k_kernel_trace.csv> [scan index from the middle]"""
+"""One stretch of a rocprofv3 kernel trace as a timeline per hardware queue, plus per-kernel averages and per-queue sums.
+python tools/trace_scan.py <k_kernel_trace.csv> [window us] [offset us into the busiest second half]"""
 import collections, csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "?"), r["Kernel_Name"].split("(")[0].replace("void ", "")[:30]) for r in rows)
-ev = ev[len(ev) // 3:]
+ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "?"), r["Kernel_Name"].split("(")[0].replace("void ", "")[:26]) for r in rows)
+win = float(sys.argv[2]) * 1e3 if len(sys.argv) > 2 else 480e3
 avg = collections.defaultdict(list)
-for s, e, q, n in ev:
+for s, e, q, n in ev[len(ev) // 3:]:
     avg[n].append(e - s)
-print("per kernel: " + "; ".join(f"{n} x{len(v)} {1e-3 * sum(v) / len(v):.1f} us (max {1e-3 * max(v):.0f})" for n, v in sorted(avg.items(), key=lambda kv: -sum(kv[1]))[:16]))
-perq = collections.Counter()
-for s, e, q, n in ev:
-    perq[q] += e - s
-print("per queue busy us:", {q: round(1e-3 * v) for q, v in perq.items()}, " wall us:", round(1e-3 * (ev[-1][1] - ev[0][0])))
-ups = [i for i, x in enumerate(ev) if x[3].startswith("k_grid_update")]
-nq = max(1, len({ev[i][2] for i in ups}))
-mid = ups[(len(ups) // 2 // nq) * nq + int(sys.argv[2]) * nq if len(sys.argv) > 2 else (len(ups) // 2 // nq) * nq]
-end = ups[ups.index(mid) + nq] if ups.index(mid) + nq < len(ups) else len(ev) - 1
-t0 = ev[mid][0]
-for s, e, q, n in ev[mid:end + nq]:
-    print(f"  q{q:>3} {1e-3 * (s - t0):9.1f} us  +{1e-3 * (e - s):7.1f}  {n}")
+print("per kernel: " + "; ".join(f"{n} x{len(v)} {1e-3 * sum(v) / len(v):.1f} us" for n, v in sorted(avg.items(), key=lambda kv: -sum(kv[1]))[:14]))
+ups = [x for x in ev if x[3].startswith("k_grid_update")]
+mid = ups[(3 * len(ups)) // 4]                       # an update launch three quarters into the trace: steady state of the last leg
+t0 = mid[0] + (float(sys.argv[3]) * 1e3 if len(sys.argv) > 3 else 0.0)
+sel = [x for x in ev if t0 <= x[0] < t0 + win]
+qs = sorted({x[2] for x in sel})
+print(f"window {win * 1e-3:.0f} us from an update launch; queues {qs}")
+for q in qs:
+    prev_end = None
+    line = []
+    for s, e, qq, n in sel:
+        if qq != q:
+            continue
+        gap = "" if prev_end is None else f"(+{1e-3 * (s - prev_end):.1f})"
+        line.append(f"{gap}{n.replace('k_', '')}@{1e-3 * (s - t0):.0f}+{1e-3 * (e - s):.0f}")
+        prev_end = e
+    print(f" q{q}: " + " ".join(line))
