@@ -522,7 +522,7 @@ typedef struct {
     int32_t merge;               /* 1: issue the merge here.  0: the caller does (sharded: an all-gather of the partials comes
                                     first); norm_stream is still ordered behind every group's ev_done */
     uint32_t* d_norm_sync;       /* NULL, or 64 device words, ZEROED ONCE, kept for the life of these groups (ABI 15): with merge == 1 and
-                                    no abort_mask the groups' normaliser blocks merge among themselves on the device -- the block
+                                    no abort_mask (ABI 16: or abort_mask with match_seq) the groups' normaliser blocks merge among themselves on the device -- the block
                                     that arrives last merges for all -- and a group's next update waits for that inside its own
                                     normaliser block: no merge launch, no norm_stream, no ev_merged / ev_done / wait_merged (they may
                                     be NULL / 0; ev_done is still recorded when given).  d_w / d_stats / the log-weights are final
