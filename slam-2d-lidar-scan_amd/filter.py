@@ -139,7 +139,7 @@ class ParticleFilter:
     the cube is large enough for it to pay (engine.bnb_default), True / False: wherever applicable / nowhere.
     ``groups``: ``run()`` steps the particles in this many groups, each on its own HIP stream, joined only by the weight
     normaliser (slam2d_groups_match_begin / slam2d_groups_commit) -- None: ``auto_groups`` (SLAM2D_FILTER_GROUPS overrides); at
-    most six (the runtime keeps eight hardware queues; groups that share one take turns).
+    most four (the GPU runs four compute queues side by side, whatever GPU_MAX_HW_QUEUES says: a fifth group makes them take turns).
     Through round 4 the closed loop gained nothing from groups (ten event packets and two copy-engine transfers per scan tied the
     groups together); round 5's grouped calls need none of them (include/slam2d.h, ABI 16) and the closed loop runs 10-12 % faster in
     two or four groups than in one.  Results are those of one group."""
@@ -223,8 +223,8 @@ class ParticleFilter:
         self.step = 0
         env_g = os.environ.get("SLAM2D_FILTER_GROUPS", "")
         g = int(env_g) if env_g.isdigit() else (groups if groups is not None else self.auto_groups(P, self.sharded))
-        if g > 6:                                        # (more groups than hardware queues take turns: eight measured 0.91 s against 0.20)
-            g = 4 if P % 4 == 0 else 2
+        if g > 4:                                        # (the GPU runs four queues side by side: five groups and more take turns --
+            g = 4 if P % 4 == 0 else 2                   #  open loop 0.265-0.30 ms per scan against 0.10-0.11, closed loop 0.91 s against 0.20)
         self.n_groups = g if (g > 1 and P % g == 0 and not self.sharded) else 1
         # run() goes through the grouped calls even with ONE group (their event-free closed loop: ranges pulled, report pushed:
         # 0.2215 s against 0.2284 s for the 910 Intel scans at 64 particles); SLAM2D_FILTER_GROUPED1=0: the one-stream calls
