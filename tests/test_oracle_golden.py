@@ -292,3 +292,59 @@ def test_synthetic_level_exact(name):
     else:
         assert np.array_equal(cube[::4, ::2, ::2], z["cube_sub"]) and cube.sum() == z["cube_sum"]
     assert [matched["x"], matched["y"], matched["theta"]] == list(z["matched"])
+
+
+# ---- corners the reference's code defines but its data never reaches (tests/golden/make_golden_edges.py) ----
+def _edge_grid(z, pre):
+    unit, R, fov, beams, wall = z[pre + "cfg"][-5:]
+    return so.GridOracle(1, 1, {"x": 0.0, "y": 0.0}, float(unit), float(fov), int(beams), float(R), float(wall))
+
+
+@pytest.mark.parametrize("case", ["outside", "inside"])
+def test_nan_first_argmax_exact(case):
+    """A heading prior with NaNs (arccos argument rounded past 1, Utils/ScanMatcher_OGBased.py:105-108): the cube carries the
+    NaNs where the reference's does, argmax (:134) is the FIRST NaN, the confidence (:141) is NaN, the matched pose is that
+    pose's -- with the NaN poses outside and inside the motion prior's ring."""
+    z = load_golden("edges.npz")
+    prob = codec.decode_field(z["nan_prob_cls"], z["nan_prob_floor"], z["nan_prob_other"])
+    sm = so.MatcherOracle(_edge_grid(z, "nan_"), *z["nan_sm"][:7], int(z["nan_sm"][7]))
+    ex, ey, eth = z["nan_est"]
+    pre = f"nan_{case}_"
+    matched, cube, conf = sm.searchToMatch(prob, ex, ey, eth, z["nan_ranges"], z["nan_xr"], z["nan_yr"], z["nan_sm"][0], z["nan_sm"][1],
+                                           float(z["nan_cfg"][1]), float(z[pre + "dist"]), float(z[pre + "psi"]), fineSearch=False, matchMax=True)
+    want = z[pre + "cube"]
+    assert np.isnan(want).any() and np.array_equal(np.isnan(cube), np.isnan(want))
+    assert np.array_equal(cube, want, equal_nan=True)
+    pick = int(cube.argmax())
+    assert pick == int(z[pre + "pick"]) and np.isnan(cube.reshape(-1)[pick]) and not np.isnan(cube.reshape(-1)[:pick]).any()
+    assert np.isnan(conf) and np.isnan(z[pre + "conf"])
+    assert [matched["x"], matched["y"], matched["theta"]] == list(z[pre + "matched"])
+    # the NaN poses are where the generator's search said (same for every angle)
+    nanp = np.argwhere(np.isnan(cube[0]))
+    assert np.array_equal(nanp, z[pre + "nan_poses"])
+
+
+@pytest.mark.parametrize("case", ["cols", "rows_cols", "coarse"])
+def test_wrapped_field_index_exact(case):
+    """Occupied cells in a window's first columns / rows of a map that grew >= 2 times on the high side: their stored
+    coordinates lie more than a cell below the window's edge, the truncated field index is negative and NumPy wraps it to the
+    field's LAST columns / rows (Utils/ScanMatcher_OGBased.py:36-37).  The oracle's field equals the reference's bit for bit."""
+    z = load_golden("edges.npz")
+    og = _edge_grid(z, "wrap_")
+    og.visited, og.total = codec.unpack_counts(z["wrap_map"])
+    og.X, og.Y = z["wrap_X"].copy(), z["wrap_Y"].copy()
+    og.mapXLim, og.mapYLim = [og.X[0], og.X[-1]], [og.Y[0], og.Y[-1]]
+    sm = so.MatcherOracle(og, *z["wrap_sm"][:7], int(z["wrap_sm"][7]))
+    pre = f"wrap_{case}_"
+    ex, ey, step, sigma, miss = z[pre + "args"]
+    fy, fx = sm.occupied_field_cells(*sm.frame_geometry(ex, ey, step)[:2], step)
+    assert int(((fx < 0) | (fy < 0)).sum()) == int(z[pre + "wrapped_cells"]) > 0
+    assert [fx.min(), fy.min()] == list(z[pre + "min_index"])
+    xr, yr, prob = sm.frameSearchSpace(ex, ey, step, sigma, miss)
+    want = codec.decode_field(z[pre + "prob_cls"], z[pre + "prob_floor"], z[pre + "prob_other"])
+    assert og.growth_log == []
+    assert np.array_equal(np.array(xr), z[pre + "xr"]) and np.array_equal(np.array(yr), z[pre + "yr"])
+    assert np.array_equal(prob, want)
+    # the wrap is visible: without it (indices clipped away) the last columns / rows would stay at the floor
+    far = (want[:, -3:] == 0).sum() + (want[-3:, :] == 0).sum()
+    assert far > 0
