@@ -76,3 +76,51 @@ if __name__ == "__main__":
         if "--raw" in sys.argv:
             for k, c in m.items():
                 print(k, {a: round(b, 1) for a, b in c.items()})
+
+
+def write_profiles(tag, rnd):
+    """profiles/<rnd>_<tag>_kernel_stats.csv (rocprofv3 --stats, copied), _pmc.txt (HBM traffic per launch), _counters.txt (SQ / TCP / TA
+    per launch + the derived columns of table())."""
+    import shutil, hashlib, glob as g
+    fs = g.glob(os.path.join(ROOT, f"gpurun_out/kstat_{tag}/**/k_kernel_stats.csv"), recursive=True)
+    if fs:
+        shutil.copy(fs[0], os.path.join(ROOT, f"profiles/{rnd}_{tag}_kernel_stats.csv"))
+    t, m, dur = table(tag)
+    wl, p = tag.rsplit("_p", 1)
+    sha = hashlib.sha256(open(os.path.join(ROOT, "slam-2d-lidar-scan_amd/csrc/slam2d.hip"), "rb").read()).hexdigest()[:16]
+    # standalone durations: the counter passes serialise the kernels (one group's launch at a time)
+    alone = collections.defaultdict(list)
+    for f in g.glob(os.path.join(ROOT, f"gpurun_out/pmc6/{tag}/fetch/**/pmc_kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            alone[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    head = (f"rocprofv3 --pmc <one pass per line of tools/gpu_r6.sh pmcp> --kernel-trace -- python bench.py --workload {wl} --particles {p} --steps 12 --warmup 6 --repeats 1 "
+            f"--no-cpu-baseline --no-variants\nper-launch means after the warm-up launches; slam2d.hip sha256 {sha}\n"
+            f"a launch serves one particle group = {int(p) // 2} particles (bench.py runs {p} particles per GPU in two groups on two streams)\n")
+    lines = [head, "HBM traffic per launch (FETCH_SIZE / WRITE_SIZE are KB counters; gfx950: HBM bytes = 2 * FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md)",
+             f"{'kernel':28s} {'FETCH MB':>9s} {'WRITE MB':>9s} {'HBM MB':>8s} {'L2 hit %':>8s} {'us alone':>9s} {'us in step':>10s} {'GB/s alone':>10s}"]
+    tot = 0.0
+    for k, c in sorted(m.items(), key=lambda kv: -dur.get(kv[0], (0, 0, 0))[0] * dur.get(kv[0], (0, 0, 0))[1]):
+        if c["_launches"] < 10:
+            continue
+        f_, w_ = c.get("FETCH_SIZE", 0) * 1024, c.get("WRITE_SIZE", 0) * 1024
+        hit, miss = c.get("TCC_HIT_sum", 0), c.get("TCC_MISS_sum", 0)
+        a = alone.get(k, [])
+        a = sum(a[len(a) // 3:]) / max(1, len(a[len(a) // 3:])) if a else float("nan")
+        tot += 2 * f_ + w_
+        lines.append(f"{k[:28]:28s} {f_ / 1e6:9.2f} {w_ / 1e6:9.2f} {(2 * f_ + w_) / 1e6:8.2f} {100 * hit / (hit + miss) if hit + miss else float('nan'):8.1f} {a:9.1f} "
+                     f"{dur.get(k, (float('nan'),))[0]:10.1f} {(2 * f_ + w_) / a / 1e3 if a == a else 0:10.0f}")
+    lines.append(f"HBM bytes of one launch sequence (one scan of one group of {int(p) // 2} particles): {tot / 1e6:.1f} MB = {tot / (int(p) // 2) / 1e3:.0f} KB per particle-scan")
+    open(os.path.join(ROOT, f"profiles/{rnd}_{tag}_pmc.txt"), "w").write("\n".join(lines) + "\n")
+    cl = [head, "derived per launch (us / % from rocprofv3 --kernel-trace --stats of the same command, two groups overlapping; /w = per wave; cyc/w = SQ_WAVE_CYCLES (quad-cycles) per wave;",
+          "valu_util = SQ_ACTIVE_INST_VALU / (4 SQ_BUSY_CU_CYCLES); lines/ld = TCP_TOTAL_CACHE_ACCESSES / SQ_INSTS_VMEM_RD; TA busy% = TA_BUSY_avr / GRBM_GUI_ACTIVE)", t, "",
+          "raw counter means per launch"]
+    for k, c in m.items():
+        if c["_launches"] >= 10:
+            cl.append(f"{k[:34]:34s} " + "  ".join(f"{a} {b:.5g}" for a, b in sorted(c.items()) if not a.startswith("_")))
+    open(os.path.join(ROOT, f"profiles/{rnd}_{tag}_counters.txt"), "w").write("\n".join(cl) + "\n")
+
+
+if __name__ == "__main__" and "--write" in sys.argv:
+    rnd = sys.argv[sys.argv.index("--write") + 1]
+    for tag in [a for a in sys.argv[1:] if not a.startswith("--") and a != rnd]:
+        write_profiles(tag, rnd)
