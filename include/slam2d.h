@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define SLAM2D_ABI_VERSION 16
+#define SLAM2D_ABI_VERSION 17
 #define SLAM2D_SPOKE_BAND 16         /* radial band width of the beam-major spoke table, in cells */
 
 /* library error codes (negative; positive values are hipError_t) */
@@ -233,6 +233,13 @@ typedef struct {
                                 (count 1, 2, ... 254, zero the buffers, start again at 1) */
     uint32_t* arrive;        /* NULL, or a device word the wave that writes a particle's Slam2dMatch adds 1 to behind it (ABI 16):
                                 slam2d_groups_match sets it on its own copy of a scan's last level (Slam2dScan.match_seq) */
+    uint8_t* gmin2b;         /* NULL, or [P][4*tmax][g2b_pitch] (ABI 17): gmin2 >> 12 in bytes (cost >> 24), written beside gmin2.  With it
+                                (bnb == 1) the tile bounds of a particle are taken by ONE block that stages this image in LDS
+                                (k_bound_lds: 2 LDS cycles per gather instead of ~20 L1 tag lookups); the bounds are looser by
+                                < 2^-7 per cell, so a few more tiles are scored exactly -- results unchanged */
+    int32_t g2b_pitch;       /* row pitch of gmin2b in bytes: a multiple of 16, >= 4*tmax, (g2b_pitch / 4) mod 32 in [5, 13] or
+                                [19, 27] (the tile rows of a lane group then fall on distinct LDS banks) */
+    int32_t reserved0;
 } Slam2dLevel;
 
 /* Result of one level for one particle. */

@@ -42,7 +42,7 @@ MAX_BLUR_RADIUS = 16
 MAX_BEAMS = 2048
 SPOKE_BAND = 16
 SYNC_WORDS = 4
-ABI_VERSION = 16
+ABI_VERSION = 17
 MATCH_PRUNE_BY_PRIOR = 1
 MATCH_PRIOR_READY = 2
 PRUNE_MARGIN = 40.0
@@ -99,7 +99,8 @@ class Slam2dLevel(C.Structure):
                 ("ring", _vp), ("prune_state", _vp), ("ring_cap", C.c_int32),
                 ("gmin", _vp), ("gmin2", _vp), ("pcells", _vp), ("bounds", _vp), ("tile_pmax", _vp), ("bnb_best", _vp),
                 ("gmin3d", _vp), ("p3cells", _vp), ("bounds1", _vp), ("seed_key", _vp),
-                ("beam_xy", _vp), ("sync", _vp), ("bnb", C.c_int32), ("ep_group", C.c_int32), ("occ_gen", C.c_int32), ("arrive", _vp)]
+                ("beam_xy", _vp), ("sync", _vp), ("bnb", C.c_int32), ("ep_group", C.c_int32), ("occ_gen", C.c_int32), ("arrive", _vp),
+                ("gmin2b", _vp), ("g2b_pitch", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class Slam2dMatch(C.Structure):

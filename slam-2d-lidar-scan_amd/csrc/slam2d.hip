@@ -998,6 +998,7 @@ __device__ __forceinline__ void gmin2_entry(const Slam2dLevel& lv, const uint32_
     const int Y1 = min(Y + 1, gp - 1), X1 = min(X + 1, gp - 1);
     const uint32_t v = min(min(G[(size_t)Y * gp + X], G[(size_t)Y * gp + X1]), min(G[(size_t)Y1 * gp + X], G[(size_t)Y1 * gp + X1]));
     G2[(size_t)Y * gp + X] = v >> 12;
+    if (lv.gmin2b) lv.gmin2b[((size_t)p * gp + Y) * lv.g2b_pitch + X] = (uint8_t)(v >> 24);      // (k_bound_lds)
     if (lv.bnb == 2) {
         // two-level bounds: the 8x8 cell window of an 8x8-pose tile lies inside blocks Y..Y+2 x X..X+2; stored decimated by
         // two in four phase planes, so that the tiles of one row (block stride 2) are contiguous
@@ -2383,6 +2384,171 @@ __global__ __launch_bounds__(64 * BOUND_GROUP) void k_bound(Slam2dLevel lv, int 
     DBG_CLOCK(3, b == 0);
     if (lane == 0 && val > -INFINITY) atomicMax(&lv.bnb_best[p], order_bits(val));
     DBG_CLOCK(4, b == 0);
+}
+
+__device__ __forceinline__ int wave64_min_i32(int v) {
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+}
+// The seed of one (particle, theta): tile `seed` (the one with the largest bound) scored exactly by one wave; its best score
+// raises lv.bnb_best[p].  (k_bound carries the same lines inline.)
+__device__ __forceinline__ void bound_seed_exact(const Slam2dLevel& lv, const int p, const int sby, const int sbx, const int* __restrict__ cl,
+                                                 const int K, const double inv) {
+    const int lane = threadIdx.x & 63;
+    const int nx = 2 * lv.ncell + 1, npose = nx * nx;
+    int pre[16];
+    tile_prefetch<16>(cl, K, pre);
+    const int dy = 4 * sby + (lane >> 4);
+    const bool leader = (lane & 15) == 0 && dy < nx;
+    const double* __restrict__ pr = lv.prior + (size_t)p * 2 * npose;
+    double prv[4], ptw[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {                           // issued ahead of the tile's field loads
+        const int qq = min(dy, nx - 1) * nx + min(4 * sbx + e, nx - 1);
+        prv[e] = pr[qq]; ptw[e] = pr[npose + qq];
+    }
+    const size_t image = (size_t)lv.fmax * lv.fpitch;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(lv.field + (size_t)p * image), (short)0, (int)(image * sizeof(uint32_t)), 0x00020000);
+    unsigned long long acc[4];
+    tile_exact<16>(lv, rsrc, cl, K, sby, sbx, pre, acc);
+    double val = -INFINITY;
+    if (leader) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * sbx + e < nx) {
+                const double sc = (-((double)acc[e] * inv) + prv[e]) + ptw[e];
+                if (!isnan(sc)) val = fmax(val, sc);
+            }
+    }
+    val = fmax(val, __shfl_xor(val, 16));
+    val = fmax(val, __shfl_xor(val, 32));
+    if (lane == 0 && val > -INFINITY) atomicMax(&lv.bnb_best[p], order_bits(val));
+}
+
+// k_bound with the particle's bound image staged in LDS (the filled-machine form: DESIGN 4).  k_bound's loop is bound by the L1's
+// tag lookups -- every wave-load touches ~20 lines (11 pose-tile rows of a 2-D window), 3 160 lines per (particle, theta) -- and
+// at 128-256 particles per launch it runs AT that bound (profiles/r06_config2_p256_counters.txt: 0.70 of one line per clock and
+// CU).  Here a block serves one particle (or 1 / bpp of its angles): its waves copy the particle's byte image of the bounds
+// (Slam2dLevel.gmin2b: cost >> 24, written beside gmin2; gp x lp bytes, 42 KB at config 2, three blocks per CU) into LDS, then wave w
+// bounds its angles one after the other: lane = one pose tile (NSET tiles per lane), one ds_read_u8 per cell and tile set --
+// 2 LDS cycles per wave instruction instead of ~20 L1 cycles.  The bound is looser by < 2^-7 per cell (floor of 12 more bits;
+// 1.2 at 158 cells against the margin of 30): a few more tiles survive, the results do not change (every surviving tile is
+// scored exactly).  Lists are padded to a multiple of BL_BATCH cells with the cell at offset 0; what the padding added is
+// taken off afterwards.
+// Seeds: as k_bound, the best-bound tile of an angle is scored exactly -- unless its bound does not exceed lv.bnb_best[p] any
+// more (a wave's second and third angles mostly find it raised by the first round's seeds): a seed's exact score cannot exceed
+// its bound, so the FINAL bnb_best is the maximum over all seeds whatever is skipped, in whatever order (k_bound2's rule).
+#define BL_BATCH 16
+template <int NSET>
+__global__ __launch_bounds__(1024) void k_bound_lds(Slam2dLevel lv, int P, int bpp, int tpb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char g2s[];                  // [gp][lp]
+    const int lp = lv.g2b_pitch;
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+    const int p = (slot / bpp) * 8 + xcd, part = slot % bpp;
+    if (p >= P) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+    const int nx = 2 * lv.ncell + 1;
+    const int nbt = (nx + 3) >> 2, nq = (nbt + 3) >> 2, nbq4 = nq << 2;
+    const int gp = lv.tmax << 2;
+    DBG_CLOCK(0, b == 0);
+    {   // the image, as it lies in memory: 16-byte chunks, four loads in flight per thread
+        const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(lv.gmin2b + (size_t)p * gp * lp);
+        u32x4* dst = reinterpret_cast<u32x4*>(g2s);
+        const int n16 = (gp * lp) >> 4, nt = blockDim.x;
+        for (int i = tid; i < n16; i += 4 * nt) {
+            u32x4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (i + k * nt < n16) v[k] = src[i + k * nt];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (i + k * nt < n16) dst[i + k * nt] = v[k];
+        }
+    }
+    DBG_CLOCK(1, b == 0);
+    // this lane's tiles (byte offsets into the LDS image, slots of the bounds array)
+    int lbase[NSET], tslot[NSET];
+    bool valid[NSET];
+#pragma unroll
+    for (int s = 0; s < NSET; ++s) {
+        const int t = s * WAVE + lane;
+        valid[s] = t < nbt * nbt;
+        const int by = valid[s] ? t / nbt : 0, bx = valid[s] ? t - by * nbt : 0;
+        lbase[s] = by * lp + bx;
+        tslot[s] = (by << 8) | bx;
+    }
+    const double inv = 1.0 / lv.cost_scale;
+    const double* __restrict__ pm = lv.tile_pmax + (size_t)p * nbt * nbq4;
+    double pmx[NSET];
+#pragma unroll
+    for (int s = 0; s < NSET; ++s) pmx[s] = valid[s] ? pm[(tslot[s] >> 8) * nbq4 + (tslot[s] & 255)] : -INFINITY;
+    const unsigned magic = (unsigned)((0x100000000ull + (unsigned)gp - 1u) / (unsigned)gp);      // e / gp = umulhi(e, magic), e < 2^32 / gp
+    const int it0 = part * tpb, it_end = min(lv.ntheta, it0 + tpb);
+    __syncthreads();
+    DBG_CLOCK(2, b == 0);
+    // angles from the middle of the block's range outwards: the first round (which finds lv.bnb_best[p] at -inf and scores every
+    // seed) then holds the angles nearest the estimate's, where a tracked pose has its maximum
+    const int nth = it_end - it0, mid = (nth - 1) >> 1;
+    for (int j = w; j < nth; j += nw) {
+        const int it = it0 + mid + ((j & 1) ? ((j + 1) >> 1) : -((j + 1) >> 1));
+        const int K = lv.kcount[p * lv.ntheta + it];
+        const int* __restrict__ pcl = lv.pcells + ((size_t)p * lv.ntheta + it) * lv.kmax;
+        unsigned sum[NSET];
+#pragma unroll
+        for (int s = 0; s < NSET; ++s) sum[s] = 0u;
+        // a cell's byte offset into gmin2 ((Y0 gp + X0) 4) -> into the LDS image (Y0 lp + X0); beyond the list: offset 0
+        auto conv = [&](const int k) -> int {
+            if (k >= K) return 0;
+            const unsigned e = (unsigned)pcl[k] >> 2, Y0 = __umulhi(e, magic);
+            return (int)(Y0 * (unsigned)lp + (e - Y0 * (unsigned)gp));
+        };
+        int cv = conv(lane);
+        for (int base = 0; base < K; base += WAVE) {
+            const int cur = cv;
+            if (base + WAVE < K) cv = conv(base + WAVE + lane);
+#pragma unroll
+            for (int j0 = 0; j0 < WAVE; j0 += BL_BATCH) {
+                if (base + j0 < K) {                        // (wave-uniform)
+                    unsigned char v[NSET][BL_BATCH];
+#pragma unroll
+                    for (int i = 0; i < BL_BATCH; ++i) {
+                        const int so = __builtin_amdgcn_readlane(cur, j0 + i);
+#pragma unroll
+                        for (int s = 0; s < NSET; ++s) v[s][i] = g2s[lbase[s] + so];
+                    }
+#pragma unroll
+                    for (int i = 0; i < BL_BATCH; ++i)
+#pragma unroll
+                        for (int s = 0; s < NSET; ++s) sum[s] += v[s][i];
+                }
+            }
+        }
+        DBG_CLOCK(3, b == 0 && j == 0);
+        const unsigned npad = (unsigned)(((K + BL_BATCH - 1) / BL_BATCH) * BL_BATCH - K);
+        double* __restrict__ bnd = lv.bounds + ((size_t)p * lv.ntheta + it) * nbt * nbq4;
+        Best me{-INFINITY, INT_MAX, 0};
+#pragma unroll
+        for (int s = 0; s < NSET; ++s) {
+            if (valid[s]) {
+                const unsigned sm = sum[s] - npad * (unsigned)g2s[lbase[s]];
+                // as k_bound: U >= every pose's score of the tile; L = (sum of the block minima >> 24) << 24
+                const double U = (-(((double)sm * 16777216.0) * inv) + pmx[s]) + 1e-9;
+                bnd[(tslot[s] >> 8) * nbq4 + (tslot[s] & 255)] = U;
+                Best cand{U, tslot[s], 0};
+                if (better(cand, me)) me = cand;
+            }
+        }
+        if (lane < nbt)                                                     // padding tiles of every tile row: -inf
+            for (int bx = nbt; bx < nbq4; ++bx) bnd[lane * nbq4 + bx] = -INFINITY;
+        me = wave_best_fast(me);
+        DBG_CLOCK(4, b == 0 && j == 0);
+        if (me.i == INT_MAX) continue;
+        const unsigned long long best = __hip_atomic_load(&lv.bnb_best[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!(me.v > unorder_bits(best))) continue;                         // (wave-uniform; bounds are never NaN: tile_pmax maps NaN to +inf)
+        bound_seed_exact(lv, p, me.i >> 8, me.i & 255, lv.cells + ((size_t)p * lv.ntheta + it) * lv.kmax, K, inv);
+        DBG_CLOCK(5, b == 0 && j == 0);
+    }
+    DBG_CLOCK(14, b == 0);
 }
 
 // Two-level bounds for long cell lists (Slam2dLevel.bnb == 2; K ~ 1000 at 1081 beams, where k_bound sits at its
@@ -3899,6 +4065,49 @@ static void launch_endpoints(const Slam2dLidar& lid, const Slam2dLevel& lv, int 
 }
 
 // cube sweep + selection
+// k_bound_lds where the level carries the byte image of the bounds (Slam2dLevel.gmin2b) and it fits the CU's LDS.
+// SLAM2D_BOUND_LDS=0: never.  A particle's angles are split over up to SLAM2D_BOUND_LDS_SPLIT blocks (each stages the image)
+// while the launch stays below SLAM2D_BOUND_LDS_BLOCKS blocks (128: measured at 16 / 64 / 128 / 256 particles per launch, four /
+// two / one / one block per particle): small launches need the CUs, large ones pay for every extra staging pass and barrier.
+static bool launch_bound_lds(const Slam2dLevel& lv, int P, hipStream_t s) {
+    static const int mode = [] { const char* e = getenv("SLAM2D_BOUND_LDS"); return e ? atoi(e) : -1; }();
+    static const int max_split = [] { const char* e = getenv("SLAM2D_BOUND_LDS_SPLIT"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4; }();
+    static const int want_blocks = [] { const char* e = getenv("SLAM2D_BOUND_LDS_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
+    if (mode == 0 || !lv.gmin2b) return false;
+    const int nx = 2 * lv.ncell + 1, nbt = (nx + 3) >> 2;
+    const int nset = cdiv(nbt * nbt, WAVE);
+    const int gp = lv.tmax << 2, lp = lv.g2b_pitch;
+    if (nset > 4 || lv.kmax > 2048 || lp < gp || (lp & 15)) return false;
+    const int bpp = max(1, min(min(max_split, lv.ntheta), want_blocks / max(P, 1)));
+    const int tpb = cdiv(lv.ntheta, bpp);                       // angles per block
+    const size_t lds = (size_t)gp * lp;
+    const size_t want = 160 * 1024 - 512;
+    if (lds > want) return false;
+    static size_t granted[64][4] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    size_t& allowed = granted[dev >= 0 && dev < 64 ? dev : 0][nset - 1];
+    if (allowed == 0) allowed = 64 * 1024;
+    if (lds > allowed) {
+        const void* f = nset == 1 ? reinterpret_cast<const void*>(k_bound_lds<1>) : nset == 2 ? reinterpret_cast<const void*>(k_bound_lds<2>)
+                      : nset == 3 ? reinterpret_cast<const void*>(k_bound_lds<3>) : reinterpret_cast<const void*>(k_bound_lds<4>);
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        allowed = want;
+    }
+    const int rounds = cdiv(tpb, 16), nw = cdiv(tpb, rounds);
+    const unsigned grid = (unsigned)cdiv(P, 8) * 8 * bpp;
+    switch (nset) {
+        case 1: k_bound_lds<1><<<grid, WAVE * nw, lds, s>>>(lv, P, bpp, tpb); break;
+        case 2: k_bound_lds<2><<<grid, WAVE * nw, lds, s>>>(lv, P, bpp, tpb); break;
+        case 3: k_bound_lds<3><<<grid, WAVE * nw, lds, s>>>(lv, P, bpp, tpb); break;
+        default: k_bound_lds<4><<<grid, WAVE * nw, lds, s>>>(lv, P, bpp, tpb); break;
+    }
+    return true;
+}
+
 static int launch_scores(const Slam2dLevel& lv, int P, const double* d_est, int est_stride, const double* d_uniform,
                          Slam2dMatch* d_out, hipStream_t s, int ring_chunks = 0) {
     const int nx = 2 * lv.ncell + 1;
@@ -4063,7 +4272,8 @@ int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2
             k_bound2<<<grid, WAVE, 0, s>>>(lv, P);
         } else {
             StageScope prof(SLAM2D_STAGE_BOUND, s);
-            k_bound<<<(unsigned)cdiv(P, 8) * 8 * cdiv(lv.ntheta, BOUND_GROUP), WAVE * BOUND_GROUP, 0, s>>>(lv, P);
+            if (!launch_bound_lds(lv, P, s))
+                k_bound<<<(unsigned)cdiv(P, 8) * 8 * cdiv(lv.ntheta, BOUND_GROUP), WAVE * BOUND_GROUP, 0, s>>>(lv, P);
         }
         {
             StageScope prof(SLAM2D_STAGE_EXACT, s);

@@ -167,6 +167,15 @@ def bnb_default(nx, ntheta, beams, tmax):
 BNB_MIN_WORK = 4_000_000      # poses x beams per particle-scan; config 2: 10.9 M, reference coarse: 3.9 M, fine: 0.65 M
 
 
+def g2b_pitch(gp):
+    """Row pitch (bytes) of Slam2dLevel.gmin2b for rows of gp entries: a multiple of 16 whose dword stride mod 32 puts the tile
+    rows a lane group of k_bound_lds reads on distinct LDS banks (include/slam2d.h)."""
+    pitch = -(-gp // 16) * 16
+    while (pitch // 4) % 32 not in (8, 12, 20, 24):
+        pitch += 16
+    return pitch
+
+
 def encode_cost(prob, scale):
     """probSP (values in [min, 0]) -> uint32 fixed-point cost, as the blur kernel stores it."""
     c = np.rint(-np.asarray(prob, dtype=np.float64) * scale)
@@ -672,6 +681,9 @@ class SearchLevel:
                 tile_pmax=torch.zeros((P, nbt, nbq4), dtype=f64, device=device),
                 bnb_best=torch.zeros(P, dtype=torch.int64, device=device),
             )
+            if self.bnb_levels == 1:    # the bounds' byte image for k_bound_lds (one block per particle stages it in LDS)
+                self.g2b_pitch = g2b_pitch(4 * self.tmax)
+                t.update(gmin2b=torch.zeros((P, 4 * self.tmax, self.g2b_pitch), dtype=torch.uint8, device=device))
             if self.bnb_levels == 2:    # long cell lists: 8x8-pose tiles first
                 t.update(
                     gmin3d=torch.zeros((P, 4, 2 * self.tmax, 2 * self.tmax), dtype=i32, device=device),
@@ -696,12 +708,13 @@ class SearchLevel:
             ring_cap=self.nx * ((self.nx + 3) // 4), bnb=self.bnb_levels, ep_group=self.ep_group, beam_xy=t["beam_xy"].data_ptr(),
             sync=t["sync"].data_ptr(),
             **({k: t[k].data_ptr() for k in ("gmin3d", "p3cells", "bounds1", "seed_key")} if self.bnb_levels == 2 else {}),
+            **(dict(gmin2b=t["gmin2b"].data_ptr(), g2b_pitch=self.g2b_pitch) if "gmin2b" in t else {}),
             **({k: t[k].data_ptr() for k in ("gmin", "gmin2", "pcells", "bounds", "bnb_best", "seed_key")} if self.abound else {}),
             **({k: t[k].data_ptr() for k in ("gmin", "gmin2", "pcells", "bounds", "tile_pmax", "bnb_best")} if self.bnb else {}))
 
     _PER_PARTICLE = ("frames", "axis_x", "axis_y", "field", "cells", "kcount", "prior", "cube", "partials", "tilestate", "tilemin",
                      "tilemax", "tilelist", "tilecount", "tileneed", "freerow", "prune_state", "beam_xy", "sync", "gmin", "gmin2",
-                     "pcells", "bounds", "tile_pmax", "bnb_best", "gmin3d", "p3cells", "bounds1", "seed_key")
+                     "pcells", "bounds", "tile_pmax", "bnb_best", "gmin3d", "p3cells", "bounds1", "seed_key", "gmin2b")
 
     def view(self, p0, p1):
         """A Slam2dLevel describing particles [p0, p1) of this level: the same parameters, every per-particle pointer advanced to

@@ -26,6 +26,9 @@ print("k_blur_clamp (one tile): halo -> LDS %.2f us, axis-0 pass %.2f, axis-1 pa
 print("k_tile_triage (particle 0): prologue + loads issued + LDS stores %.2f us, barrier %.2f, slices OR %.2f, classify %.2f, barrier-or %.2f, lists + fills %.2f, barrier + counts %.2f; total %.2f" % (
     us(20, 21), us(21, 22), us(22, 23), us(23, 24), us(24, 25), us(25, 26), us(26, 27), us(20, 27)))
 print("k_endpoints (theta 0, particle 0): cells %.2f us, hash + tile marking %.2f, global marks + compaction %.2f" % (us(40, 41), us(41, 42), us(42, 43)))
+if os.environ.get("SLAM2D_BOUND_LDS", "1") != "0":
+    print("k_bound_lds (block 0, wave 0): staging loads+stores %.2f us, tiles/pmax + barrier %.2f, first angle's loop %.2f, its bounds + seed pick %.2f, its seed %.2f, remaining angles %.2f; total %.2f" % (
+        us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(5, 14), us(0, 14)))
 print("k_bound: prologue->loop end %.2f us, bounds+argmax %.2f, seed tile %.2f, atomic %.2f" % (us(0, 1), us(1, 2), us(2, 3), us(3, 4)))
 print("k_exact_select: scan %.2f us, list %.2f, tiles %.2f, max %.2f, exp %.2f, theta sums %.2f, select %.2f; total %.2f" % (
     us(8, 9), us(9, 10), us(10, 11), us(11, 29), us(29, 30), us(30, 12), us(12, 13), us(8, 13)))

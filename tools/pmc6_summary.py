@@ -67,8 +67,30 @@ def table(tag):
     return "\n".join(lines), m, dur
 
 
+def alone_table(tag):
+    """Standalone durations (the counter passes serialise the kernels) + LDS counters where collected."""
+    import glob as g
+    alone = collections.defaultdict(list)
+    for f in g.glob(os.path.join(ROOT, f"gpurun_out/pmc6/{tag}/sq/**/pmc_kernel_trace.csv"), recursive=True) or g.glob(os.path.join(ROOT, f"gpurun_out/pmc6/{tag}/*/**/pmc_kernel_trace.csv"), recursive=True)[:1]:
+        for r in csv.DictReader(open(f)):
+            alone[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    m = load(tag)
+    out = []
+    for k, v in sorted(alone.items(), key=lambda kv: -sum(kv[1])):
+        if len(v) < 10 or not k.startswith("k_"):
+            continue
+        v = v[len(v) // 3:]
+        c = m.get(k, {})
+        out.append(f"  {k[:30]:30s} alone {sum(v) / len(v):7.1f} us (min {min(v):6.1f})  " + "  ".join(f"{a} {c[a]:.4g}" for a in ("SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_ADDR_CONFLICT", "SQ_LDS_UNALIGNED_STALL", "SQ_WAIT_INST_LDS", "SQ_INST_CYCLES_VMEM", "SQ_WAIT_ANY") if a in c))
+    return "\n".join(out)
+
+
 if __name__ == "__main__":
     tags = [a for a in sys.argv[1:] if not a.startswith("--")]
+    if "--alone" in sys.argv:
+        for tag in tags:
+            print(f"== {tag} (standalone durations under the counter passes)")
+            print(alone_table(tag))
     for tag in tags:
         t, m, dur = table(tag)
         print(f"== {tag}")
