@@ -3504,6 +3504,9 @@ __global__ __launch_bounds__(256) void k_weights(double* logw, const double* __r
 #ifndef UPDB_MIN_WAVES
 #define UPDB_MIN_WAVES 1
 #endif
+#ifndef UPDB_SKIP_R
+#define UPDB_SKIP_R 1
+#endif
 __global__ __launch_bounds__(256, UPDB_MIN_WAVES) void k_grid_update(Slam2dLidar lid, const Slam2dMap* __restrict__ maps, int P,
                                                            const double* __restrict__ pose, int pstride,
                                                            const double* __restrict__ ranges,
@@ -3588,6 +3591,9 @@ __global__ __launch_bounds__(256, UPDB_MIN_WAVES) void k_grid_update(Slam2dLidar
         if (qhi < 0) return;
         const int b0 = returned ? 0 : min(qlo / SLAM2D_SPOKE_BAND, nb), b1 = min(qhi / SLAM2D_SPOKE_BAND + 1, nb);
         const int kbeg = bp[b0], kend = bp[max(b0, b1)];
+        // cells of the bands wholly below band(lo) have floor(r / unit) < floor(lo / unit), hence r < lo: free by construction
+        // (most of a returned beam's cells); their radii are not read (8 of a chunk's ~36 lines; UPDB_SKIP_R=0: read them all)
+        const int klo = (UPDB_SKIP_R && lo > 0.0) ? bp[min(qlo / SLAM2D_SPOKE_BAND, nb)] : kbeg;
         const double* __restrict__ sr = lid.spoke_r;
         const uint32_t* __restrict__ sc = lid.spoke_cells;
         // stale indices of a beam during which the map grew on a low side (:144-152): shift of the beam's own growth,
@@ -3616,11 +3622,19 @@ __global__ __launch_bounds__(256, UPDB_MIN_WAVES) void k_grid_update(Slam2dLidar
             double r[UPDB_UNROLL], xj[UPDB_UNROLL], yi[UPDB_UNROLL];
             uint32_t cell[UPDB_UNROLL], inc[UPDB_UNROLL], c[UPDB_UNROLL], at[UPDB_UNROLL];
             int mxs[UPDB_UNROLL], mys[UPDB_UNROLL];
+            if ((k0 - lane) + 64 * UPDB_UNROLL <= klo) {        // (wave-uniform)
 #pragma unroll
-            for (int u = 0; u < UPDB_UNROLL; ++u) {
-                const int k = min(k0 + u * 64, kend - 1);
-                r[u] = sr[k];
-                cell[u] = sc[k];
+                for (int u = 0; u < UPDB_UNROLL; ++u) {
+                    r[u] = -INFINITY;
+                    cell[u] = sc[k0 + u * 64];
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < UPDB_UNROLL; ++u) {
+                    const int k = min(k0 + u * 64, kend - 1);
+                    r[u] = sr[k];
+                    cell[u] = sc[k];
+                }
             }
             if (lattice) {
                 // the window's cells sit on the map's lattice: column index + the particle's offset, nothing else
