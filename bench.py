@@ -1170,9 +1170,14 @@ def predicted_strong_scaling(ps, total, added_us, spread_us=None):
             base_n = n
         rows[str(n)] = dict(particles_per_gpu=total // n, ms_per_step=round(ms, 5), particle_scans_per_sec=round(total / ms * 1e3),
                             speedup_vs_1_gpu=round((base / ms) if base_n == 1 else float("nan"), 3))
+    s8 = rows.get("8", {}).get("speedup_vs_1_gpu")
+    verdict = (f"STRONG scaling of {total} particles: {s8:.1f}x predicted at 8 GPUs, {'below' if s8 < 6.0 else 'at or above'} the north-star's 6x bar "
+               f"({total // 8} particles per GPU do not fill an MI355X); WEAK scaling (64 per GPU) is predicted at 8 x t(64) / (t(64) + normaliser) "
+               f"= {8 * ps['64']['ms_per_step'] / (ps['64']['ms_per_step'] + 1e-3 * added_us):.1f}x"
+               if s8 is not None and s8 == s8 and "64" in ps else "no 1-GPU and 8-GPU points in the sweep")
     return dict(total_particles=total, per_n_gpus=rows, normaliser_added_us=round(added_us, 2), normaliser_added_us_spread=spread_us and round(spread_us, 2),
                 note="from variants.p_sweep (one GPU, the same kernels) + variants.sharded_normaliser_probe; xGMI latency of the 24-byte-per-group "
-                     "all-gather and host contention between ranks not included")
+                     "all-gather and host contention between ranks not included.  " + verdict)
 
 
 def closed_loop_sharded(args, world, rank, device):
@@ -1194,7 +1199,8 @@ def closed_loop_sharded(args, world, rank, device):
     force = set(range(args.resample_every, K, args.resample_every)) if args.resample_every > 0 else set()
 
     def leg():
-        kw = dict(total_particles=total, first_index=first) if world > 1 else {}
+        # (SLAM2D_FORCE_DIST=1 on one rank: the sharded closed loop -- gate, all-gather over RCCL, publishing merge -- with nobody to wait for)
+        kw = dict(total_particles=total, first_index=first, force_sharded=True) if dist.is_initialized() else {}
         pf = pkg.ParticleFilter(count, ogP, smP, device=device, rng=np.random.RandomState(0), **kw)
         if dist.is_initialized():
             dist.barrier()
@@ -1220,9 +1226,10 @@ def closed_loop_sharded(args, world, rank, device):
             "dtype": "u32 fixed-point field, u64 exact accumulate, f64 priors/scores, u32 packed counts", "data": "bundled Intel log (tests/golden/intel_gfs.npz)",
             "config": {"workload": "config3: FastSLAM closed loop, reference defaults, 910-scan Intel log, maps growing from 50 m",
                        "total_particles": total, "particles_per_gpu": count, "resample_every": args.resample_every,
-                       "parallelism": f"particles sharded x{world}" if world > 1 else "single GPU"},
+                       "parallelism": (f"particles sharded x{world}, " if dist.is_initialized() else "single GPU, ") +
+                                      f"{pf.n_groups} particle group(s) per GPU on the event-free calls" + (" (sharded commit: gate + all-gather + publishing merge)" if pf.sharded else "")},
             "scans_per_sec": K / el, "resamples": len(res), "state_moving_resamples": pf.stats["state_moving_resamples"],
-            "scans_redone": pf.stats["redo"], "final_map_of_particle_0": [pf.engine.maps[0].rows, pf.engine.maps[0].cols]}), flush=True)
+            "scans_redone": pf.stats["redo"], "filter_stats": dict(pf.stats), "final_map_of_particle_0": [pf.engine.maps[0].rows, pf.engine.maps[0].cols]}), flush=True)
 
 
 def spawn_check(args, world, rank):
@@ -1439,7 +1446,12 @@ def main():
                        "particle_groups_per_gpu": G if isinstance(hot, HotPathGroups) else 1,
                        "parallelism": f"particles sharded x{world}, one 24-byte-per-rank {'RCCL' if args.backend == 'nccl' else 'gloo (dry mode)'} "
                                       "all-gather of the weight normaliser per scan" if world > 1 else
-                                      ("single GPU, two particle groups on two HIP streams + one for the normaliser's merge" if isinstance(hot, HotPathGroups) else "single GPU")},
+                                      (f"single GPU, {G} particle groups on {G} HIP streams, their normaliser merged on the device"
+                                       if isinstance(hot, HotPathGroups) else "single GPU, one stream"),
+                       "input": f"{scen.mode}: " + {"tracked": "scans ray-cast from the mapped world, every estimate within two cells of the true pose -- the "
+                                                               "steady state of a converged filter and the BEST case of the branch and bound; the other inputs "
+                                                               "are in config.other_measurements (worst_case_ms_per_step, displaced)",
+                                                    "worst": "structure-free ranges (SURVEY 8d)", "displaced": "estimates 1.5 m / 0.2 rad off"}[scen.mode]},
             "scans_per_sec": K / elapsed,
             "timed_blocks": {"repeats": R, "steps_each": K, "ms_per_step_of_each": [round(1e3 * b / K, 5) for b in blocks], "reported": "median",
                              "host_enqueue_ms_per_step": round(1e3 * statistics.median(enq) / K, 5),

@@ -454,6 +454,19 @@ int slam2d_weights_merge(double* d_logw, int32_t N, const double* d_parts, int32
 int slam2d_norm_gate(uint32_t* d_norm_sync, int32_t G, void* stream);
 int slam2d_weights_merge_publish(double* d_logw, int32_t N, const double* d_parts, int32_t world, int64_t total_particles,
                                  double* d_w, double* d_stats, uint32_t* d_norm_sync, void* stream);
+/* ... and the closed loop's report (ABI 17): slam2d_weights_merge_publish, after which the same block copies d_pack[0 .. pack_doubles)
+ * to the pinned host buffer h_pack and stores report_seq into the pinned host word h_seq (system scope) -- what the merging
+ * normaliser block does on one rank (Slam2dScan.h_seq).  A sharded rank's commit is slam2d_groups_commit (merge == 0, h_seq NULL),
+ * slam2d_norm_gate, the all-gather of the partials, this call; the host waits with slam2d_host_wait_seq.  The NEXT commit may be
+ * issued only after that wait has returned: its groups rewrite d_pack's report rows and fault-bit snapshot.
+ * A scan VOIDED on some rank (abort_mask: a search window had left a map): that rank's groups leave the void partial (sum -1)
+ * and still arrive, so the enqueued gate, collective and merge run on every rank; the merge then changes no weight, publishes
+ * nothing to the groups and reports d_stats = [NaN, -1].  The voiding rank grows its maps and issues the scan again (match, commit,
+ * gate, all-gather, this call); every OTHER rank -- its own commit stands, its partials are intact, its groups' next normaliser
+ * blocks wait -- answers a voided report with the all-gather and this call alone (no gate).  One all-gather per attempt and rank. */
+int slam2d_weights_merge_publish_report(double* d_logw, int32_t N, const double* d_parts, int32_t world, int64_t total_particles,
+                                        double* d_w, double* d_stats, uint32_t* d_norm_sync, const double* d_pack, double* h_pack,
+                                        int32_t pack_doubles, uint32_t* h_seq, uint32_t report_seq, void* stream);
 
 /* ---- one scan for several particle GROUPS, each on its own HIP stream, issued from C in ONE call ----
  * Particles are independent during a scan (Algorithm/FastSlam.py:25-27); every kernel of the step is latency- or issue-bound
@@ -536,8 +549,11 @@ typedef struct {
                                     once EVERY group's stream has passed the scan.  Needs n_parts == G, the groups' d_part being
                                     rows 0 .. G-1 of d_parts.  With merge == 0 (sharded) the groups only wait and arrive through
                                     the words; the caller follows with slam2d_norm_gate, its collective, slam2d_weights_merge_publish.
-                                    Use it for every scan of the groups or for none.  The device-side waits are bounded: after
-                                    2 s a group's fault word 0 receives SLAM2D_F_SYNC_TIMEOUT (word 62 carries it from the gate) */
+                                    Use it for every scan of the groups or for none.  At most 56 groups.  The device-side waits are
+                                    bounded: word 59 holds the bound in milliseconds (the caller may set it once, before the first
+                                    scan; 0 = 30 s); after it a group's fault word 0 receives SLAM2D_F_SYNC_TIMEOUT (word 62 carries
+                                    it from the gate) and, where an abort_mask is in use, the scan is voided so that its report
+                                    still reaches the host */
     /* ---- ABI 16: the closed loop without events and without copies (all optional; 0 / NULL = as before) ----
      * Measured in round 5: an event packet between two kernels of a stream costs 3 us, a wait across streams 6-8 us, a copy-engine
      * transfer in front of a kernel ~10 us; a grouped closed-loop scan had ten of them. */
@@ -553,7 +569,9 @@ typedef struct {
                                     ev_matched, and d_norm_sync's device-side merge stays usable with abort_mask (a voided scan has no
                                     normaliser: nobody arrives there, the words stay in step).  n_abort_flags = all groups' particles */
     uint32_t report_seq;         /* with h_seq: the value to publish for this scan (the caller counts its commits) */
-    uint32_t* h_seq;             /* PINNED HOST word, or NULL.  With d_norm_sync and merge == 1: the block that finishes the scan for
+    uint32_t* h_seq;             /* PINNED HOST word, or NULL.  (The caller waits for scan s's value before it issues the commit of scan
+                                    s + 1: that commit's groups rewrite the report rows and the fault-bit snapshot inside d_pack.)
+                                    With d_norm_sync and merge == 1: the block that finishes the scan for
                                     all groups (the merging normaliser block; for a voided scan the last group's block 0, counted in
                                     word 60) copies d_pack[0 .. pack_doubles) to h_pack and then stores report_seq here, system scope.
                                     The host waits with slam2d_host_wait_seq: no download, no event */

@@ -33,7 +33,7 @@ FLAG_NAMES = {
     F_UPDATE_OUTSIDE_MAP: "map update touched a cell outside the map",
     F_COUNT_OVERFLOW: "16-bit cell count overflow",
     F_FLOOR_REDO: "field minimum differed from the analytic floor (clamp redone)",
-    F_SYNC_TIMEOUT: "a device-side wait of the groups' normaliser gave up after 2 s (a producer never arrived)",
+    F_SYNC_TIMEOUT: "a device-side wait of the groups' normaliser gave up after its bound (30 s unless set: a producer never arrived)",
 }
 INIT_CELL = 0x00010002
 INIT_CELL_WIDE = (1 << 32) | 2        # the same in the 64-bit cell format (Slam2dMap.wide)
@@ -171,6 +171,7 @@ SIGNATURES = {
     "slam2d_host_wait_seq": (C.c_int, [_vp, C.c_uint32, C.c_double]),
     "slam2d_norm_gate": (C.c_int, [_vp, C.c_int32, _vp]),
     "slam2d_weights_merge_publish": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, C.c_int64, _vp, _vp, _vp, _vp]),
+    "slam2d_weights_merge_publish_report": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, C.c_int64, _vp, _vp, _vp, _vp, _vp, C.c_int32, _vp, C.c_uint32, _vp]),
     "slam2d_weights_local": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _vp, _vp]),
     "slam2d_weights_merge": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, C.c_int64, _vp, _vp, _vp]),
     "slam2d_gather_maps": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int64, _vp]),

@@ -3393,14 +3393,20 @@ __global__ __launch_bounds__(256) void k_weights_local(double* logw, const doubl
 // that before it touches its log-weights.  Plain stores + release fence before every flag, one acquire fence behind every wait
 // (MI355X_MICROARCH.md, "inter-workgroup visibility", the valid producer / consumer forms): placement-independent.  No deadlock:
 // a waiting block was enqueued after everything it waits for (slam2d_groups_* issue a whole scan of every group per call).
-// Both waits are BOUNDED (SYNC_SPIN_TICKS of the 100 MHz wall clock = 2 s, five orders of magnitude above a scan): a producer
-// that never comes -- a dead rank behind the all-gather, a caller that broke the whole-scan-per-call order -- ends as the fatal
-// SLAM2D_F_SYNC_TIMEOUT in the group's fault words (word 62 of the sync block carries it from the gate kernel), not as a hung GPU.
-#define SYNC_SPIN_TICKS 200000000ull
+// All waits are BOUNDED: a producer that never comes -- a dead rank behind the all-gather, a caller that broke the
+// whole-scan-per-call order -- ends as the fatal SLAM2D_F_SYNC_TIMEOUT in the group's fault words (word 62 of the sync block
+// carries it from the gate kernel), not as a hung GPU.  The bound is word 59 of the sync block in milliseconds (0: 30 s -- round 5's
+// fixed 2 s turned ordinary lateness into a fault: a peer rank behind the all-gather that grows its maps, a second process or a
+// profiler on the GPU); slam2d_host_wait_seq's bound on the host side should exceed it.
+#define SLAM2D_SYNC_DEFAULT_MS 30000u
+__device__ __forceinline__ unsigned long long sync_spin_ticks(const uint32_t* nsync) {
+    const uint32_t ms = __hip_atomic_load(&nsync[59], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (unsigned long long)(ms ? ms : SLAM2D_SYNC_DEFAULT_MS) * 100000ull;                 // (100 MHz wall clock)
+}
 __device__ __forceinline__ void normaliser_wait(uint32_t* nsync, const int g, uint32_t* flags) {
     if (threadIdx.x == 0) {
         const uint32_t want = nsync[2 + g];
-        const unsigned long long t0 = wall_clock64();
+        const unsigned long long t0 = wall_clock64(), SYNC_SPIN_TICKS = sync_spin_ticks(nsync);
         bool late = false;
         while ((int)(__hip_atomic_load(&nsync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
             __builtin_amdgcn_s_sleep(8);
@@ -3520,7 +3526,11 @@ __global__ __launch_bounds__(256, UPDB_MIN_WAVES) void k_grid_update(Slam2dLidar
         bool bad = false;
         const uint32_t* af = wj.abort_flags ? wj.abort_flags : flags;
         const int an = wj.abort_flags ? wj.abort_n : wj.N;
-        for (int i = threadIdx.x; i < an; i += blockDim.x) bad |= (af[i] & wj.abort_mask) != 0u;
+        // (with the device-side gate: a gate that gave up has left SLAM2D_F_SYNC_TIMEOUT in a group's fault word -- the scan is
+        // voided like one whose window left a map, its report still reaches the host, which raises at once instead of waiting
+        // for a sequence number that would never come)
+        const uint32_t am = wj.abort_mask | (wj.nsync ? SLAM2D_F_SYNC_TIMEOUT : 0u);
+        for (int i = threadIdx.x; i < an; i += blockDim.x) bad |= (af[i] & am) != 0u;
         if (__syncthreads_or(bad)) {
             if (blockIdx.x == 0 && wj.flag_snapshot)
                 for (int i = threadIdx.x; i < wj.N; i += blockDim.x) wj.flag_snapshot[i] = flags[i];
@@ -3531,6 +3541,16 @@ __global__ __launch_bounds__(256, UPDB_MIN_WAVES) void k_grid_update(Slam2dLidar
                     wj.report[5 * i] = wj.coarse[i].x; wj.report[5 * i + 1] = wj.coarse[i].y; wj.report[5 * i + 2] = wj.coarse[i].theta;
                 }
             if (blockIdx.x == 0) abort_arrive(wj);
+            if (blockIdx.x == 0 && wj.nsync && wj.part && !wj.logw_all && threadIdx.x == 0) {
+                // a sharded rank (the groups only arrive, the merge follows the all-gather on the normaliser's stream): the gate, the
+                // collective and the merge of this scan are enqueued already, on every rank.  The group leaves the VOID partial
+                // (sum < 0: no sum of exponentials is) and counts itself in -- not in its own word 2 + g: the scan comes again --
+                // so the gate passes, every rank's merge finds the marker, merges nothing and reports the scan as voided
+                // (slam2d_weights_merge_publish_report); the ranks that committed keep their partials and gather again.
+                wj.part[0] = -INFINITY; wj.part[1] = -1.0; wj.part[2] = 0.0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __hip_atomic_fetch_add(&wj.nsync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             return;
         }
     }
@@ -3750,12 +3770,15 @@ __global__ __launch_bounds__(256, UPDB_MIN_WAVES) void k_grid_update(Slam2dLidar
 __global__ __launch_bounds__(256) void k_weights_merge(double* logw, int N, const double* __restrict__ parts, int world,
                                                        double total_particles, double* w, double* stats,
                                                        const uint32_t* __restrict__ abort_flags, int abort_n, uint32_t abort_mask,
-                                                       uint32_t* nsync = nullptr) {
+                                                       uint32_t* nsync = nullptr, const double* pack_d = nullptr, double* pack_h = nullptr,
+                                                       int pack_n = 0, uint32_t* h_seq = nullptr, uint32_t seq = 0u) {
     if (abort_mask) {                                      // slam2d_groups_commit: a voided scan (see k_grid_update) has no partials to merge
         bool bad = false;
         for (int i = threadIdx.x; i < abort_n; i += blockDim.x) bad |= (abort_flags[i] & abort_mask) != 0u;
         if (__syncthreads_or(bad)) return;
     }
+    bool voided = false;                                   // (a group of some rank left the VOID partial: k_grid_update's sharded abort)
+    for (int r = 0; r < world; ++r) voided |= parts[3 * r + 1] < 0.0;
     double gm = -INFINITY;
     for (int r = 0; r < world; ++r) gm = fmax(gm, parts[3 * r]);
     double s1 = 0.0, s2 = 0.0;
@@ -3765,19 +3788,30 @@ __global__ __launch_bounds__(256) void k_weights_merge(double* logw, int N, cons
         s2 += parts[3 * r + 2] * sc * sc;
     }
     const double lse = gm + log(s1);
-    for (int i = threadIdx.x; i < N; i += 256) {
-        const double lw = logw[i];
-        w[i] = exp(lw - gm) / s1;
-        logw[i] = lw - lse;
+    if (!voided)
+        for (int i = threadIdx.x; i < N; i += 256) {
+            const double lw = logw[i];
+            w[i] = exp(lw - gm) / s1;
+            logw[i] = lw - lse;
+        }
+    if (threadIdx.x == 0) {
+        if (voided) { stats[0] = NAN; stats[1] = -1.0; }   // the report's marker: variance NaN, log of the sum -1 (a peer's NaN weights give NaN, NaN)
+        else { stats[0] = s2 / (s1 * s1) - 1.0 / total_particles; stats[1] = lse; }
     }
-    if (threadIdx.x == 0) { stats[0] = s2 / (s1 * s1) - 1.0 / total_particles; stats[1] = lse; }
-    if (nsync) {                                           // (slam2d_weights_merge_publish: the groups' next normaliser blocks wait for this)
+    if (nsync && !voided) {                                // (slam2d_weights_merge_publish: the groups' next normaliser blocks wait for this)
         __syncthreads();
         if (threadIdx.x == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             const uint32_t gen = __hip_atomic_load(&nsync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&nsync[1], gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    }
+    if (h_seq) {                                           // (slam2d_weights_merge_publish_report: the scan's pack to the host, as publish_pack)
+        __syncthreads();
+        for (int i = threadIdx.x; i < pack_n; i += blockDim.x) pack_h[i] = pack_d[i];
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(h_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -3787,15 +3821,18 @@ __global__ __launch_bounds__(256) void k_weights_merge(double* logw, int N, cons
 // publishes d_norm_sync[1], which the groups' next normaliser blocks wait for (normaliser_wait).
 __global__ __launch_bounds__(64) void k_norm_gate(uint32_t* nsync, int G) {
     if (threadIdx.x == 0) {
-        const unsigned long long t0 = wall_clock64();
+        const unsigned long long t0 = wall_clock64(), SYNC_SPIN_TICKS = sync_spin_ticks(nsync);
+        bool late = false;
         while (__hip_atomic_load(&nsync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)G) {
             __builtin_amdgcn_s_sleep(8);
             if (wall_clock64() - t0 > SYNC_SPIN_TICKS) {           // (sticky: every later normaliser block raises the fault bit)
                 __hip_atomic_store(&nsync[62], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                late = true;
                 break;
             }
         }
-        __hip_atomic_store(&nsync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (a tripped gate leaves the arrivals where they are: late groups still count themselves in, and the fault is fatal anyway)
+        if (!late) __hip_atomic_store(&nsync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // (the partials: the collective behind this kernel reads them)
     }
 }
@@ -3831,7 +3868,7 @@ __global__ __launch_bounds__(256) void k_prior_pull(const double* __restrict__ p
 // of them the default stream's: two groups shared a queue and the first gate waited for the one queued behind it.)
 __global__ __launch_bounds__(64) void k_abort_gate(uint32_t* nsync, uint32_t want, uint32_t* flags) {
     if (threadIdx.x == 0) {
-        const unsigned long long t0 = wall_clock64();
+        const unsigned long long t0 = wall_clock64(), SYNC_SPIN_TICKS = sync_spin_ticks(nsync);
         while ((int)(__hip_atomic_load(&nsync[61], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
             __builtin_amdgcn_s_sleep(8);
             if (wall_clock64() - t0 > SYNC_SPIN_TICKS) { atomicOr(&flags[0], SLAM2D_F_SYNC_TIMEOUT); break; }
@@ -4416,6 +4453,7 @@ int slam2d_scan_commit_next(const Slam2dLidar* lidar, const Slam2dMap* d_maps, i
 // The normaliser merged by the groups' own blocks (Slam2dScan.d_norm_sync): one rank (the sharded merge has an all-gather in front of
 // it), no abort decision across groups (a voided scan's groups would not all arrive), the groups' partials in d_parts in group order.
 // (round 5, ABI 16: ... or an abort decided behind k_match_arrive / k_abort_gate, Slam2dScan.match_seq != 0)
+#define SLAM2D_SYNC_MAX_GROUPS 56       // words 2 .. 57 of the sync block: one per group; 59: the waits' bound; 60-62: tickets and flags
 static inline bool abort_on_device(const Slam2dScan& sc) { return sc.d_norm_sync != nullptr && sc.match_seq != 0u; }
 static inline bool device_merged(const Slam2dScan& sc) { return sc.d_norm_sync != nullptr && sc.merge && (!sc.abort_mask || sc.match_seq != 0u); }
 // ... or only synchronised through those words (merge == 0, the sharded normaliser: slam2d_norm_gate, the collective and
@@ -4432,7 +4470,7 @@ static int groups_check(const Slam2dLidar* lidar, const Slam2dGroup* groups, int
         if (commit && (!g.d_logw || !g.d_part)) return SLAM2D_E_BADARG;
         if (commit && sc->abort_mask && !g.ev_matched && !abort_on_device(*sc)) return SLAM2D_E_BADARG;
         if (sc->h_ranges && (g.d_est || !g.d_pull)) return SLAM2D_E_BADARG;          // (the pull rides in the closed loop's prior launch)
-        if (commit && sc->h_next_ranges && (!sc->h_ranges || !g.d_pull_next || !device_merged(*sc))) return SLAM2D_E_BADARG;
+        if (commit && sc->h_next_ranges && (!sc->h_ranges || !g.d_pull_next || !device_synced(*sc))) return SLAM2D_E_BADARG;
     }
     if (commit) {
         const bool dm = device_merged(*sc);
@@ -4440,7 +4478,7 @@ static int groups_check(const Slam2dLidar* lidar, const Slam2dGroup* groups, int
         if (sc->merge && (!sc->d_logw_all || !sc->d_parts || !sc->d_w || !sc->d_stats || (!dm && !sc->ev_merged) || sc->n_local <= 0 || sc->n_parts <= 0 ||
                           sc->total_particles < sc->n_local)) return SLAM2D_E_BADARG;
         if (dm && sc->n_parts != G) return SLAM2D_E_BADARG;                  // (one partial per group, in group order)
-        if (sc->d_norm_sync && (G > 57 || (sc->abort_mask && !sc->match_seq))) return SLAM2D_E_BADARG;  // (2 + G words, 60-62 taken; an abort
+        if (sc->d_norm_sync && (G > SLAM2D_SYNC_MAX_GROUPS || (sc->abort_mask && !sc->match_seq))) return SLAM2D_E_BADARG;  // (2 + G words, 59-62 taken; an abort
         //                                                             decision across groups needs the events or k_match_arrive / k_abort_gate)
         if (sc->abort_mask && (!sc->d_abort_flags || sc->n_abort_flags <= 0)) return SLAM2D_E_BADARG;
     }
@@ -4516,12 +4554,13 @@ static int group_commit(const Slam2dLidar* lidar, const Slam2dGroup* groups, int
     if (device_merge) {
         wj.parts_all = sc.d_parts; wj.logw_all = sc.d_logw_all; wj.n_all = sc.n_local; wj.total = (double)sc.total_particles;
         wj.w_all = sc.d_w; wj.stats_all = sc.d_stats;
-        if (sc.h_next_ranges && !g.d_est) {             // closed loop: the next scan's prior and ranges ride in this launch's block 0
-            wj.next_est = g.d_est_out; wj.next_psi = g.d_psi_out; wj.next_raw_theta = sc.next_raw_theta;
-            wj.next_prev_raw_theta = sc.next_prev_raw_theta; wj.next_raw_turn = sc.next_raw_turn; wj.next_has_turn = sc.next_has_turn;
-            wj.pull_src = sc.h_next_ranges; wj.pull_dst = g.d_pull_next; wj.pull_n = lidar->beams;
-        }
         if (sc.h_seq) { wj.pack_d = sc.d_pack; wj.pack_h = sc.h_pack; wj.pack_n = sc.pack_doubles; wj.h_seq = sc.h_seq; wj.seq = sc.report_seq; }
+    }
+    if (device_sync && sc.h_next_ranges && !g.d_est) {  // closed loop: the next scan's prior and ranges ride in this launch's block 0 (needs the
+        //                                                 matched poses only: a sharded rank's commit, which does not merge, carries them too)
+        wj.next_est = g.d_est_out; wj.next_psi = g.d_psi_out; wj.next_raw_theta = sc.next_raw_theta;
+        wj.next_prev_raw_theta = sc.next_prev_raw_theta; wj.next_raw_turn = sc.next_raw_turn; wj.next_has_turn = sc.next_has_turn;
+        wj.pull_src = sc.h_next_ranges; wj.pull_dst = g.d_pull_next; wj.pull_n = lidar->beams;
     }
     rc = launch_update(lidar, g.d_maps, g.P, reinterpret_cast<const double*>(fin), md, sc.h_ranges ? g.d_pull : sc.d_ranges, nullptr, g.d_flags, wj, g.stream);
     if (rc || (device_sync && !g.ev_done)) return rc;
@@ -4765,7 +4804,7 @@ int slam2d_weights_merge(double* d_logw, int32_t N, const double* d_parts, int32
 }
 
 int slam2d_norm_gate(uint32_t* d_norm_sync, int32_t G, void* stream) {
-    if (!d_norm_sync || G <= 0 || G > 59) return SLAM2D_E_BADARG;
+    if (!d_norm_sync || G <= 0 || G > SLAM2D_SYNC_MAX_GROUPS) return SLAM2D_E_BADARG;
     k_norm_gate<<<1, 64, 0, (hipStream_t)stream>>>(d_norm_sync, G);
     return launch_status();
 }
@@ -4774,6 +4813,16 @@ int slam2d_weights_merge_publish(double* d_logw, int32_t N, const double* d_part
                                  double* d_w, double* d_stats, uint32_t* d_norm_sync, void* stream) {
     if (!d_logw || !d_parts || !d_w || !d_stats || !d_norm_sync || N <= 0 || world <= 0 || total_particles < N) return SLAM2D_E_BADARG;
     k_weights_merge<<<1, 256, 0, (hipStream_t)stream>>>(d_logw, N, d_parts, world, (double)total_particles, d_w, d_stats, nullptr, 0, 0u, d_norm_sync);
+    return launch_status();
+}
+
+int slam2d_weights_merge_publish_report(double* d_logw, int32_t N, const double* d_parts, int32_t world, int64_t total_particles,
+                                        double* d_w, double* d_stats, uint32_t* d_norm_sync, const double* d_pack, double* h_pack,
+                                        int32_t pack_doubles, uint32_t* h_seq, uint32_t report_seq, void* stream) {
+    if (!d_logw || !d_parts || !d_w || !d_stats || !d_norm_sync || N <= 0 || world <= 0 || total_particles < N) return SLAM2D_E_BADARG;
+    if (!d_pack || !h_pack || !h_seq || pack_doubles <= 0) return SLAM2D_E_BADARG;
+    k_weights_merge<<<1, 256, 0, (hipStream_t)stream>>>(d_logw, N, d_parts, world, (double)total_particles, d_w, d_stats, nullptr, 0, 0u, d_norm_sync,
+                                                        d_pack, h_pack, pack_doubles, h_seq, report_seq);
     return launch_status();
 }
 

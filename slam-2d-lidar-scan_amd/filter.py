@@ -77,6 +77,11 @@ class MapView:
         return self._m.image(xIdx[0], xIdx[1], yIdx[0], yIdx[1], flipud=True, as_u8=as_u8).cpu().numpy()
 
 
+# the host's bound on a scan's report: beyond the device-side waits' (word 59 of the sync block: 30 s unless SLAM2D_SYNC_TIMEOUT_MS says otherwise),
+# so that a tripped device-side wait is what the caller gets to see
+_HOST_WAIT_S = 15.0 + (int(os.environ["SLAM2D_SYNC_TIMEOUT_MS"]) / 1e3 if os.environ.get("SLAM2D_SYNC_TIMEOUT_MS", "").isdigit() else 30.0)
+
+
 class _ReportWaiter:
     """Stands where a torch Event stood in run()'s pending tuple: the scan's report is PUSHED into the pinned host pack by the
     device (Slam2dScan.h_seq); synchronize() polls the sequence word from C (GIL released), bounded."""
@@ -86,7 +91,7 @@ class _ReportWaiter:
         self.ptr, self.seq = ptr, seq
 
     def synchronize(self):
-        _lib.check(_lib.lib().slam2d_host_wait_seq(self.ptr, self.seq, 20.0), "slam2d_host_wait_seq")
+        _lib.check(_lib.lib().slam2d_host_wait_seq(self.ptr, self.seq, _HOST_WAIT_S), "slam2d_host_wait_seq")
 
 
 def _heading(dx, dy, dist):
@@ -145,7 +150,7 @@ class ParticleFilter:
     two or four groups than in one.  Results are those of one group."""
 
     def __init__(self, numParticles, ogParameters, smParameters, device=None, growable=True, rng=None,
-                 total_particles=None, first_index=0, group=None, bnb=None, match_max=False, groups=None):
+                 total_particles=None, first_index=0, group=None, bnb=None, match_max=False, groups=None, force_sharded=False):
         (mapX, mapY, initXY, unit, fov, max_range, beams, wall) = ogParameters            # :66
         (sr, half_rad, sigma, move_sigma, max_dev, turn_sigma, miss, cf) = smParameters   # :67-68
         self.device = require_gpu(device or "cuda:0")
@@ -156,7 +161,7 @@ class ParticleFilter:
         self.match_max = bool(match_max)
         self.rng = rng
         self.group = group
-        self.sharded = self.total_particles != numParticles
+        self.sharded = self.total_particles != numParticles or bool(force_sharded)     # (force_sharded: the sharded code path on ONE rank)
         if self.sharded:
             import torch.distributed as dist
             if not dist.is_initialized():
@@ -225,10 +230,21 @@ class ParticleFilter:
         g = int(env_g) if env_g.isdigit() else (groups if groups is not None else self.auto_groups(P, self.sharded))
         if g > 4:                                        # (the GPU runs four queues side by side: five groups and more take turns --
             g = 4 if P % 4 == 0 else 2                   #  open loop 0.265-0.30 ms per scan against 0.10-0.11, closed loop 0.91 s against 0.20)
-        self.n_groups = g if (g > 1 and P % g == 0 and not self.sharded) else 1
+        if self.sharded:
+            # every rank gathers the same number of partials per scan: the same G everywhere, so it has to divide every rank's share
+            counts = [parallel.shard_range(self.total_particles, self.world, r)[1] for r in range(self.world)]
+            if not env_g.isdigit() and groups is None:
+                g = self.auto_groups(min(counts), True)
+            self.n_groups = g if (g > 1 and all(c % g == 0 for c in counts)) else 1
+        else:
+            self.n_groups = g if (g > 1 and P % g == 0) else 1
         # run() goes through the grouped calls even with ONE group (their event-free closed loop: ranges pulled, report pushed:
-        # 0.2215 s against 0.2284 s for the 910 Intel scans at 64 particles); SLAM2D_FILTER_GROUPED1=0: the one-stream calls
-        self.grouped_single = os.environ.get("SLAM2D_FILTER_GROUPED1", "1") == "1" and not self.sharded
+        # 0.2215 s against 0.2284 s for the 910 Intel scans at 64 particles); SLAM2D_FILTER_GROUPED1=0: the one-stream calls.
+        # A sharded filter too (round 6): its commit ends in slam2d_norm_gate + the all-gather of the partials +
+        # slam2d_weights_merge_publish_report on the normaliser's stream (the event path, SLAM2D_FILTER_EVENTS=1, is one rank's only)
+        self.grouped_single = os.environ.get("SLAM2D_FILTER_GROUPED1", "1") == "1"
+        if self.sharded and os.environ.get("SLAM2D_FILTER_EVENTS", "0") == "1":
+            self.n_groups, self.grouped_single = 1, False
         self._grp = None                                 # streams, events, level views: built by the first grouped run()
         # run(): scans redone step by step (discarded speculative match); resample(): all / those that moved any state
         self.stats = {"redo": 0, "aborted": 0, "reissued": 0, "step_by_step": 0, "resamples": 0, "state_moving_resamples": 0}
@@ -240,8 +256,10 @@ class ParticleFilter:
         host has cores for the threads that issue them (slam2d_group_policy); else one.  Round 5, 64 particles x the 910 Intel
         scans, legs interleaved in one process: one group 0.2284 s, one through the event-free calls 0.2215, two 0.2064, four
         0.2043 (the event path of rounds 3-4: 0.238 in two, 0.42-0.60 in four)."""
-        if sharded or not _lib.group_policy()["threads"]:
+        if not _lib.group_policy()["threads"]:
             return 1
+        if sharded:          # (a sharded rank: two groups + the normaliser's stream + the collective's make four busy queues, the most the
+            return 2 if (P >= 16 and P % 2 == 0) else 1      #  GPU runs side by side: bench.py, one-rank RCCL group, 0.1211 ms in two groups, 0.1286 in four)
         if P >= 32 and P % 4 == 0:
             return 4
         return 2 if (P >= 16 and P % 2 == 0) else 1
@@ -332,6 +350,13 @@ class ParticleFilter:
             self._normalize_on_device()                             # Algorithm/FastSlam.py:43-48, ahead of weightUnbalanced()
             self._h_pack.copy_(self._d_pack, non_blocking=True)     # poses, confidences, weights, variance
             eng.take_flags()                                        # the one synchronisation of the scan
+            while self.sharded and np.isnan(self._h_pack.numpy()[6 * P]) and self._h_pack.numpy()[6 * P + 1] == -1.0:
+                # another rank voided this scan in its pipelined run() (its groups left the void partial: slam2d.h,
+                # slam2d_weights_merge_publish_report): nothing was merged; gather again -- that rank comes back with the scan
+                self.stats["peer_voids"] = self.stats.get("peer_voids", 0) + 1
+                self._normalizer(self.d_logw, None, 1, self.d_w, self.d_stats, local_done=True)
+                self._h_pack.copy_(self._d_pack, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
             rep = self._h_pack.numpy()[:5 * P].reshape(P, 5)
             matched, conf = rep[:, 0:3].copy(), rep[:, 3].copy()
             self._normalized_step = self.step + 1
@@ -369,7 +394,7 @@ class ParticleFilter:
         # pending = (count, reading, raw_heading, event, state of the random stream before the scan's uniforms) of the scan in flight
         resamples, pending = [], None
         events = [torch.cuda.Event(), torch.cuda.Event()]
-        grouped = (self.n_groups > 1 or self.grouped_single) and self.lazy_field and not self.sharded
+        grouped = (self.n_groups > 1 or self.grouped_single) and self.lazy_field
         if grouped and self._grp is None:
             self._setup_groups()
 
@@ -380,7 +405,12 @@ class ParticleFilter:
         # finds the bit in the scan's report, grows the maps and runs the scan again, step by step.  (Round 2 did not speculate
         # while any window was within 2.5 m of a map's edge: 39 % of the Intel log's scans.)  Sharded filters commit in three
         # calls around a collective and keep the conservative rule.
-        abortable = self.growable and not self.sharded
+        # ... Sharded filters on the grouped calls (round 6) void a scan RANK BY RANK: particles are independent, so a rank whose
+        # windows were inside commits its share, and only the normaliser waits -- the voiding rank's groups leave a void partial,
+        # every rank's merge reports the scan as voided and changes nothing; the voiding rank grows and re-issues, the others
+        # answer with another all-gather + merge over the partials they already hold (slam2d_weights_merge_publish_report).  On the
+        # one-stream calls a sharded filter keeps the conservative rule (no speculation near a map's edge).
+        abortable = self.growable and (not self.sharded or (grouped and self._grp.devsync))
         abort_mask = _lib.F_WINDOW_OUTSIDE_MAP if abortable else 0
 
         def was_aborted(p):
@@ -388,6 +418,11 @@ class ParticleFilter:
             p[3].synchronize()
             if abortable and (self._h_flagsnap.numpy().view(np.uint32) & abort_mask).any():
                 return True
+            if self.sharded and abortable:
+                while np.isnan(self._h_pack.numpy()[6 * P]) and self._h_pack.numpy()[6 * P + 1] == -1.0:
+                    # voided on ANOTHER rank: this rank's commit stands; meet the re-issued scan's partials in another all-gather
+                    self.stats["peer_voids"] = self.stats.get("peer_voids", 0) + 1
+                    self._sharded_regather().synchronize()
             self._check_flag_snapshot()
             return False
 
@@ -409,7 +444,7 @@ class ParticleFilter:
 
         # the next scan's pose prior rides in this scan's commit (slam2d_scan_commit_next) when the next reading is at hand:
         # prior_ready = count of the scan whose prior the last commit wrote (its match then skips the prior's launch)
-        fold_prior = (not grouped or self._grp.devsync) and not self.sharded and os.environ.get("SLAM2D_FILTER_FOLD_PRIOR", "1") != "0"
+        fold_prior = ((not grouped and not self.sharded) or (grouped and self._grp.devsync)) and os.environ.get("SLAM2D_FILTER_FOLD_PRIOR", "1") != "0"
         prior_ready = [None]
 
         def plain(count, reading):
@@ -613,6 +648,15 @@ class ParticleFilter:
         sc.d_parts = grp.parts.data_ptr()
         sc.norm_stream, sc.ev_merged, sc.ev_inputs = C.c_void_p(grp.norm.cuda_stream), grp.ev_merged, grp.ev_inputs
         sc.merge = 1
+        if self.sharded:
+            # the groups only arrive and wait (merge == 0); the rank's G partials are all-gathered on the normaliser's stream and merged
+            # there in (rank, group) order (_sharded_gather_merge)
+            import torch.distributed as dist
+            grp.parts_all = torch.zeros((G * self.world, 3), dtype=torch.float64, device=dev)
+            sc.merge, sc.n_parts, sc.total_particles = 0, G * self.world, self.total_particles
+            sc.d_parts = grp.parts_all.data_ptr()
+            grp.via_host = dist.get_backend(self.group) == "gloo"
+            grp.rccl = None if grp.via_host else parallel.DirectRccl.create(dev, self.group)
         grp.merged_once, grp.active = False, False
         # Round 5: the grouped closed loop WITHOUT events and copies (include/slam2d.h, ABI 16).  Every group's prior launch pulls the
         # scan's inputs from the pinned staging buffer; the abort decision over all groups' fault bits sits behind an arrival counter
@@ -630,8 +674,12 @@ class ParticleFilter:
                 grp.c[g].ev_matched = grp.c[g].ev_done = None
             sc.ev_inputs = sc.ev_merged = sc.norm_stream = None
             sc.d_norm_sync = grp.sync.data_ptr()
-            sc.h_seq, sc.h_pack, sc.d_pack = grp.h_seq.data_ptr(), self._h_pack.data_ptr(), self._d_pack.data_ptr()
-            sc.pack_doubles = self._d_pack.numel()
+            ms = os.environ.get("SLAM2D_SYNC_TIMEOUT_MS", "")
+            if ms.isdigit():                             # the bound of the device-side waits (word 59; default 30 s)
+                grp.sync[59] = int(ms)
+            if not self.sharded:                         # (sharded: the merge on the normaliser's stream pushes the report, slam2d_weights_merge_publish_report)
+                sc.h_seq, sc.h_pack, sc.d_pack = grp.h_seq.data_ptr(), self._h_pack.data_ptr(), self._d_pack.data_ptr()
+                sc.pack_doubles = self._d_pack.numel()
             torch.cuda.synchronize(dev)
         self._grp = grp
 
@@ -745,6 +793,13 @@ class ParticleFilter:
         if os.environ.get("SLAM2D_FILTER_NO_ABORT") == "1":      # timing experiment only (a window leaving a map is then fatal)
             sc.abort_mask = 0
         if grp.devsync:
+            # as in the match: nothing orders the group streams behind the main stream -- a resample that moved nothing leaves the
+            # speculative match standing and its weight reset (d_logw / d_w fills) on the main stream, which this commit's normaliser
+            # blocks rewrite (idle in the steady state: one query)
+            ms = torch.cuda.current_stream(self.device)
+            if not ms.query():
+                ms.synchronize()
+        if grp.devsync:
             sc.match_seq = grp.gate_seq or 1             # (the match call's: its particles are what this commit's gates wait for)
             if next_prior is not None:
                 # the next scan's prior and ranges ride in this commit (Slam2dScan.h_next_ranges): its ranges go into the OTHER
@@ -758,6 +813,8 @@ class ParticleFilter:
             grp.report_seq = (grp.report_seq + 1) & 0xFFFFFFFF
             sc.report_seq = grp.report_seq
             _lib.check(L.slam2d_groups_commit(C.byref(eng.lidar_c), grp.c, self.n_groups, C.byref(sc)), "slam2d_groups_commit")
+            if self.sharded:
+                self._sharded_gather_merge(grp.report_seq)
             grp.merged_once = True
             return _ReportWaiter(grp.h_seq.data_ptr(), grp.report_seq)
         _lib.check(L.slam2d_groups_commit(C.byref(eng.lidar_c), grp.c, self.n_groups, C.byref(sc)), "slam2d_groups_commit")
@@ -766,6 +823,40 @@ class ParticleFilter:
             self._h_pack.copy_(self._d_pack, non_blocking=True)
             grp.ready[parity].record()
         return grp.ready[parity]
+
+    def _sharded_regather(self):
+        """Another all-gather + merge of the scan just committed, over the partials this rank already holds (the scan was voided on
+        another rank and comes again there): no gate -- this rank's groups do not arrive a second time."""
+        grp = self._grp
+        grp.report_seq = (grp.report_seq + 1) & 0xFFFFFFFF
+        self._sharded_gather_merge(grp.report_seq, gate=False)
+        return _ReportWaiter(grp.h_seq.data_ptr(), grp.report_seq)
+
+    def _sharded_gather_merge(self, report_seq, gate=True):
+        """The sharded half of a grouped commit, on the normaliser's stream: a one-wave gate waits for the groups' normaliser blocks
+        (their partials), ONE all-gather of the rank's G x 3 doubles, then the merge over all (rank, group) partials in that order --
+        which publishes the word the groups' next normaliser blocks wait for and pushes the scan's report to the host
+        (slam2d_weights_merge_publish_report).  No event, no copy; with RCCL nothing here waits on the host."""
+        import torch.distributed as dist
+        grp, L, G = self._grp, _lib.lib(), self.n_groups
+        ns = C.c_void_p(grp.norm.cuda_stream)
+        if gate:
+            _lib.check(L.slam2d_norm_gate(C.c_void_p(grp.sync.data_ptr()), G, ns), "slam2d_norm_gate")
+        if grp.rccl is not None:
+            grp.rccl.all_gather(grp.parts.data_ptr(), grp.parts_all.data_ptr(), 3 * G, ns)
+        else:
+            with torch.cuda.stream(grp.norm):
+                if grp.via_host:                         # gloo (tests, dry runs): the partials hop through host memory
+                    mine = grp.parts.reshape(-1).cpu()
+                    got = [torch.empty_like(mine) for _ in range(self.world)]
+                    dist.all_gather(got, mine, group=self.group)
+                    grp.parts_all.copy_(torch.cat(got).reshape(-1, 3))
+                else:
+                    dist.all_gather_into_tensor(grp.parts_all.reshape(-1), grp.parts.reshape(-1), group=self.group)
+        _lib.check(L.slam2d_weights_merge_publish_report(
+            _ptr(self.d_logw), self.numParticles, _ptr(grp.parts_all), G * self.world, self.total_particles, _ptr(self.d_w), _ptr(self.d_stats),
+            C.c_void_p(grp.sync.data_ptr()), _ptr(self._d_pack), _ptr(self._h_pack), self._d_pack.numel(), C.c_void_p(grp.h_seq.data_ptr()),
+            int(report_seq), ns), "slam2d_weights_merge_publish_report")
 
     def _enqueue_match(self, reading, prev_raw, dist, has_turn, turn, prior_ready=False):
         """prior + coarse + fine match of one scan for all particles (slam2d_scan_match: one library call); reads the
@@ -924,7 +1015,10 @@ class ParticleFilter:
         """log-weights -> normalised weights + variance on the device (no host round trip)."""
         if self.sharded:
             if self._normalizer is None:
-                self._normalizer = parallel.ShardedNormalizer(_lib.lib(), _lib.check, self.device, self.total_particles, self.group)
+                # (partials per rank: as many as run()'s grouped commits gather, so that a rank that takes a scan step by step and a
+                # rank that takes it through the groups meet in the same all-gather)
+                slots = self.n_groups if (self.n_groups > 1 or self.grouped_single) and self.lazy_field else 1
+                self._normalizer = parallel.ShardedNormalizer(_lib.lib(), _lib.check, self.device, self.total_particles, self.group, slots=slots)
             self._normalizer(self.d_logw, None, 1, self.d_w, self.d_stats)
         else:
             _lib.check(_lib.lib().slam2d_weights_normalize(_ptr(self.d_logw), None, 1, self.numParticles, _ptr(self.d_w),

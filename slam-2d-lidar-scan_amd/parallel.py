@@ -171,11 +171,18 @@ class ShardedNormalizer:
     normalise this rank's particles, variance over all N).  The torch-op version above costs a dozen
     small launches per scan (measured 77 us on one MI355X -- a quarter of a config-2 step)."""
 
-    def __init__(self, lib, check, device, total, group=None, overlap=False):
+    def __init__(self, lib, check, device, total, group=None, overlap=False, slots=1):
+        """slots: partials per rank in the all-gather -- a filter whose run() steps its particles in G groups gathers G partials
+        per rank and scan (filter._sharded_gather_merge); its step-by-step scans must take part in collectives of the same shape:
+        the rank's one partial goes into slot 0, the other slots hold the empty partial (max -inf, sums 0: it adds nothing)."""
         self.lib, self.check, self.total, self.group = lib, check, int(total), group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.part = torch.zeros(3, dtype=torch.float64, device=device)
-        self.parts = torch.zeros(3 * self.world, dtype=torch.float64, device=device)
+        self.slots = int(slots)
+        self._part_all = torch.zeros(3 * self.slots, dtype=torch.float64, device=device)
+        for k in range(1, self.slots):
+            self._part_all[3 * k] = float("-inf")
+        self.part = self._part_all[:3]
+        self.parts = torch.zeros(3 * self.slots * self.world, dtype=torch.float64, device=device)
         self.via_host = dist.is_initialized() and dist.get_backend(group) == "gloo"
         self.rccl = DirectRccl.create(device, group) if dist.is_initialized() and not self.via_host else None
         # overlap: the collective and the merge run on a side stream, so the launch stream goes straight on to the next
@@ -223,25 +230,25 @@ class ShardedNormalizer:
                 t.record_stream(self.side)
             with torch.cuda.stream(self.side):
                 self.side.wait_event(self.ev_local)
-                dist.all_gather_into_tensor(self.parts, self.part, group=self.group)
-                self.check(self.lib.slam2d_weights_merge(logw.data_ptr(), n, self.parts.data_ptr(), self.world, self.total,
+                dist.all_gather_into_tensor(self.parts, self._part_all, group=self.group)
+                self.check(self.lib.slam2d_weights_merge(logw.data_ptr(), n, self.parts.data_ptr(), self.world * self.slots, self.total,
                                                          w.data_ptr(), stats.data_ptr(), self.side.cuda_stream),
                            "slam2d_weights_merge")
                 self.ev_merged.record(self.side)
             self.pending = True
             return
         if not dist.is_initialized():
-            self.parts.copy_(self.part)
+            self.parts.copy_(self._part_all)
         elif self.via_host:                                   # gloo: the 24 bytes hop through host memory
-            mine = self.part.cpu()
+            mine = self._part_all.cpu()
             got = [torch.empty_like(mine) for _ in range(self.world)]
             dist.all_gather(got, mine, group=self.group)
             self.parts.copy_(torch.cat(got))
         elif self.rccl is not None:                           # one RCCL call on the launch stream itself (no c10d, no stream hop)
-            self.rccl.all_gather(self.part.data_ptr(), self.parts.data_ptr(), 3, stream)
+            self.rccl.all_gather(self._part_all.data_ptr(), self.parts.data_ptr(), 3 * self.slots, stream)
         else:
-            dist.all_gather_into_tensor(self.parts, self.part, group=self.group)
-        self.check(self.lib.slam2d_weights_merge(logw.data_ptr(), n, self.parts.data_ptr(), self.world, self.total,
+            dist.all_gather_into_tensor(self.parts, self._part_all, group=self.group)
+        self.check(self.lib.slam2d_weights_merge(logw.data_ptr(), n, self.parts.data_ptr(), self.world * self.slots, self.total,
                                                  w.data_ptr(), stats.data_ptr(), stream), "slam2d_weights_merge")
 
 

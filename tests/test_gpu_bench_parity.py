@@ -175,13 +175,16 @@ def test_benchmarked_config5_slice_matches_oracle(bench):
 
 def test_device_side_waits_are_bounded(bench):
     """The groups' normaliser waits on the device (Slam2dScan.d_norm_sync); a producer that never arrives must end as the fatal
-    SLAM2D_F_SYNC_TIMEOUT after the 2 s bound, not as a hung GPU: (a) the sharded path's gate kernel with nobody to count,
+    SLAM2D_F_SYNC_TIMEOUT after the bound (word 59 of the sync block, milliseconds; 0 = 30 s), not as a hung GPU: (a) the sharded
+    path's gate kernel with nobody to count -- and it leaves the arrival counter alone (late groups still count themselves in),
     (b) a group's normaliser block told to expect a merge that never happens (its step still completes, flagged)."""
     import ctypes as C
     import time
     import torch
     L = E._lib.lib()
     sync = torch.zeros(64, dtype=torch.int32, device="cuda")
+    sync[59] = 1500                                # the bound of this test: 1.5 s
+    sync[0] = 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     E._lib.check(L.slam2d_norm_gate(C.c_void_p(sync.data_ptr()), 1, E._stream()), "slam2d_norm_gate")
@@ -198,6 +201,7 @@ def test_device_side_waits_are_bounded(bench):
     hot.step(0)
     assert not (hot.take_flags() & E._lib.FATAL_FLAGS).any()
     hot.norm_sync[2] += 1                         # group 0's next normaliser block now waits for a merge nobody will publish
+    hot.norm_sync[59] = 1500
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     hot.step(1)

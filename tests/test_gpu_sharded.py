@@ -82,6 +82,72 @@ def test_two_rank_filter_reproduces_the_golden_run(tmp_path, golden, n_scans):
     assert [open(os.path.join(str(tmp_path), f"ok{r}")).read() for r in range(2)] == ["True", "True"]
 
 
+def _run_worker(rank, world, port, golden, groups, out_dir):
+    """A rank of a sharded filter driven by ParticleFilter.run(): the pipelined, event-free closed loop (round 6: the sharded commit is
+    slam2d_groups_commit + slam2d_norm_gate + the all-gather of the partials + slam2d_weights_merge_publish_report)."""
+    import hashlib as hl
+    import torch.distributed as dist
+    here = os.path.dirname(os.path.abspath(__file__))
+    for pth in (os.path.dirname(here), os.path.join(here, "golden")):
+        if pth not in sys.path:
+            sys.path.insert(0, pth)
+    import codec
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pkg = importlib.import_module("slam-2d-lidar-scan_amd")
+        par = importlib.import_module("slam-2d-lidar-scan_amd.parallel")
+        z = np.load(os.path.join(here, "golden", golden))
+        zi = np.load(os.path.join(here, "golden", "intel_gfs.npz"))
+        rng_cm = zi["range_cm"].astype(np.float64) / 100.0
+        readings = [{"x": float(p[0]), "y": float(p[1]), "theta": float(p[2]), "range": r} for p, r in zip(zi["pose"], rng_cm)]
+        n_particles, n_scans, seed, map_m = (int(v) for v in z["cfg"])
+        first, count = par.shard_range(n_particles, world, rank)
+        u = 0.02
+        ogP = [map_m, map_m, readings[0], u, np.pi, 10, 180, 5 * u]
+        pf = pkg.ParticleFilter(count, ogP, list(REF_SM), rng=np.random.RandomState(seed), total_particles=n_particles,
+                                first_index=first, groups=groups)
+        why, seen = [], []
+
+        def expect(cond, what):
+            if not cond and len(why) < 5:
+                why.append(what)
+
+        def on_scan(c, f, unb):
+            expect(unb == bool(z["unbalanced"][c - 1]), f"scan {c}: unbalanced {unb}")
+            expect(np.allclose(f.weights, z["weights"][c - 1][first:first + count], rtol=1e-5, atol=1e-290), f"scan {c}: weights")
+            expect(np.isclose(f.last_variance, z["variance"][c - 1], rtol=1e-5, atol=1e-12), f"scan {c}: variance {f.last_variance}")
+            expect(np.array_equal(f.prev_matched, z["matched"][c - 1][first:first + count]), f"scan {c}: matched poses")
+            seen.append(c)
+        resamples = pf.run(readings[:n_scans], force_resample=set(int(v) for v in z["force_resample"]), on_scan=on_scan)
+        expect(seen == list(range(1, n_scans + 1)), f"scans seen {len(seen)}")
+        expect(pf._grp is not None and pf._grp.devsync and pf.n_groups == groups, "the run did not go through the grouped, event-free calls")
+        expect(pf.stats["step_by_step"] < n_scans // 2, f"stats {pf.stats}")
+        got = np.array([np.concatenate(([c], idx)) for c, idx in resamples]).reshape(-1, n_particles + 1)
+        expect(np.array_equal(got, z["resamples"]), f"resample draws {got[:, 0].tolist()}")
+        shas = [hl.sha256(codec.pack_counts(*m.download()).tobytes()).digest() for m in pf.engine.maps]
+        expect(all(sh == z["maps_sha"][first + i].tobytes() for i, sh in enumerate(shas)), "final maps")
+        lims = [[m.lim_x[0], m.lim_x[1], m.lim_y[0], m.lim_y[1]] for m in pf.engine.maps]
+        expect(np.array_equal(np.array(lims), z["final_lims"][first:first + count]), "final map limits")
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("True" if not why else "; ".join(why) + f" | stats {pf.stats}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("golden,groups", [("flow_fastslam_growth.npz", 1), ("flow_fastslam_long.npz", 1), ("flow_fastslam_long.npz", 3)])
+def test_two_rank_filter_run_reproduces_the_golden_run(tmp_path, golden, groups):
+    """The sharded CLOSED loop on the event-free grouped calls (Algorithm/FastSlam.py:25-48,152-163 over two ranks): the 3-particle
+    run from a 10 m map (2 + 1 particles: ragged shards, growth, resamples that move maps across ranks) and the 6-particle run over
+    the whole 910-scan Intel log with its five natural resamples (3 + 3, in one group and in three groups per rank) -- every matched
+    pose, weight, trigger decision, resample draw and final map as the reference's."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    mp.spawn(_run_worker, args=(2, _free_port(), golden, groups, str(tmp_path)), nprocs=2, join=True)
+    assert [open(os.path.join(str(tmp_path), f"ok{r}")).read() for r in range(2)] == ["True", "True"]
+
+
 def _rccl_worker(port, out_path):
     """One rank over the nccl (= RCCL) backend: the overlapped normaliser against the in-order one and against
     slam2d_weights_normalize, over a sequence of scans (the carried log-weights make every scan depend on the last)."""
