@@ -15,6 +15,9 @@ import time
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
+# four particle groups on their own HIP streams + the default stream want more hardware queues than the runtime's 4: the
+# application's choice, made before the process's first HIP call ("environment")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import numpy as np  # noqa: E402
 
 

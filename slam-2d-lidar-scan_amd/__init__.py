@@ -15,11 +15,10 @@ CPU fallback.
 """
 __version__ = "0.1.0"
 
-# Particle groups run on their own HIP streams (ParticleFilter(groups=G), slam2d_groups_*), and streams that share a hardware queue
-# serialise: the HIP runtime's default of 4 queues holds two groups beside the default stream.  The runtime reads this when it
-# initialises, i.e. at the process's first HIP call -- import this package (or set the variable) before that for more than two groups.
-import os as _os
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (Importing this package changes nothing in the process's environment.  Particle groups run on their own HIP streams, and streams
+# that share a hardware queue take turns: the HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES = 4 queues unless the
+# APPLICATION sets the variable before its first HIP call -- bench.py and the examples set 8; engine.group_streams() sets it only
+# when HIP has not been initialised yet and otherwise says so once.  INTEGRATION.md, "environment".)
 
 _LAZY = {
     "OccupancyGrid": ("grid", "OccupancyGrid"),

@@ -11,6 +11,7 @@ host<->device copies and for the stream handle.
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -92,6 +93,16 @@ def group_streams(device, n):
     four groups 0.42-0.50 s against 0.21 s when two of its streams were taken from the pool later than the others (round 5)."""
     dev = torch.device(device)
     key = str(dev)
+    if n > 3 and "GPU_MAX_HW_QUEUES" not in os.environ and not _GROUP_STREAMS:
+        # more than two groups (+ the normaliser's stream) need more than the runtime's default of 4 hardware queues, and the
+        # runtime reads the variable when it initialises: this is the last place where this library can still set it -- if no HIP
+        # call has been made yet.  Otherwise the application has to (before importing torch.cuda work): say so, once.
+        if not torch.cuda.is_initialized():
+            os.environ["GPU_MAX_HW_QUEUES"] = "8"
+        else:
+            import warnings
+            warnings.warn("slam2d: %d particle-group streams on the HIP runtime's default of 4 hardware queues (HIP is already initialised): "
+                          "groups that share a queue take turns; set GPU_MAX_HW_QUEUES=8 before the process's first HIP call" % n, RuntimeWarning, stacklevel=2)
     have = _GROUP_STREAMS.setdefault(key, [])
     while len(have) < n:
         k = max(9 if not have else 0, n - len(have))

@@ -144,7 +144,9 @@ class ParticleFilter:
     the cube is large enough for it to pay (engine.bnb_default), True / False: wherever applicable / nowhere.
     ``groups``: ``run()`` steps the particles in this many groups, each on its own HIP stream, joined only by the weight
     normaliser (slam2d_groups_match_begin / slam2d_groups_commit) -- None: ``auto_groups`` (SLAM2D_FILTER_GROUPS overrides); at
-    most four (the GPU runs four compute queues side by side, whatever GPU_MAX_HW_QUEUES says: a fifth group makes them take turns).
+    most four (the GPU runs four compute queues side by side: a fifth group makes them take turns -- and four groups get a queue each
+    only when the application has set GPU_MAX_HW_QUEUES >= 8 before its first HIP call; on the runtime's default of 4 hardware queues
+    two groups share one with the default stream's, engine.group_streams).
     Through round 4 the closed loop gained nothing from groups (ten event packets and two copy-engine transfers per scan tied the
     groups together); round 5's grouped calls need none of them (include/slam2d.h, ABI 16) and the closed loop runs 10-12 % faster in
     two or four groups than in one.  Results are those of one group."""

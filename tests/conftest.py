@@ -4,6 +4,9 @@ import sys
 import numpy as np
 import pytest
 
+# the test process is the application here: particle groups on their own streams want more hardware queues than the HIP runtime's
+# default of 4, and the runtime reads this at its first call (the package itself no longer touches the environment)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(REPO, "tests", "golden")
 for p in (REPO, GOLDEN):

@@ -148,6 +148,75 @@ def test_two_rank_filter_run_reproduces_the_golden_run(tmp_path, golden, groups)
     assert [open(os.path.join(str(tmp_path), f"ok{r}")).read() for r in range(2)] == ["True", "True"]
 
 
+def _solo_worker(idx, golden, groups, out_dir):
+    """One of two INDEPENDENT filter processes on the same GPU (no process group): the golden run through ParticleFilter.run() in particle
+    groups, i.e. with the device-side gates and normaliser waits, while the other process's queues compete for the GPU."""
+    import hashlib as hl
+    import time
+    here = os.path.dirname(os.path.abspath(__file__))
+    for pth in (os.path.dirname(here), os.path.join(here, "golden")):
+        if pth not in sys.path:
+            sys.path.insert(0, pth)
+    import codec
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    pkg = importlib.import_module("slam-2d-lidar-scan_amd")
+    z = np.load(os.path.join(here, "golden", golden))
+    zi = np.load(os.path.join(here, "golden", "intel_gfs.npz"))
+    rng_cm = zi["range_cm"].astype(np.float64) / 100.0
+    readings = [{"x": float(p[0]), "y": float(p[1]), "theta": float(p[2]), "range": r} for p, r in zip(zi["pose"], rng_cm)]
+    n_particles, n_scans, seed, map_m = (int(v) for v in z["cfg"])
+    u = 0.02
+    pf = pkg.ParticleFilter(n_particles, [map_m, map_m, readings[0], u, np.pi, 10, 180, 5 * u], list(REF_SM), rng=np.random.RandomState(seed), groups=groups)
+    why, seen = [], []
+
+    def expect(cond, what):
+        if not cond and len(why) < 5:
+            why.append(what)
+
+    def on_scan(c, f, unb):
+        expect(unb == bool(z["unbalanced"][c - 1]), f"scan {c}: unbalanced {unb}")
+        expect(np.allclose(f.weights, z["weights"][c - 1], rtol=1e-5, atol=1e-290), f"scan {c}: weights")
+        expect(np.array_equal(f.prev_matched, z["matched"][c - 1]), f"scan {c}: matched poses")
+        seen.append(c)
+    # start together: wait for the other process's marker
+    open(os.path.join(out_dir, f"ready{idx}"), "w").write("1")
+    t0 = time.time()
+    while not os.path.exists(os.path.join(out_dir, f"ready{1 - idx}")) and time.time() - t0 < 120:
+        time.sleep(0.01)
+    t0 = time.time()
+    resamples = pf.run(readings[:n_scans], force_resample=set(int(v) for v in z["force_resample"]), on_scan=on_scan)
+    el = time.time() - t0
+    expect(seen == list(range(1, n_scans + 1)), f"scans seen {len(seen)}")
+    expect(pf.n_groups == groups and pf._grp is not None and pf._grp.devsync, "not on the device-synchronised grouped calls")
+    got = np.array([np.concatenate(([c], idx_)) for c, idx_ in resamples]).reshape(-1, n_particles + 1)
+    expect(np.array_equal(got, z["resamples"]), "resample draws")
+    shas = [hl.sha256(codec.pack_counts(*m.download()).tobytes()).digest() for m in pf.engine.maps]
+    expect(all(sh == z["maps_sha"][i].tobytes() for i, sh in enumerate(shas)), "final maps")
+    open(os.path.join(out_dir, f"ok{idx}"), "w").write(("True" if not why else "; ".join(why)) + f" {el:.2f}")
+
+
+def test_two_filter_processes_share_the_gpu(tmp_path):
+    """Two independent closed loops in particle groups on ONE GPU at the same time (each process: three groups on their own streams,
+    device-side gates and normaliser waits whose producers sit in queues the hardware scheduler shares out between the processes):
+    both finish, each identical to its golden -- the waits' bound (30 s) is a dead-producer alarm, not a scheduling assumption."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_solo_worker, args=(i, "flow_fastslam_long.npz", 3, str(tmp_path))) for i in range(2)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(600)
+    alive = [pr.is_alive() for pr in procs]
+    for pr in procs:
+        if pr.is_alive():
+            pr.terminate()
+    assert not any(alive), "a filter process hung"
+    res = [open(os.path.join(str(tmp_path), f"ok{r}")).read().split(" ") for r in range(2)]
+    assert [r[0] for r in res] == ["True", "True"], res
+
+
 def _rccl_worker(port, out_path):
     """One rank over the nccl (= RCCL) backend: the overlapped normaliser against the in-order one and against
     slam2d_weights_normalize, over a sequence of scans (the carried log-weights make every scan depend on the last)."""
