@@ -1067,7 +1067,7 @@ def dropin_serial(P, n_scans, device):
         for pt in parts:
             pt.update(rd, count)
     torch.cuda.synchronize()
-    t_match = t_upd = 0.0
+    t_match = t_upd = t_upd_host = 0.0
     t0 = time.perf_counter()
     for count, rd in enumerate(readings[3:], start=4):
         for pt in parts:
@@ -1089,12 +1089,15 @@ def dropin_serial(P, n_scans, device):
         torch.cuda.synchronize(); a = time.perf_counter()
         matched, _ = pt.sm.matchScan(est, 0.1, None, count, matchMax=False)
         b = time.perf_counter()
-        pt.og.updateOccupancyGrid(matched); pt.og.flush(); torch.cuda.synchronize()
+        pt.og.updateOccupancyGrid(matched)
+        b2 = time.perf_counter()
+        pt.og.flush(); torch.cuda.synchronize()
         c = time.perf_counter()
-        t_match += b - a; t_upd += c - b
+        t_match += b - a; t_upd += c - b; t_upd_host += b2 - b
         pt.prev_matched = matched
     return dict(value=P * n / el, unit="particle-scans/s", scans=n, particles=P, seconds=el, scans_per_sec=n / el,
                 ms_per_matchScan=1e3 * t_match / 8, ms_per_updateOccupancyGrid=1e3 * t_upd / 8,
+                ms_per_updateOccupancyGrid_host=1e3 * t_upd_host / 8,      # the call alone (it does not wait for its launch); the figure before it includes the kernel and a synchronisation
                 note="the reference's serial per-particle loop (Algorithm/FastSlam.py:25-27,122-135) on the drop-in OccupancyGrid / "
                      "ScanMatcher classes: one synchronous matchScan (one upload, one download) and one updateOccupancyGrid per "
                      "particle and scan; host- and PCIe-inclusive")

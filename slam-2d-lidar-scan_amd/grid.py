@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .engine import LidarModel, MapState, ParticleEngine, pinned_stream, require_gpu
+from .engine import MATCH_DOUBLES, LidarModel, MapState, ParticleEngine, pinned_stream, require_gpu
 
 DEFAULT_DEVICE = "cuda:0"
 
@@ -129,6 +129,15 @@ class OccupancyGrid:
         if x - R < m.lim_x[0] or x + R > m.lim_x[1] or y - R < m.lim_y[0] or y + R > m.lim_y[1]:
             shifts = self._grow_for_update(x, y, theta, rng)      # rare: first scan of a small map
         eng = self.engine()
+        lm, self._last_match = getattr(self, "_last_match", None), None
+        if (shifts is None and lm is not None and lm["ref"] is reading and dTheta == 0 and lm["eng"] is eng and reading['range'] is lm["rng"]
+                and (x, y, theta) == lm["pose"]):
+            # the very dict this grid's matcher has just returned, untouched: its pose (the first doubles of the fine match) and the
+            # scan's ranges are on the device already -- one launch, nothing copied (0.075 -> 0.0x ms of host time per call, round 6)
+            with pinned_stream():
+                eng.grid_update(lm["d_pose"], MATCH_DOUBLES, lm["d_rng"], None)
+            self._update_pending = True
+            return
         if shifts is not None:                                      # (rare: synchronous, with its own uploads)
             eng.grid_update(eng.to_device([[x, y, theta]]), 3, eng.to_device(rng), eng.to_device(shifts[None], dtype=np.int32))
             eng.take_flags()
@@ -198,7 +207,7 @@ class OccupancyGrid:
         new = OccupancyGrid.__new__(OccupancyGrid)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            if k in ("map", "_engine", "lidar", "device"):
+            if k in ("map", "_engine", "lidar", "device", "_last_match"):
                 continue
             setattr(new, k, copy.deepcopy(v, memo))
         new.device, new.lidar = self.device, self.lidar
@@ -206,6 +215,7 @@ class OccupancyGrid:
             self._engine.sync_bounds()
         new.map = self.map.clone()
         new._engine = None
+        new._last_match = None
         new._update_pending = False
         new.version = 0
         return new

@@ -180,6 +180,9 @@ class ScanMatcher:
             og._update_pending = False                                            # (the download has looked at the last update's fault bits too)
             matched = {"x": float(f["x"]), "y": float(f["y"]), "theta": float(f["theta"]), "range": rMeasure}
             self.last = dict(coarse=c.copy(), fine=f.copy())
+            # the matched pose and the scan's ranges are still on the device: an updateOccupancyGrid(matched) that follows on this
+            # grid (Algorithm/FastSlam.py:129-133) launches from them -- no second upload (grid.updateOccupancyGrid)
+            og._last_match = dict(ref=matched, pose=(matched["x"], matched["y"], matched["theta"]), rng=rMeasure, d_pose=m_fine, d_rng=d_rng, eng=eng)
             return matched, np.float64(c["confidence"])                            # :79
 
     def searchToMatch(self, probSP, estimatedX, estimatedY, estimatedTheta, rMeasure, xRangeList, yRangeList,
