@@ -732,9 +732,12 @@ def processed_bytes(hot, scen, stats):
             scatter=wm * wm // 8 + 2 * st["occupied_field_cells"],                                              # map bits in; stamped bytes + tile flags out
             triage=2 * lv.tmax * lv.tmax + 4 * groups * nneed + 4 * (st["blur_tiles"] + st["fill_tiles"]),
             blur=256 * (1 + 4) * st["blur_tiles"] + 256 * 4 * st["fill_tiles"],                                 # occupied image in, field out
-            check=(2 * 16 * 4) * (st["blur_tiles"] + st["fill_tiles"]) if lv.bnb else 0.0)                      # block minima in, gmin2 out
+            check=(2 * 16 * 4 + (16 if "gmin2b" in lv.t else 0)) * (st["blur_tiles"] + st["fill_tiles"]) if lv.bnb else 0.0)   # block minima in, gmin2 (+ its byte image) out
         if lv.bnb:
-            d["bound"] = 16 * 4 * st["needed_tiles"] + 4 * lv.ntheta * st["kbar"] + 8 * lv.ntheta * nbt * 4 * ((nbt + 3) // 4)
+            # tile bounds: the bound entries of the needed tiles in (k_bound_lds: the particle's whole byte image, staged in LDS once),
+            # cell lists in, one double per pose tile out
+            staged = 4 * lv.tmax * lv.g2b_pitch if "gmin2b" in lv.t and os.environ.get("SLAM2D_BOUND_LDS", "1") != "0" else 16 * 4 * st["needed_tiles"]
+            d["bound"] = staged + 4 * lv.ntheta * st["kbar"] + 8 * lv.ntheta * nbt * 4 * ((nbt + 3) // 4)
             d["exact"] = 64 * st["kbar"] * st.get("kept_per_particle", 0.0) + 4 * lv.ntheta * st["kbar"] + 8 * 16 * st.get("kept_per_particle", 0.0)
         else:
             d["sweep"] = 256 * 4 * st["needed_tiles"] + 4 * lv.ntheta * st["kbar"] + 8 * lv.ntheta * lv.nx * lv.nx

@@ -58,7 +58,7 @@ pmc)
       echo "pmc $WL $N rc=$?"
     done
   done
-  ROUND=r05 python tools/summarize_profiles.py > gpurun_out/profile_summary.txt 2>&1; tail -n 60 gpurun_out/profile_summary.txt | cut -c1-260 ;;
+  ROUND=${ROUND:-r06} python tools/summarize_profiles.py > gpurun_out/profile_summary.txt 2>&1; tail -n 60 gpurun_out/profile_summary.txt | cut -c1-260 ;;
 bnbtests)
   timeout 1200 python -m pytest tests -m gpu -q -x -p no:cacheprovider -k "branch_and_bound or benchmarked or config5 or synthetic_shapes or particle_counts" > gpurun_out/pytest_bnb.log 2>&1
   echo "bnbtests rc=$?"; tail -n 15 gpurun_out/pytest_bnb.log | cut -c1-400 ;;

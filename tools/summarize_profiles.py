@@ -67,7 +67,7 @@ for wl in ("config2", "ref2level", "config5"):
         fetch, write = mean.get("FETCH_SIZE", 0.0) * 1024, mean.get("WRITE_SIZE", 0.0) * 1024
         hit, miss = mean.get("TCC_HIT_sum", 0.0), mean.get("TCC_MISS_sum", 0.0)
         lps = n / n_steps
-        k = per_kernel[base]
+        k = per_kernel[{"k_bound_lds": "k_bound"}.get(base, base)]      # (the LDS-staged bounds are the same stage of the step)
         k["fetch"] += fetch * lps; k["write"] += write * lps; k["hit"] += hit * lps; k["miss"] += miss * lps; k["launches"] += n
         lines.append(f"{base + targs:34s} launches/step {lps:5.2f}  FETCH {fetch / 1e6:9.2f} MB  WRITE {write / 1e6:9.2f} MB  2*FETCH+WRITE {(2 * fetch + write) / 1e6:9.2f} MB"
                      f"  L2 hit {100 * hit / (hit + miss) if hit + miss else float('nan'):5.1f} %")
@@ -114,6 +114,7 @@ for wl in ("config2", "ref2level", "config5"):
             dur = collections.defaultdict(lambda: [0.0, 0])
             for r in _csv.DictReader(open(ks[0])):
                 nm = r["Name"].split("(")[0].split("<")[0].replace("void ", "").strip()
+                nm = {"k_bound_lds": "k_bound"}.get(nm, nm)
                 dur[nm][0] += float(r["AverageNs"]) * int(r["Calls"]); dur[nm][1] += int(r["Calls"])
             for base in per_kernel:
                 if dur[base][1]:
