@@ -2441,9 +2441,12 @@ __device__ __forceinline__ void bound_seed_exact(const Slam2dLevel& lv, const in
 // more (a wave's second and third angles mostly find it raised by the first round's seeds): a seed's exact score cannot exceed
 // its bound, so the FINAL bnb_best is the maximum over all seeds whatever is skipped, in whatever order (k_bound2's rule).
 #define BL_BATCH 16
-template <int NSET>
+// RLE (long lists: ~1000 beams): neighbouring beams end in the same 4 x 4-cell block more often than not, so a wave's 64 cell offsets are
+// run-length compressed first (ballot of the run heads, the (offset, run length) pairs compacted through 256 bytes of LDS per wave)
+// and the gathers go over the runs: sum += entry x run length.
+template <int NSET, bool RLE>
 __global__ __launch_bounds__(1024) void k_bound_lds(Slam2dLevel lv, int P, int bpp, int tpb) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char g2s[];                  // [gp][lp]
+    extern __shared__ __attribute__((aligned(16))) unsigned char g2s[];                  // [gp][lp] (+ RLE: [waves][64] words)
     const int lp = lv.g2b_pitch;
     const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
     const int p = (slot / bpp) * 8 + xcd, part = slot % bpp;
@@ -2506,6 +2509,39 @@ __global__ __launch_bounds__(1024) void k_bound_lds(Slam2dLevel lv, int P, int b
         for (int base = 0; base < K; base += WAVE) {
             const int cur = cv;
             if (base + WAVE < K) cv = conv(base + WAVE + lane);
+            if constexpr (RLE) {
+                volatile unsigned* rl = reinterpret_cast<volatile unsigned*>(g2s + (((size_t)gp * lp + 15) & ~(size_t)15)) + w * WAVE;
+                const int n = min(WAVE, K - base);
+                const int prev = __shfl_up(cur, 1);
+                const bool head = lane < n && (lane == 0 || cur != prev);
+                const unsigned long long hm = __ballot(head);
+                const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+                const int nu = __popcll(hm);
+                if (head) {
+                    const unsigned long long later = hm & ~(below | (1ull << lane));
+                    const int nxt = later ? __ffsll((long long)later) - 1 : n;
+                    rl[__popcll(hm & below)] = (unsigned)cur | ((unsigned)(nxt - lane) << 16);     // (offsets < 64 KB: checked at the launch)
+                }
+                const unsigned comp = lane < nu ? rl[lane] : 0u;                                    // (one wave: its LDS operations stay in order)
+#pragma unroll
+                for (int j0 = 0; j0 < WAVE; j0 += BL_BATCH) {
+                    if (j0 < nu) {                              // (wave-uniform)
+                        unsigned char v[NSET][BL_BATCH];
+                        unsigned cnt[BL_BATCH];
+#pragma unroll
+                        for (int i = 0; i < BL_BATCH; ++i) {
+                            const unsigned so = (unsigned)__builtin_amdgcn_readlane((int)comp, j0 + i);
+                            cnt[i] = so >> 16;
+#pragma unroll
+                            for (int s = 0; s < NSET; ++s) v[s][i] = g2s[lbase[s] + (int)(so & 0xFFFFu)];
+                        }
+#pragma unroll
+                        for (int i = 0; i < BL_BATCH; ++i)
+#pragma unroll
+                            for (int s = 0; s < NSET; ++s) sum[s] += (unsigned)v[s][i] * cnt[i];
+                    }
+                }
+            } else {
 #pragma unroll
             for (int j0 = 0; j0 < WAVE; j0 += BL_BATCH) {
                 if (base + j0 < K) {                        // (wave-uniform)
@@ -2522,9 +2558,10 @@ __global__ __launch_bounds__(1024) void k_bound_lds(Slam2dLevel lv, int P, int b
                         for (int s = 0; s < NSET; ++s) sum[s] += v[s][i];
                 }
             }
+            }
         }
         DBG_CLOCK(3, b == 0 && j == 0);
-        const unsigned npad = (unsigned)(((K + BL_BATCH - 1) / BL_BATCH) * BL_BATCH - K);
+        const unsigned npad = RLE ? 0u : (unsigned)(((K + BL_BATCH - 1) / BL_BATCH) * BL_BATCH - K);
         double* __restrict__ bnd = lv.bounds + ((size_t)p * lv.ntheta + it) * nbt * nbq4;
         Best me{-INFINITY, INT_MAX, 0};
 #pragma unroll
@@ -4124,6 +4161,7 @@ static bool launch_bound_lds(const Slam2dLevel& lv, int P, hipStream_t s) {
     static const int mode = [] { const char* e = getenv("SLAM2D_BOUND_LDS"); return e ? atoi(e) : -1; }();
     static const int max_split = [] { const char* e = getenv("SLAM2D_BOUND_LDS_SPLIT"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4; }();
     static const int want_blocks = [] { const char* e = getenv("SLAM2D_BOUND_LDS_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
+    static const int rle_mode = [] { const char* e = getenv("SLAM2D_BOUND_LDS_RLE"); return e ? atoi(e) : -1; }();
     if (mode == 0 || !lv.gmin2b) return false;
     const int nx = 2 * lv.ncell + 1, nbt = (nx + 3) >> 2;
     const int nset = cdiv(nbt * nbt, WAVE);
@@ -4131,30 +4169,38 @@ static bool launch_bound_lds(const Slam2dLevel& lv, int P, hipStream_t s) {
     if (nset > 4 || lv.kmax > 2048 || lp < gp || (lp & 15)) return false;
     const int bpp = max(1, min(min(max_split, lv.ntheta), want_blocks / max(P, 1)));
     const int tpb = cdiv(lv.ntheta, bpp);                       // angles per block
-    const size_t lds = (size_t)gp * lp;
+    const int rounds = cdiv(tpb, 16), nw = cdiv(tpb, rounds);
+    const size_t image = ((size_t)gp * lp + 15) & ~(size_t)15;
+    const bool rle = (rle_mode < 0 ? lv.kmax >= SLAM2D_BEAM_TABLE_MIN : rle_mode != 0) && image + (size_t)nbt * lp < 65536;   // (16-bit offsets in the run words)
+    const size_t lds = image + (rle ? (size_t)nw * WAVE * sizeof(unsigned) : 0);
     const size_t want = 160 * 1024 - 512;
     if (lds > want) return false;
-    static size_t granted[64][4] = {};
+    static size_t granted[64][8] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    size_t& allowed = granted[dev >= 0 && dev < 64 ? dev : 0][nset - 1];
+    size_t& allowed = granted[dev >= 0 && dev < 64 ? dev : 0][(nset - 1) * 2 + (rle ? 1 : 0)];
     if (allowed == 0) allowed = 64 * 1024;
+    const void* fn[8] = {reinterpret_cast<const void*>(k_bound_lds<1, false>), reinterpret_cast<const void*>(k_bound_lds<1, true>),
+                         reinterpret_cast<const void*>(k_bound_lds<2, false>), reinterpret_cast<const void*>(k_bound_lds<2, true>),
+                         reinterpret_cast<const void*>(k_bound_lds<3, false>), reinterpret_cast<const void*>(k_bound_lds<3, true>),
+                         reinterpret_cast<const void*>(k_bound_lds<4, false>), reinterpret_cast<const void*>(k_bound_lds<4, true>)};
     if (lds > allowed) {
-        const void* f = nset == 1 ? reinterpret_cast<const void*>(k_bound_lds<1>) : nset == 2 ? reinterpret_cast<const void*>(k_bound_lds<2>)
-                      : nset == 3 ? reinterpret_cast<const void*>(k_bound_lds<3>) : reinterpret_cast<const void*>(k_bound_lds<4>);
-        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) != hipSuccess) {
+        if (hipFuncSetAttribute(fn[(nset - 1) * 2 + (rle ? 1 : 0)], hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) != hipSuccess) {
             (void)hipGetLastError();
             return false;
         }
         allowed = want;
     }
-    const int rounds = cdiv(tpb, 16), nw = cdiv(tpb, rounds);
     const unsigned grid = (unsigned)cdiv(P, 8) * 8 * bpp;
-    switch (nset) {
-        case 1: k_bound_lds<1><<<grid, WAVE * nw, lds, s>>>(lv, P, bpp, tpb); break;
-        case 2: k_bound_lds<2><<<grid, WAVE * nw, lds, s>>>(lv, P, bpp, tpb); break;
-        case 3: k_bound_lds<3><<<grid, WAVE * nw, lds, s>>>(lv, P, bpp, tpb); break;
-        default: k_bound_lds<4><<<grid, WAVE * nw, lds, s>>>(lv, P, bpp, tpb); break;
+    switch ((nset - 1) * 2 + (rle ? 1 : 0)) {
+        case 0: k_bound_lds<1, false><<<grid, WAVE * nw, lds, s>>>(lv, P, bpp, tpb); break;
+        case 1: k_bound_lds<1, true><<<grid, WAVE * nw, lds, s>>>(lv, P, bpp, tpb); break;
+        case 2: k_bound_lds<2, false><<<grid, WAVE * nw, lds, s>>>(lv, P, bpp, tpb); break;
+        case 3: k_bound_lds<2, true><<<grid, WAVE * nw, lds, s>>>(lv, P, bpp, tpb); break;
+        case 4: k_bound_lds<3, false><<<grid, WAVE * nw, lds, s>>>(lv, P, bpp, tpb); break;
+        case 5: k_bound_lds<3, true><<<grid, WAVE * nw, lds, s>>>(lv, P, bpp, tpb); break;
+        case 6: k_bound_lds<4, false><<<grid, WAVE * nw, lds, s>>>(lv, P, bpp, tpb); break;
+        default: k_bound_lds<4, true><<<grid, WAVE * nw, lds, s>>>(lv, P, bpp, tpb); break;
     }
     return true;
 }

@@ -628,7 +628,11 @@ class SearchLevel:
         # bound: ~1000-cell lists); SLAM2D_BNB_LEVELS=1 / 2 forces the choice
         import os
         lv_env = os.environ.get("SLAM2D_BNB_LEVELS", "auto")
-        self.bnb_levels = 0 if not self.bnb else (int(lv_env) if lv_env in ("1", "2") else (2 if lidar.beams >= 512 else 1))
+        # (round 6: with the bound image staged in LDS -- k_bound_lds, where it fits in 64 KB beside the run words -- one level of
+        # bounds beats two at 1081 beams as well: config 5 1.203 -> 1.130 ms per 128-particle step)
+        gp_ = 4 * self.tmax
+        lds_one_level = os.environ.get("SLAM2D_BOUND_LDS", "1") != "0" and gp_ * g2b_pitch(gp_) + nbt_ * g2b_pitch(gp_) + 16 < 65536
+        self.bnb_levels = 0 if not self.bnb else (int(lv_env) if lv_env in ("1", "2") else (2 if lidar.beams >= 512 and not lds_one_level else 1))
         if self.bnb_levels == 2 and self.nx < 17:
             self.bnb_levels = 1
         # angle bounds (Slam2dLevel.bnb == 3): a cube of <= 5 x 5 poses per angle is too small for pose tiles, but behind a long

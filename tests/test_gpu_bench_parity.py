@@ -165,12 +165,17 @@ def test_benchmarked_config2_matches_oracle(bench, variant, monkeypatch):
     assert bench.bench_groups(None, 64, sharded=True) == 2 and bench.bench_groups(None, 64, sharded=False) in (2, 4)
 
 
-def test_benchmarked_config5_slice_matches_oracle(bench):
+@pytest.mark.parametrize("bounds", ["lds_one_level", "two_level"])
+def test_benchmarked_config5_slice_matches_oracle(bench, bounds, monkeypatch):
     """The per-GPU slice of BASELINE config 5 as bench.py's `variants.config5` runs it: 128 particles, 2000^2 maps @ 0.05 m,
-    1081 beams, coarse 139 x 41 x 41 (two-level bounds) + fine 139 x 5 x 5; 4 distinct maps; three particles in
-    different XCD classes against the oracle (two-level matchScan, draw, update)."""
+    1081 beams, coarse 139 x 41 x 41 + fine 139 x 5 x 5; 4 distinct maps; three particles in different XCD classes against the
+    oracle (two-level matchScan, draw, update).  The coarse bounds as round 6 runs them (one level, the byte image staged in LDS,
+    the cell lists run-length compressed: k_bound_lds<2, true>) and as rounds 3-5 did (two levels: k_bound1 / k_seed / k_bound2)."""
+    if bounds == "two_level":
+        monkeypatch.setenv("SLAM2D_BNB_LEVELS", "2")
     hot = _run_against_oracle(bench, "config5", 128, [3, 70, 125], n_scans=1, n_worlds=4, groups=2)
-    assert hot.coarse.bnb and hot.coarse.bnb_levels == 2
+    assert hot.coarse.bnb and hot.coarse.bnb_levels == (2 if bounds == "two_level" else 1)
+    assert ("gmin2b" in hot.coarse.t) == (bounds != "two_level")
 
 
 def test_device_side_waits_are_bounded(bench):
