@@ -240,6 +240,9 @@ typedef struct {
     int32_t g2b_pitch;       /* row pitch of gmin2b in bytes: a multiple of 16, >= 4*tmax, (g2b_pitch / 4) mod 32 in [5, 13] or
                                 [19, 27] (the tile rows of a lane group then fall on distinct LDS banks) */
     int32_t reserved0;
+    double* theta_umax;      /* NULL, or [P][ntheta] (ABI 17, bnb == 1): the largest tile bound of every angle, written with `bounds` by k_bound /
+                                k_bound_lds; k_exact_select then reads the bounds only of angles that can hold a surviving tile
+                                (theta_umax >= bnb_best - margin): same list, a fraction of the loads */
 } Slam2dLevel;
 
 /* Result of one level for one particle. */

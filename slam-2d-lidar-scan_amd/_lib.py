@@ -100,7 +100,7 @@ class Slam2dLevel(C.Structure):
                 ("gmin", _vp), ("gmin2", _vp), ("pcells", _vp), ("bounds", _vp), ("tile_pmax", _vp), ("bnb_best", _vp),
                 ("gmin3d", _vp), ("p3cells", _vp), ("bounds1", _vp), ("seed_key", _vp),
                 ("beam_xy", _vp), ("sync", _vp), ("bnb", C.c_int32), ("ep_group", C.c_int32), ("occ_gen", C.c_int32), ("arrive", _vp),
-                ("gmin2b", _vp), ("g2b_pitch", C.c_int32), ("reserved0", C.c_int32)]
+                ("gmin2b", _vp), ("g2b_pitch", C.c_int32), ("reserved0", C.c_int32), ("theta_umax", _vp)]
 
 
 class Slam2dMatch(C.Structure):

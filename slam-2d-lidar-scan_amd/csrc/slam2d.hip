@@ -2352,6 +2352,7 @@ __global__ __launch_bounds__(64 * BOUND_GROUP) void k_bound(Slam2dLevel lv, int 
         }
     }
     me = wave_best_ordered(me);                             // tiles ascend with the lane
+    if (lv.theta_umax && lane == 0) lv.theta_umax[(size_t)p * lv.ntheta + it] = me.i != INT_MAX ? me.v : -INFINITY;
     DBG_CLOCK(2, b == 0);
     // the tile with the largest bound, exactly: its best score is a lower bound of the cube's maximum
     const int seed = me.i;
@@ -2441,6 +2442,9 @@ __device__ __forceinline__ void bound_seed_exact(const Slam2dLevel& lv, const in
 // more (a wave's second and third angles mostly find it raised by the first round's seeds): a seed's exact score cannot exceed
 // its bound, so the FINAL bnb_best is the maximum over all seeds whatever is skipped, in whatever order (k_bound2's rule).
 #define BL_BATCH 16
+#ifndef BL_RLE_BATCH
+#define BL_RLE_BATCH 8       // (runs of a 64-cell chunk: ~22 at config 5 -- batches of 16 waste a third of their gathers)
+#endif
 // RLE (long lists: ~1000 beams): neighbouring beams end in the same 4 x 4-cell block more often than not, so a wave's 64 cell offsets are
 // run-length compressed first (ballot of the run heads, the (offset, run length) pairs compacted through 256 bytes of LDS per wave)
 // and the gathers go over the runs: sum += entry x run length.
@@ -2492,6 +2496,8 @@ __global__ __launch_bounds__(1024) void k_bound_lds(Slam2dLevel lv, int P, int b
     // angles from the middle of the block's range outwards: the first round (which finds lv.bnb_best[p] at -inf and scores every
     // seed) then holds the angles nearest the estimate's, where a tracked pose has its maximum
     const int nth = it_end - it0, mid = (nth - 1) >> 1;
+    double seedU = -INFINITY;
+    int seedT = INT_MAX, seedIt = 0, seedK = 0;
     for (int j = w; j < nth; j += nw) {
         const int it = it0 + mid + ((j & 1) ? ((j + 1) >> 1) : -((j + 1) >> 1));
         const int K = lv.kcount[p * lv.ntheta + it];
@@ -2524,19 +2530,19 @@ __global__ __launch_bounds__(1024) void k_bound_lds(Slam2dLevel lv, int P, int b
                 }
                 const unsigned comp = lane < nu ? rl[lane] : 0u;                                    // (one wave: its LDS operations stay in order)
 #pragma unroll
-                for (int j0 = 0; j0 < WAVE; j0 += BL_BATCH) {
+                for (int j0 = 0; j0 < WAVE; j0 += BL_RLE_BATCH) {
                     if (j0 < nu) {                              // (wave-uniform)
-                        unsigned char v[NSET][BL_BATCH];
-                        unsigned cnt[BL_BATCH];
+                        unsigned char v[NSET][BL_RLE_BATCH];
+                        unsigned cnt[BL_RLE_BATCH];
 #pragma unroll
-                        for (int i = 0; i < BL_BATCH; ++i) {
+                        for (int i = 0; i < BL_RLE_BATCH; ++i) {
                             const unsigned so = (unsigned)__builtin_amdgcn_readlane((int)comp, j0 + i);
                             cnt[i] = so >> 16;
 #pragma unroll
                             for (int s = 0; s < NSET; ++s) v[s][i] = g2s[lbase[s] + (int)(so & 0xFFFFu)];
                         }
 #pragma unroll
-                        for (int i = 0; i < BL_BATCH; ++i)
+                        for (int i = 0; i < BL_RLE_BATCH; ++i)
 #pragma unroll
                             for (int s = 0; s < NSET; ++s) sum[s] += (unsigned)v[s][i] * cnt[i];
                     }
@@ -2578,12 +2584,25 @@ __global__ __launch_bounds__(1024) void k_bound_lds(Slam2dLevel lv, int P, int b
         if (lane < nbt)                                                     // padding tiles of every tile row: -inf
             for (int bx = nbt; bx < nbq4; ++bx) bnd[lane * nbq4 + bx] = -INFINITY;
         me = wave_best_fast(me);
+        if (lv.theta_umax && lane == 0) lv.theta_umax[(size_t)p * lv.ntheta + it] = me.i != INT_MAX ? me.v : -INFINITY;
         DBG_CLOCK(4, b == 0 && j == 0);
         if (me.i == INT_MAX) continue;
+        if (RLE) {
+            // long lists: a seed costs as much as the angle's bounds (16 poses x ~1000 cells: 17.8 us against 16.0 at config 5), and the
+            // looser byte bounds let few later seeds be skipped -- the wave scores ONE seed, that of its angle with the largest
+            // bound (the particle's largest bound is some wave's largest: the seed that matters is among them)
+            if (me.v > seedU || seedT == INT_MAX) { seedU = me.v; seedT = me.i; seedIt = it; seedK = K; }
+            continue;
+        }
         const unsigned long long best = __hip_atomic_load(&lv.bnb_best[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (!(me.v > unorder_bits(best))) continue;                         // (wave-uniform; bounds are never NaN: tile_pmax maps NaN to +inf)
         bound_seed_exact(lv, p, me.i >> 8, me.i & 255, lv.cells + ((size_t)p * lv.ntheta + it) * lv.kmax, K, inv);
         DBG_CLOCK(5, b == 0 && j == 0);
+    }
+    if (RLE && seedT != INT_MAX) {
+        const unsigned long long best = __hip_atomic_load(&lv.bnb_best[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seedU > unorder_bits(best))
+            bound_seed_exact(lv, p, seedT >> 8, seedT & 255, lv.cells + ((size_t)p * lv.ntheta + seedIt) * lv.kmax, seedK, inv);
     }
     DBG_CLOCK(14, b == 0);
 }
@@ -2945,10 +2964,17 @@ __global__ __launch_bounds__(XS_THREADS) void k_exact_select(Slam2dLevel lv, con
     const int per = (ntot + XS_THREADS - 1) / XS_THREADS;          // <= XS_MAX_PER (checked by the host)
     const int g0 = tid * per;
     unsigned keepbits = 0u;
-    for (int i = 0; i < per; ++i) {
-        const int g = g0 + i;
-        if (g < ntot && bnd[g] >= thr) keepbits |= 1u << i;        // (padding tiles hold -inf)
+    bool look = g0 < ntot;
+    if (look && lv.theta_umax && lv.bnb == 1) {        // only the angles whose largest bound reaches the threshold can hold a surviving tile
+        const double* __restrict__ um = lv.theta_umax + (size_t)p * lv.ntheta;
+        look = false;
+        for (int it = g0 / nt; it <= min(g0 + per - 1, ntot - 1) / nt; ++it) look |= um[it] >= thr;
     }
+    if (look)
+        for (int i = 0; i < per; ++i) {
+            const int g = g0 + i;
+            if (g < ntot && bnd[g] >= thr) keepbits |= 1u << i;    // (padding tiles hold -inf)
+        }
     // (a block that scores a quarter of the tiles reads the few lists it needs from global memory instead of staging them all)
     const bool cells_in_lds = (!SPLIT || XS_SPLIT_STAGE_CELLS) && lv.ntheta * lv.kmax <= XS_CELLS;
     if (cells_in_lds) {
@@ -4160,18 +4186,20 @@ static void launch_endpoints(const Slam2dLidar& lid, const Slam2dLevel& lv, int 
 static bool launch_bound_lds(const Slam2dLevel& lv, int P, hipStream_t s) {
     static const int mode = [] { const char* e = getenv("SLAM2D_BOUND_LDS"); return e ? atoi(e) : -1; }();
     static const int max_split = [] { const char* e = getenv("SLAM2D_BOUND_LDS_SPLIT"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4; }();
-    static const int want_blocks = [] { const char* e = getenv("SLAM2D_BOUND_LDS_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
+    static const int want_blocks_env = [] { const char* e = getenv("SLAM2D_BOUND_LDS_BLOCKS"); return e ? atoi(e) : 0; }();
     static const int rle_mode = [] { const char* e = getenv("SLAM2D_BOUND_LDS_RLE"); return e ? atoi(e) : -1; }();
     if (mode == 0 || !lv.gmin2b) return false;
     const int nx = 2 * lv.ncell + 1, nbt = (nx + 3) >> 2;
     const int nset = cdiv(nbt * nbt, WAVE);
     const int gp = lv.tmax << 2, lp = lv.g2b_pitch;
     if (nset > 4 || lv.kmax > 2048 || lp < gp || (lp & 15)) return false;
-    const int bpp = max(1, min(min(max_split, lv.ntheta), want_blocks / max(P, 1)));
-    const int tpb = cdiv(lv.ntheta, bpp);                       // angles per block
-    const int rounds = cdiv(tpb, 16), nw = cdiv(tpb, rounds);
     const size_t image = ((size_t)gp * lp + 15) & ~(size_t)15;
     const bool rle = (rle_mode < 0 ? lv.kmax >= SLAM2D_BEAM_TABLE_MIN : rle_mode != 0) && image + (size_t)nbt * lp < 65536;   // (16-bit offsets in the run words)
+    // (long lists: an angle is 16 us of one wave -- 256 blocks: config 5's 64-particle launches, 139 angles, four blocks per particle)
+    const int blocks = want_blocks_env > 0 ? want_blocks_env : (rle ? 256 : 128);
+    const int bpp = max(1, min(min(max_split, lv.ntheta), blocks / max(P, 1)));
+    const int tpb = cdiv(lv.ntheta, bpp);                       // angles per block
+    const int rounds = cdiv(tpb, 16), nw = cdiv(tpb, rounds);
     const size_t lds = image + (rle ? (size_t)nw * WAVE * sizeof(unsigned) : 0);
     const size_t want = 160 * 1024 - 512;
     if (lds > want) return false;

@@ -698,7 +698,8 @@ class SearchLevel:
             )
             if self.bnb_levels == 1:    # the bounds' byte image for k_bound_lds (one block per particle stages it in LDS)
                 self.g2b_pitch = g2b_pitch(4 * self.tmax)
-                t.update(gmin2b=torch.zeros((P, 4 * self.tmax, self.g2b_pitch), dtype=torch.uint8, device=device))
+                t.update(gmin2b=torch.zeros((P, 4 * self.tmax, self.g2b_pitch), dtype=torch.uint8, device=device),
+                         theta_umax=torch.zeros((P, self.ntheta), dtype=f64, device=device))
             if self.bnb_levels == 2:    # long cell lists: 8x8-pose tiles first
                 t.update(
                     gmin3d=torch.zeros((P, 4, 2 * self.tmax, 2 * self.tmax), dtype=i32, device=device),
@@ -723,13 +724,13 @@ class SearchLevel:
             ring_cap=self.nx * ((self.nx + 3) // 4), bnb=self.bnb_levels, ep_group=self.ep_group, beam_xy=t["beam_xy"].data_ptr(),
             sync=t["sync"].data_ptr(),
             **({k: t[k].data_ptr() for k in ("gmin3d", "p3cells", "bounds1", "seed_key")} if self.bnb_levels == 2 else {}),
-            **(dict(gmin2b=t["gmin2b"].data_ptr(), g2b_pitch=self.g2b_pitch) if "gmin2b" in t else {}),
+            **(dict(gmin2b=t["gmin2b"].data_ptr(), g2b_pitch=self.g2b_pitch, theta_umax=t["theta_umax"].data_ptr()) if "gmin2b" in t else {}),
             **({k: t[k].data_ptr() for k in ("gmin", "gmin2", "pcells", "bounds", "bnb_best", "seed_key")} if self.abound else {}),
             **({k: t[k].data_ptr() for k in ("gmin", "gmin2", "pcells", "bounds", "tile_pmax", "bnb_best")} if self.bnb else {}))
 
     _PER_PARTICLE = ("frames", "axis_x", "axis_y", "field", "cells", "kcount", "prior", "cube", "partials", "tilestate", "tilemin",
                      "tilemax", "tilelist", "tilecount", "tileneed", "freerow", "prune_state", "beam_xy", "sync", "gmin", "gmin2",
-                     "pcells", "bounds", "tile_pmax", "bnb_best", "gmin3d", "p3cells", "bounds1", "seed_key", "gmin2b")
+                     "pcells", "bounds", "tile_pmax", "bnb_best", "gmin3d", "p3cells", "bounds1", "seed_key", "gmin2b", "theta_umax")
 
     def view(self, p0, p1):
         """A Slam2dLevel describing particles [p0, p1) of this level: the same parameters, every per-particle pointer advanced to
