@@ -3,7 +3,7 @@
 cd ${GRAFT_REPO_ROOT:-$PWD}
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 run () {
-  env "$@" python bench.py --workload config3 --particles ${P:-64} 2>/tmp/err.txt | python -c "
+  env "$@" python bench.py --workload config3 --particles ${P:-64} --resample-every ${RE:-100} 2>/tmp/err.txt | python -c "
 import sys, json
 for line in sys.stdin:
     if line.startswith('{'):
