@@ -964,10 +964,10 @@ def config3_closed_loop(P, device):
         pf.updateParticles(raw, count)
         pf.weightUnbalanced()
     def leg(force=(), groups=None, P=P):
-        # (the previous leg's filter sits in a reference cycle -- its particle views point back at it -- and its 1.6 GB of maps stay
-        # allocated until the cyclic collector runs: whether it had run decided whether this leg's 143 growth re-allocations were
-        # served from torch's cache or by ~67 hipMalloc calls of ~1.2 ms each, the "slow legs" of round 5 (0.28 s against 0.20 s).
-        # Collected here, every timed leg runs on a warm cache; the cold figure is the first leg's, reported beside it)
+        # (the previous leg's filter sits in a reference cycle -- its particle views point back at it -- so its 1.6 GB of maps, its
+        # streams and events live until Python's cyclic collector happens to run: inside this timed leg, or not at all -- then this
+        # leg's growth re-allocations miss torch's cache.  The "slow legs" of round 5, 0.28 s against 0.20 s, were the ones with
+        # 67-68 device allocations.  Collected here, every timed leg runs alike; the cold figure is the first leg's)
         import gc
         gc.collect()
         pf = pkg.ParticleFilter(P, ogP, smP, device=device, rng=np.random.RandomState(0), groups=groups)

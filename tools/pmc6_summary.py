@@ -109,6 +109,7 @@ def write_profiles(tag, rnd):
         shutil.copy(fs[0], os.path.join(ROOT, f"profiles/{rnd}_{tag}_kernel_stats.csv"))
     t, m, dur = table(tag)
     wl, p = tag.rsplit("_p", 1)
+    p = p.split("_")[0]                                     # (a tag suffix behind the particle count: config2_p256_final)
     sha = hashlib.sha256(open(os.path.join(ROOT, "slam-2d-lidar-scan_amd/csrc/slam2d.hip"), "rb").read()).hexdigest()[:16]
     # standalone durations: the counter passes serialise the kernels (one group's launch at a time)
     alone = collections.defaultdict(list)
