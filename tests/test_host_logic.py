@@ -442,3 +442,22 @@ def test_auto_groups_follow_particles_and_cores(monkeypatch):
     assert [auto(p, sharded=True) for p in (3, 15, 16, 64, 65, 256)] == [1, 1, 2, 2, 1, 2]
     pol["threads"] = False
     assert [auto(p) for p in (16, 64, 256)] == [1, 1, 1] and auto(64, sharded=True) == 1
+
+
+def test_bound_image_pitch_keeps_tile_rows_on_distinct_lds_banks():
+    """engine.g2b_pitch (Slam2dLevel.g2b_pitch): a multiple of 16 bytes (the image is staged with 16-byte copies), >= the row, and its
+    dword stride mod 32 leaves the three 11-byte tile rows a 32-lane group of k_bound_lds reads (4 dwords each, any byte phase) on
+    distinct banks -- for every tile-grid size a level can have."""
+    import importlib
+    E = importlib.import_module("slam-2d-lidar-scan_amd.engine")
+    for tmax in range(4, 140):
+        gp = 4 * tmax
+        pitch = E.g2b_pitch(gp)
+        assert pitch % 16 == 0 and gp <= pitch < gp + 128
+        sd = (pitch // 4) % 32
+        for phase in range(4):                                  # byte phase of the window's first column inside its dword
+            for nbt in (11, 16):
+                ndw = (phase + nbt + 3) // 4                    # dwords a tile row spans
+                rows = -(-32 // nbt)
+                banks = [(r * sd + k) % 32 for r in range(rows) for k in range(ndw)]
+                assert len(set(banks)) == len(banks), (tmax, pitch, phase, nbt)
