@@ -4378,7 +4378,12 @@ int slam2d_match(const Slam2dLidar* lidar, const Slam2dLevel* level, const Slam2
     // Below SLAM2D_BEAM_TABLE_MIN beams k_frame_axis is not launched at all: the endpoint kernel's per-particle block does
     // its work (one launch less per level); above, k_frame_axis also tabulates the beam endpoints once per particle.
     static const bool keep_frame_kernel = [] { const char* e = getenv("SLAM2D_FRAME_KERNEL"); return e && atoi(e) == 1; }();
-    const bool framed = lidar->beams >= SLAM2D_BEAM_TABLE_MIN || keep_frame_kernel || lv.occ_gen == 0;
+    // ... from SLAM2D_FRAME_MIN_P particles per launch as well (round 6): the merged launch makes every angle block evaluate the
+    // cos / sin of all beams and every scatter block the frame; when the launch fills the machine that work costs more than the
+    // two launches it saves (config 2: k_endpoints 57 -> 27 + 26 us at 128 particles per launch, the step 0.309 -> 0.305 ms; at 256
+    // per launch 0.580 -> 0.561; at 16 per launch the two launches cost 0.113 -> 0.123)
+    static const int frame_min_p = [] { const char* e = getenv("SLAM2D_FRAME_MIN_P"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
+    const bool framed = lidar->beams >= SLAM2D_BEAM_TABLE_MIN || keep_frame_kernel || lv.occ_gen == 0 || P >= frame_min_p;
     const Slam2dMap* own = framed ? nullptr : d_maps;
     // ... and then the occupied-cell scatter rides in the endpoint launch as well (SLAM2D_MERGE_SCATTER=0: its own launch)
     static const bool merge_scatter = [] { const char* e = getenv("SLAM2D_MERGE_SCATTER"); return !e || atoi(e) != 0; }();
