@@ -67,7 +67,10 @@ extern "C" {
 #define SLAM2D_F_UPDATE_OUTSIDE_MAP 0x08u  /* map update touched a cell outside the map */
 #define SLAM2D_F_COUNT_OVERFLOW     0x10u  /* a 16-bit count would overflow */
 #define SLAM2D_F_FLOOR_REDO         0x20u  /* informational: field minimum != analytic floor, clamp pass redone */
-#define SLAM2D_F_SYNC_TIMEOUT       0x40u  /* a device-side wait of the groups' normaliser (d_norm_sync) gave up after 2 s */
+#define SLAM2D_F_SYNC_TIMEOUT       0x40u  /* a device-side wait of the groups' normaliser / gates (d_norm_sync) gave up after its bound */
+#define SLAM2D_F_SCAN_VOIDED        0x80u  /* informational, in a voided scan's fault-bit SNAPSHOT only (never in d_flags): the commit did nothing
+                                              on the device (abort_mask).  With SLAM2D_F_SYNC_TIMEOUT beside it the scan is intact and may be
+                                              run again (the gate gave up BEFORE anything was written); without this bit a timeout is fatal */
 
 #define SLAM2D_INIT_CELL 0x00010002u       /* visited = 1, total = 2 */
 #define SLAM2D_MAX_BLUR_RADIUS 16

@@ -25,6 +25,7 @@ F_UPDATE_OUTSIDE_MAP = 0x08
 F_COUNT_OVERFLOW = 0x10
 F_FLOOR_REDO = 0x20
 F_SYNC_TIMEOUT = 0x40
+F_SCAN_VOIDED = 0x80           # (snapshot only: the commit was a no-op on the device)
 FATAL_FLAGS = F_WINDOW_OUTSIDE_MAP | F_FIELD_INDEX | F_ENDPOINT_OUTSIDE | F_UPDATE_OUTSIDE_MAP | F_COUNT_OVERFLOW | F_SYNC_TIMEOUT
 FLAG_NAMES = {
     F_WINDOW_OUTSIDE_MAP: "search window outside the map (grow the map first)",

@@ -3596,7 +3596,7 @@ __global__ __launch_bounds__(256, UPDB_MIN_WAVES) void k_grid_update(Slam2dLidar
         for (int i = threadIdx.x; i < an; i += blockDim.x) bad |= (af[i] & am) != 0u;
         if (__syncthreads_or(bad)) {
             if (blockIdx.x == 0 && wj.flag_snapshot)
-                for (int i = threadIdx.x; i < wj.N; i += blockDim.x) wj.flag_snapshot[i] = flags[i];
+                for (int i = threadIdx.x; i < wj.N; i += blockDim.x) wj.flag_snapshot[i] = flags[i] | SLAM2D_F_SCAN_VOIDED;
             // ... except that the report receives the COARSE matched poses: the host grows the maps for the fine windows round
             // them (Utils/ScanMatcher_OGBased.py:27 at the fine level) before it issues the scan again
             if (blockIdx.x == 0 && wj.report && wj.coarse)

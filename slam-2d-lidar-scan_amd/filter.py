@@ -415,10 +415,20 @@ class ParticleFilter:
         abortable = self.growable and (not self.sharded or (grouped and self._grp.devsync))
         abort_mask = _lib.F_WINDOW_OUTSIDE_MAP if abortable else 0
 
+        sync_tripped = [False]
+
         def was_aborted(p):
             """Wait for scan p's report; True if its commit was a no-op on the device (a window had left a map)."""
             p[3].synchronize()
-            if abortable and (self._h_flagsnap.numpy().view(np.uint32) & abort_mask).any():
+            snap = self._h_flagsnap.numpy().view(np.uint32)
+            if abortable and (snap & abort_mask).any():
+                return True
+            if abortable and (snap & _lib.F_SCAN_VOIDED).any() and (snap & _lib.F_SYNC_TIMEOUT).any():
+                # a commit's gate gave up waiting for the match's arrivals (a device-side wait ran into its bound: the groups' queues
+                # starved behind another process, a debugger, a hung peer) BEFORE anything of the scan was written: the scan is intact.
+                # It is run again through the calls that wait for nothing on the device, and the sync words start afresh.
+                self.stats["sync_timeouts"] = self.stats.get("sync_timeouts", 0) + 1
+                sync_tripped[0] = True
                 return True
             if self.sharded and abortable:
                 while np.isnan(self._h_pack.numpy()[6 * P]) and self._h_pack.numpy()[6 * P + 1] == -1.0:
@@ -469,6 +479,12 @@ class ParticleFilter:
                 torch.cuda.synchronize(self.device)
                 self._grp.flags2.zero_()
                 self._grp.active = False
+                if sync_tripped[0] and self._grp.devsync:          # (every stream is idle: the counters and tickets start from zero again)
+                    bound = int(self._grp.sync[59].item())
+                    self._grp.sync.zero_()
+                    self._grp.sync[59] = bound
+                    self._grp.gate_seq = 0
+                    torch.cuda.synchronize(self.device)
             else:
                 torch.cuda.current_stream().synchronize()
                 eng.flags.zero_()
@@ -544,7 +560,10 @@ class ParticleFilter:
                     p, pending = pending, None
                     self.stats["redo"] += 1
                     tries = retried[1] if retried[0] == p[0] else 0
-                    if reissue and tries < 2:
+                    if sync_tripped[0]:                        # a gate's timeout: this scan and its successor through the waiting-free calls
+                        redo_aborted(p)
+                        sync_tripped[0] = False
+                    elif reissue and tries < 2:
                         self.stats["aborted"] = self.stats.get("aborted", 0) + 1
                         coarse_xy = self._h_pack.numpy()[:5 * P].reshape(P, 5)[:, :2].copy()     # (a voided commit reports the coarse poses)
                         discard_speculation(p[4])

@@ -1748,3 +1748,37 @@ def test_large_launches_take_the_frame_kernel_and_agree_with_small_ones(pkg):
             fh, fw = a.shape
             mask = np.kron(na, np.ones((16, 16), dtype=bool))[:fh, :fw]
             assert mask.any() and np.array_equal(a[mask], b[mask])
+
+
+def test_a_gate_timeout_is_survived(pkg, intel_readings, monkeypatch):
+    """A device-side wait that runs into its bound (here: the commit's gate, made to wait for match arrivals that never come by
+    taking some away behind the filter's back, twice in a run; bound 0.3 s) must not end the run: the gate voids the scan before
+    anything is written (the report carries SLAM2D_F_SCAN_VOIDED | SLAM2D_F_SYNC_TIMEOUT), the driver runs that scan and its successor
+    through the calls that wait for nothing on the device, resets the sync words and goes on in groups -- and the whole 910-scan
+    golden run still comes out pose for pose, draw for draw."""
+    import hashlib
+    monkeypatch.setenv("SLAM2D_SYNC_TIMEOUT_MS", "300")
+    z = load_golden("flow_fastslam_long.npz")
+    n_particles, n_scans, seed, map_m = (int(v) for v in z["cfg"])
+    u = 0.02
+    ogP = [map_m, map_m, intel_readings[0], u, np.pi, 10, 180, 5 * u]
+    pf = pkg.ParticleFilter(n_particles, ogP, list(REF_SM), rng=np.random.RandomState(seed), groups=3)
+    seen = []
+
+    def on_scan(count, f, unb):
+        assert unb == bool(z["unbalanced"][count - 1]), f"scan {count}"
+        np.testing.assert_allclose(f.weights, z["weights"][count - 1], rtol=RTOL, atol=1e-290, err_msg=f"scan {count}")
+        assert np.array_equal(f.prev_matched, z["matched"][count - 1]), f"scan {count}"
+        seen.append(count)
+        if count in (200, 600) and f._grp is not None:
+            f._grp.sync[61] -= 2                      # two arrivals fewer than the next gates will wait for
+    resamples = pf.run(intel_readings[:n_scans], force_resample=set(int(v) for v in z["force_resample"]), on_scan=on_scan)
+    assert seen == list(range(1, n_scans + 1))
+    assert pf.stats.get("sync_timeouts", 0) >= 1, pf.stats
+    assert pf._grp.devsync and pf.n_groups == 3
+    got = np.array([np.concatenate(([c], idx)) for c, idx in resamples]).reshape(-1, n_particles + 1)
+    assert np.array_equal(got, z["resamples"])
+    for p, m, sha, lim in zip(pf.particles, pf.engine.maps, z["maps_sha"], z["final_lims"]):
+        assert [m.lim_x[0], m.lim_x[1], m.lim_y[0], m.lim_y[1]] == list(lim)
+        packed = codec.pack_counts(p.og.occupancyGridVisited, p.og.occupancyGridTotal)
+        assert hashlib.sha256(packed.tobytes()).digest() == sha.tobytes()
