@@ -174,8 +174,10 @@ def test_benchmarked_config5_slice_matches_oracle(bench, bounds, monkeypatch):
     if bounds == "two_level":
         monkeypatch.setenv("SLAM2D_BNB_LEVELS", "2")
     hot = _run_against_oracle(bench, "config5", 128, [3, 70, 125], n_scans=1, n_worlds=4, groups=2)
-    assert hot.coarse.bnb and hot.coarse.bnb_levels == (2 if bounds == "two_level" else 1)
-    assert ("gmin2b" in hot.coarse.t) == (bounds != "two_level")
+    import os
+    two = bounds == "two_level" or os.environ.get("SLAM2D_BOUND_LDS") == "0"         # (without the LDS path long lists keep two levels)
+    assert hot.coarse.bnb and hot.coarse.bnb_levels == (2 if two else 1)
+    assert ("gmin2b" in hot.coarse.t) == (not two)
 
 
 def test_device_side_waits_are_bounded(bench):
