@@ -10,6 +10,7 @@ this class handles the particles of one rank.
 import ctypes as C
 import math
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -22,7 +23,9 @@ class ParticleView:
     """What the reference's callers read from a particle (Algorithm/FastSlam.py:164-177)."""
 
     def __init__(self, pf, i):
-        self._pf, self._i = pf, i
+        # (a weak reference: the filter owns its views, and a cycle would keep gigabytes of maps alive until the cyclic collector
+        # happens to run -- bench.py's "slow legs" of round 5)
+        self._pf, self._i = weakref.proxy(pf), i
 
     @property
     def weight(self):
@@ -48,7 +51,7 @@ class ParticleView:
 
 class MapView:
     def __init__(self, pf, i):
-        self._pf, self._m = pf, pf.engine.maps[i]
+        self._pf, self._m = pf, pf.engine.maps[i]           # (short-lived: made per access by ParticleView.og)
 
     @property
     def occupancyGridVisited(self):
