@@ -2042,12 +2042,18 @@ __global__ __launch_bounds__(64) void k_sweep_small(Slam2dLevel lv, int P, int p
 #ifndef ABOUND_STRIDE
 #define ABOUND_STRIDE 1
 #endif
-__global__ __launch_bounds__(64) void k_abound(Slam2dLevel lv, int P) {
+// (ABOUND_WAVES angles per block: a launch of one-wave blocks pays ~4.5 ns of dispatch per block whatever they do -- 8 896 blocks at
+// config 5, 40-50 us for ten gathers per wave; round 6)
+#ifndef ABOUND_WAVES
+#define ABOUND_WAVES 16
+#endif
+__global__ __launch_bounds__(64 * ABOUND_WAVES) void k_abound(Slam2dLevel lv, int P) {
     const int b = blockIdx.x;
+    const int ngrp = (lv.ntheta + ABOUND_WAVES - 1) / ABOUND_WAVES;
     const int xcd = b & 7, slot = b >> 3;
-    const int p = (slot / lv.ntheta) * 8 + xcd, it = slot % lv.ntheta;
-    if (p >= P) return;
-    const int lane = threadIdx.x;
+    const int p = (slot / ngrp) * 8 + xcd, it = (slot % ngrp) * ABOUND_WAVES + (threadIdx.x >> 6);
+    if (p >= P || it >= lv.ntheta) return;
+    const int lane = threadIdx.x & 63;
     const int nx = 2 * lv.ncell + 1, npose = nx * nx;
     const int gp = lv.tmax << 2;
     const int K = lv.kcount[p * lv.ntheta + it];
@@ -4305,7 +4311,7 @@ static int launch_scores(const Slam2dLevel& lv, int P, const double* d_est, int 
         const int pruned = lv.bnb == 3 ? 1 : 0;
         if (pruned) {                                                     // angle bounds first, then one exact seed per particle
             StageScope prof(SLAM2D_STAGE_BOUND, s);
-            k_abound<<<grid, WAVE, 0, s>>>(lv, P);
+            k_abound<<<(unsigned)cdiv(P, 8) * 8 * cdiv(lv.ntheta, ABOUND_WAVES), WAVE * ABOUND_WAVES, 0, s>>>(lv, P);
             k_aseed<<<P, WAVE * ASEED_WAVES, (size_t)ASEED_WAVES * WAVE * 4 * sizeof(unsigned long long) + (size_t)lv.kmax * sizeof(int), s>>>(lv, P);
         }
         {
